@@ -1,0 +1,798 @@
+// axial_core.hip -- the L x L stages of the axial-attention layer, fused.
+//
+// Replaces, per (sequence b, head g) of reference lib/models/axialnet.py:
+//   :155-159  index_select + 3 einsums (qk, qr, kr)          -> recomputed in registers, never stored
+//   :163-167  gates, cat, BatchNorm2d(3G) on (B*,3G,L,L)     -> statistics pass + affine inside the main pass
+//   :170-176  softmax, sv / sve einsums, gates               -> same pass, row per lane
+//   :178      cat(sv,sve).view                               -> interleaved channel store
+// and the autograd backward of all of it (two recompute passes around the
+// bn_similarity backward barrier).
+//
+// Work decomposition (gfx950, wave64): one 256-thread workgroup owns S_T = 256/L whole
+// sequences of one head; thread t owns query row i = t % L of sequence t / L ("row per lane":
+// softmax max/sum and the P.V products need no cross-lane traffic).  q/k/v of the tile are
+// staged once through LDS (coalesced along whichever of (sequence, position) is contiguous in
+// NCHW), bn_qkv's affine is applied in place, keys/values are then read as LDS broadcasts and
+// the three relative tables by a skewed index d = i - j + L - 1 (consecutive lanes ->
+// consecutive addresses).  All tensors stay NCHW: the reference's permute+contiguous copies
+// (:143-148, :181-184) become address arithmetic.
+#include "medt_kernels.h"
+
+namespace medt {
+
+// --------------------------------------------------------------------------- //
+// geometry
+// --------------------------------------------------------------------------- //
+int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
+    if (d.N <= 0 || d.C <= 0 || d.H <= 0 || d.W <= 0 || d.G <= 0 || d.C % d.G) {
+        set_error("axial: bad shape N=%d C=%d H=%d W=%d G=%d", d.N, d.C, d.H, d.W, d.G);
+        return MEDT_EINVAL;
+    }
+    if (d.bn_groups < 1 || d.N % d.bn_groups || (d.stride != 1 && d.stride != 2) || (d.axis != 0 && d.axis != 1)) {
+        set_error("axial: bad bn_groups=%d / stride=%d / axis=%d", d.bn_groups, d.stride, d.axis);
+        return MEDT_EINVAL;
+    }
+    const int gp = d.C / d.G;
+    if (gp != 2 && gp != 4 && gp != 8 && gp != 16) {
+        set_error("axial: group_planes=%d not in {2,4,8,16}", gp);
+        return MEDT_EUNSUPPORTED;
+    }
+    g->N = d.N; g->C = d.C; g->H = d.H; g->W = d.W; g->G = d.G; g->gp = gp; g->hq = gp / 2;
+    g->axis = d.axis; g->pos = d.has_pos ? 1 : 0;
+    g->L = d.axis ? d.W : d.H;
+    g->Bo = d.axis ? d.H : d.W;
+    if (g->L > MEDT_THREADS) {
+        set_error("axial: sequence length %d > %d unsupported", g->L, MEDT_THREADS);
+        return MEDT_EUNSUPPORTED;
+    }
+    g->OC = g->pos ? 2 * d.C : d.C;
+    g->OCg = g->pos ? 2 * gp : gp;
+    g->SC = g->pos ? 3 * d.G : d.G;
+    g->groups = d.bn_groups;
+    g->npg = d.N / d.bn_groups;
+    g->spg = g->npg * g->Bo;
+    g->S_T = MEDT_THREADS / g->L;
+    g->tpg = cdiv(g->spg, g->S_T);
+    g->HW = d.H * d.W;
+    g->sim_count = (double)g->spg * g->L * g->L;
+    g->row_count = (double)g->spg * g->L;
+    return MEDT_OK;
+}
+
+static inline int region_stride(const AxialGeom& g) { return (2 * g.gp + 1) * g.L + 1; }
+
+size_t axial_core_lds_bytes(const AxialGeom& g, bool backward) {
+    const int TL = 2 * g.L - 1;
+    size_t fl = (size_t)g.S_T * region_stride(g) + 256;                       // qkv region + reduction scratch
+    if (g.pos) fl += (size_t)2 * g.gp * TL;                                   // tables
+    if (backward) {
+        fl += (size_t)g.S_T * (2 * g.gp * g.L + 1);                           // stacked -> dsv|dsve
+        fl += (size_t)g.S_T * ((g.gp + 2) * g.L + 1);                         // dy, lse, delta
+        if (g.pos) fl += (size_t)2 * g.gp * TL;                               // table-gradient accumulators
+    }
+    return fl * sizeof(float);
+}
+
+// --------------------------------------------------------------------------- //
+// tile movers: (channel, sequence, position) <-> NCHW
+// --------------------------------------------------------------------------- //
+struct TileCtx {
+    int L, Bo, W, HW, seq0, nseq;
+};
+
+// lds[ls*stride + (lch0+ch)*L + i] = src[n][ch0+ch][pixel(seq0+ls, i)]
+template <int AXIS>
+__device__ __forceinline__ void tile_load(float* lds, int stride, int lch0, const float* __restrict__ src, int CH,
+                                          int ch0, int nch, const TileCtx& t) {
+    const int per = t.nseq * t.L;
+    for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
+        const int ch = e / per, r = e - ch * per;
+        int ls, i;
+        if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
+        const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
+        const size_t off = ((size_t)n * CH + ch0 + ch) * t.HW + (AXIS == 1 ? s * t.W + i : i * t.W + s);
+        lds[ls * stride + (lch0 + ch) * t.L + i] = src[off];
+    }
+}
+
+template <int AXIS>
+__device__ __forceinline__ void tile_store(const float* lds, int stride, int lch0, float* __restrict__ dst, int CH,
+                                           int ch0, int nch, const TileCtx& t) {
+    const int per = t.nseq * t.L;
+    for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
+        const int ch = e / per, r = e - ch * per;
+        int ls, i;
+        if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
+        const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
+        const size_t off = ((size_t)n * CH + ch0 + ch) * t.HW + (AXIS == 1 ? s * t.W + i : i * t.W + s);
+        dst[off] = lds[ls * stride + (lch0 + ch) * t.L + i];
+    }
+}
+
+// pooled gradient: lds <- dy[n][ch0+ch][h/stride][w/stride] (0 outside the pooled extent)
+template <int AXIS>
+__device__ __forceinline__ void tile_load_pooled(float* lds, int stride, int lch0, const float* __restrict__ dy, int C,
+                                                 int ch0, int nch, int H, int pool, const TileCtx& t) {
+    const int per = t.nseq * t.L;
+    const int Ho = H / pool, Wo = t.W / pool;
+    for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
+        const int ch = e / per, r = e - ch * per;
+        int ls, i;
+        if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
+        const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
+        const int h = AXIS == 1 ? s : i, w = AXIS == 1 ? i : s;
+        const int ho = h / pool, wo = w / pool;
+        float v = 0.f;
+        if (ho < Ho && wo < Wo) v = dy[((size_t)(n * C + ch0 + ch) * Ho + ho) * Wo + wo];
+        lds[ls * stride + (lch0 + ch) * t.L + i] = v;
+    }
+}
+
+__device__ __forceinline__ float gate(const float* p) { return p ? *p : 1.f; }
+
+// --------------------------------------------------------------------------- //
+// forward statistics pass: sum / sum-of-squares of qk, f_qr*qr, f_kr*kr per head
+// --------------------------------------------------------------------------- //
+template <int GP, bool POS, int AXIS>
+__global__ __launch_bounds__(MEDT_THREADS) void logit_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
+                                                                   BnStats qs, const float* __restrict__ relative,
+                                                                   GatePtrs gates, float* __restrict__ partials) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = g.L, TL = 2 * L - 1, RS = (NCH + 1) * L + 1;
+    float* reg = smem;
+    float* red = reg + g.S_T * RS;
+    float* tq = red + 256;
+    float* tk = tq + HQ * TL;
+    const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
+    TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
+    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, GP, t);          // q and k channels only
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
+    if (POS) {
+        for (int e = threadIdx.x; e < HQ * TL; e += MEDT_THREADS) {
+            const int c = e / TL, d = e - c * TL;
+            tq[e] = relative[c * TL + d];
+            tk[e] = relative[(HQ + c) * TL + (TL - 1 - d)];
+        }
+    }
+    __syncthreads();
+    const int ls = threadIdx.x / L, i = threadIdx.x - ls * L;
+    const bool active = ls < t.nseq;
+    const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
+    const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
+    if (active) {
+#pragma unroll
+        for (int ch = 0; ch < GP; ++ch) {
+            const int idx = ls * RS + ch * L + i;
+            reg[idx] = fmaf(reg[idx], sc[ch], sh[ch]);
+        }
+    }
+    __syncthreads();
+    float acc[POS ? 6 : 2];
+#pragma unroll
+    for (int k = 0; k < (POS ? 6 : 2); ++k) acc[k] = 0.f;
+    if (active) {
+        float q[HQ];
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) q[c] = reg[ls * RS + c * L + i];
+        const float* kp = reg + ls * RS + HQ * L;
+        for (int j = 0; j < L; ++j) {
+            const int d = i - j + L - 1;
+            float tqk = 0.f, rq = 0.f, rk = 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                const float kc = kp[c * L + j];
+                tqk = fmaf(q[c], kc, tqk);
+                if (POS) {
+                    rq = fmaf(q[c], tq[c * TL + d], rq);
+                    rk = fmaf(kc, tk[c * TL + d], rk);
+                }
+            }
+            acc[0] += tqk;
+            acc[1] = fmaf(tqk, tqk, acc[1]);
+            if (POS) {
+                const float a = f_qr * rq, b = f_kr * rk;
+                acc[2] += a;
+                acc[3] = fmaf(a, a, acc[3]);
+                acc[4] += b;
+                acc[5] = fmaf(b, b, acc[5]);
+            }
+        }
+    }
+    // partial layout [grp][tile][SC][2], channel x*G + hg
+    float* dst = partials + ((size_t)blockIdx.x * g.SC + hg) * 2;
+    float tmp[POS ? 6 : 2];
+#pragma unroll
+    for (int k = 0; k < (POS ? 6 : 2); ++k) tmp[k] = acc[k];
+    // block_sum writes dst[k*stride]; channels are G apart -> do the three pairs by hand
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < (POS ? 6 : 2); ++k) {
+        const float s = wave_sum(tmp[k]);
+        if (lane == 0) red[wave * 6 + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < (POS ? 6 : 2)) {
+        const int k = threadIdx.x;
+        const float s = (red[k] + red[6 + k]) + (red[12 + k] + red[18 + k]);
+        dst[(size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// forward main pass
+// --------------------------------------------------------------------------- //
+template <int GP, bool POS, int AXIS>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
+                                                                BnStats qs, BnStats ss,
+                                                                const float* __restrict__ relative, GatePtrs gates,
+                                                                float* __restrict__ stacked, float* __restrict__ lse_out,
+                                                                float* __restrict__ out_partials) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = POS ? 2 * GP : GP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = g.L, TL = 2 * L - 1, RS = (NCH + 1) * L + 1;
+    float* reg = smem;
+    float* red = reg + g.S_T * RS;
+    float* tq = red + 256;
+    float* tk = tq + HQ * TL;
+    float* tv = tk + HQ * TL;
+    const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
+    TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
+    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t);
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
+    const float a_qr = POS ? ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E : 0.f;
+    const float a_kr = POS ? ss.scale[grp * g.SC + 2 * g.G + hg] * f_kr * MEDT_LOG2E : 0.f;
+    if (POS) {
+        for (int e = threadIdx.x; e < HQ * TL; e += MEDT_THREADS) {
+            const int c = e / TL, d = e - c * TL;
+            tq[e] = relative[c * TL + d];
+            tk[e] = a_kr * relative[(HQ + c) * TL + (TL - 1 - d)];
+        }
+        for (int e = threadIdx.x; e < GP * TL; e += MEDT_THREADS) tv[e] = relative[GP * TL + e];
+    }
+    __syncthreads();
+    const int ls = threadIdx.x / L, i = threadIdx.x - ls * L;
+    const bool active = ls < t.nseq;
+    const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
+    const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
+    if (active) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int idx = ls * RS + ch * L + i;
+            reg[idx] = fmaf(reg[idx], sc[ch], sh[ch]);
+        }
+    }
+    __syncthreads();
+    float outv[OCG];
+    float lse = 0.f;
+#pragma unroll
+    for (int k = 0; k < OCG; ++k) outv[k] = 0.f;
+    if (active) {
+        float qa[HQ], qb[HQ];
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) {
+            const float q = reg[ls * RS + c * L + i];
+            qa[c] = q * a_qk;
+            qb[c] = q * a_qr;
+        }
+        const float* kp = reg + ls * RS + HQ * L;
+        const float* vp = reg + ls * RS + GP * L;
+        float m = -INFINITY;
+        for (int j = 0; j < L; ++j) {
+            const int d = i - j + L - 1;
+            float z = 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                const float kc = kp[c * L + j];
+                z = fmaf(qa[c], kc, z);
+                if (POS) {
+                    z = fmaf(qb[c], tq[c * TL + d], z);
+                    z = fmaf(kc, tk[c * TL + d], z);
+                }
+            }
+            m = fmaxf(m, z);
+        }
+        float l = 0.f, accv[GP], acce[GP];
+#pragma unroll
+        for (int c = 0; c < GP; ++c) { accv[c] = 0.f; acce[c] = 0.f; }
+        for (int j = 0; j < L; ++j) {
+            const int d = i - j + L - 1;
+            float z = 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                const float kc = kp[c * L + j];
+                z = fmaf(qa[c], kc, z);
+                if (POS) {
+                    z = fmaf(qb[c], tq[c * TL + d], z);
+                    z = fmaf(kc, tk[c * TL + d], z);
+                }
+            }
+            const float p = __builtin_amdgcn_exp2f(z - m);
+            l += p;
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                accv[c] = fmaf(p, vp[c * L + j], accv[c]);
+                if (POS) acce[c] = fmaf(p, tv[c * TL + d], acce[c]);
+            }
+        }
+        const float inv = 1.f / l;
+        lse = m + __log2f(l);
+#pragma unroll
+        for (int c = 0; c < GP; ++c) {
+            if (POS) {
+                outv[2 * c] = f_sv * accv[c] * inv;
+                outv[2 * c + 1] = f_sve * acce[c] * inv;
+            } else {
+                outv[c] = accv[c] * inv;
+            }
+        }
+    }
+    __syncthreads();                                   // all reads of reg done
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < OCG; ++k) reg[ls * RS + k * L + i] = outv[k];
+        reg[ls * RS + NCH * L + i] = lse;
+    }
+    __syncthreads();
+    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t);
+    if (lse_out) tile_store<AXIS>(reg, RS, NCH, lse_out, g.G, hg, 1, t);
+    if (out_partials) {
+        float v[2 * OCG];
+#pragma unroll
+        for (int k = 0; k < OCG; ++k) { v[2 * k] = outv[k]; v[2 * k + 1] = outv[k] * outv[k]; }
+        block_sum<2 * OCG>(v, red, out_partials + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// backward: shared staging
+// --------------------------------------------------------------------------- //
+// LDS map (floats):  reg  [S_T][RS]      q|k|v normalised (+1 spare channel)
+//                    red  [256]
+//                    tq|tk|tv            raw tables, tk reversed        (POS)
+//                    dtq|dtk|dtv         table-gradient accumulators    (POS, pass B)
+//                    g2   [S_T][R2]      stacked -> dsv|dsve (gradient wrt stacked, pre bn_output)
+//                    g3   [S_T][R3]      dy (gp ch) | lse | delta
+template <int GP, bool POS>
+struct BwdLds {
+    static constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = POS ? 2 * GP : GP;
+    float *reg, *red, *tq, *tk, *tv, *dtq, *dtk, *dtv, *g2, *g3;
+    int RS, R2, R3, TL;
+    __device__ BwdLds(float* smem, const AxialGeom& g) {
+        const int L = g.L;
+        TL = 2 * L - 1;
+        RS = (NCH + 1) * L + 1;
+        R2 = NCH * L + 1;
+        R3 = (GP + 2) * L + 1;
+        reg = smem;
+        red = reg + g.S_T * RS;
+        float* p = red + 256;
+        tq = p; tk = tq + HQ * TL; tv = tk + HQ * TL;
+        if (POS) p = tv + GP * TL;
+        dtq = p; dtk = dtq + HQ * TL; dtv = dtk + HQ * TL;
+        if (POS) p = dtv + GP * TL;
+        g2 = p;
+        g3 = g2 + g.S_T * R2;
+    }
+};
+
+// Stage everything the two backward passes need; on return (after the trailing barrier):
+//   reg = normalised q|k|v, g2 = dsv|dsve (wrt gated stacked values), g3 = [dy.. | lse | delta]
+// rawv[] receives this thread's own raw qkv elements (position idx of its sequence).
+template <int GP, bool POS, int AXIS>
+__device__ __forceinline__ void bwd_stage(const AxialGeom& g, BwdLds<GP, POS>& S, const TileCtx& t, int grp, int hg,
+                                          const float* __restrict__ qkv_raw, const BnStats& qs,
+                                          const float* __restrict__ relative, const float* __restrict__ stacked,
+                                          const float* __restrict__ lse, const float* __restrict__ dy,
+                                          const float* __restrict__ out_coef, int pool, float (&rawv)[2 * GP]) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = POS ? 2 * GP : GP;
+    const int L = g.L, TL = S.TL;
+    tile_load<AXIS>(S.reg, S.RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t);
+    tile_load<AXIS>(S.g2, S.R2, 0, stacked, g.OC, hg * OCG, OCG, t);
+    tile_load_pooled<AXIS>(S.g3, S.R3, 0, dy, g.C, hg * GP, GP, g.H, pool, t);
+    tile_load<AXIS>(S.g3, S.R3, GP, lse, g.G, hg, 1, t);
+    if (POS) {
+        for (int e = threadIdx.x; e < HQ * TL; e += MEDT_THREADS) {
+            const int c = e / TL, d = e - c * TL;
+            S.tq[e] = relative[c * TL + d];
+            S.tk[e] = relative[(HQ + c) * TL + (TL - 1 - d)];
+        }
+        for (int e = threadIdx.x; e < GP * TL; e += MEDT_THREADS) S.tv[e] = relative[GP * TL + e];
+    }
+    __syncthreads();
+    const int ls = threadIdx.x / L, i = threadIdx.x - ls * L;
+    if (ls < t.nseq) {
+        const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
+        const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int idx = ls * S.RS + ch * L + i;
+            rawv[ch] = S.reg[idx];
+            S.reg[idx] = fmaf(rawv[ch], sc[ch], sh[ch]);
+        }
+        // gradient wrt the stacked (pre-bn_output) values: c0*dy + c1*stacked + c2 ; delta = sum dstk*stk
+        const float* cf = out_coef + ((size_t)grp * g.OC + hg * OCG) * 3;
+        float delta = 0.f;
+#pragma unroll
+        for (int k = 0; k < OCG; ++k) {
+            const int idx = ls * S.R2 + k * L + i;
+            const float sv = S.g2[idx];
+            const float d = S.g3[ls * S.R3 + (POS ? (k >> 1) : k) * L + i];
+            const float ds = fmaf(cf[k * 3 + 0], d, fmaf(cf[k * 3 + 1], sv, cf[k * 3 + 2]));
+            delta = fmaf(ds, sv, delta);
+            S.g2[idx] = ds;
+        }
+        S.g3[ls * S.R3 + (GP + 1) * L + i] = delta;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) rawv[ch] = 0.f;
+    }
+    __syncthreads();
+}
+
+// Everything one (i, j) pair contributes, shared by the row- and column-oriented loops.
+struct PairTerms {
+    float tqk, rq, rk;      // sum_c q k ; sum_c q Rq[d] ; sum_c k Rk[d']   (ungated)
+    float P, dPv, dPe, dZ;
+};
+
+// --------------------------------------------------------------------------- //
+// backward pass A: sum over (b,i,j) of dZ * {1, S_qk, S_qr, S_kr} per head
+// --------------------------------------------------------------------------- //
+template <int GP, bool POS, int AXIS>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_stats_kernel(
+    AxialGeom g, const float* __restrict__ qkv_raw, BnStats qs, BnStats ss, const float* __restrict__ relative,
+    GatePtrs gates, const float* __restrict__ stacked, const float* __restrict__ lse, const float* __restrict__ dy,
+    const float* __restrict__ out_coef, int pool, float* __restrict__ partials) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    BwdLds<GP, POS> S(smem, g);
+    const int L = g.L, TL = S.TL;
+    const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
+    TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
+    float rawv[NCH];
+    bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv);
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const float e_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
+    const float e_qr = POS ? ss.scale[grp * g.SC + g.G + hg] * MEDT_LOG2E : 0.f;
+    const float e_kr = POS ? ss.scale[grp * g.SC + 2 * g.G + hg] * MEDT_LOG2E : 0.f;
+    const int ls = threadIdx.x / L, i = threadIdx.x - ls * L;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ls < t.nseq) {
+        float q[HQ], dsv[GP], dse[GP];
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) q[c] = S.reg[ls * S.RS + c * L + i];
+#pragma unroll
+        for (int c = 0; c < GP; ++c) {
+            dsv[c] = S.g2[ls * S.R2 + (POS ? 2 * c : c) * L + i];
+            dse[c] = POS ? S.g2[ls * S.R2 + (2 * c + 1) * L + i] : 0.f;
+        }
+        const float lse_i = S.g3[ls * S.R3 + GP * L + i], delta = S.g3[ls * S.R3 + (GP + 1) * L + i];
+        const float* kp = S.reg + ls * S.RS + HQ * L;
+        const float* vp = S.reg + ls * S.RS + GP * L;
+        for (int j = 0; j < L; ++j) {
+            const int d = i - j + L - 1;
+            float tqk = 0.f, rq = 0.f, rk = 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                const float kc = kp[c * L + j];
+                tqk = fmaf(q[c], kc, tqk);
+                if (POS) {
+                    rq = fmaf(q[c], S.tq[c * TL + d], rq);
+                    rk = fmaf(kc, S.tk[c * TL + d], rk);
+                }
+            }
+            const float tqr = f_qr * rq, tkr = f_kr * rk;
+            const float z = fmaf(e_qk, tqk, fmaf(e_qr, tqr, e_kr * tkr));
+            const float P = __builtin_amdgcn_exp2f(z - lse_i);
+            float dPv = 0.f, dPe = 0.f;
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                dPv = fmaf(dsv[c], vp[c * L + j], dPv);
+                if (POS) dPe = fmaf(dse[c], S.tv[c * TL + d], dPe);
+            }
+            const float dP = POS ? fmaf(f_sv, dPv, f_sve * dPe) : dPv;
+            const float dZ = P * (dP - delta);
+            acc[0] += dZ;
+            acc[1] = fmaf(dZ, tqk, acc[1]);
+            if (POS) {
+                acc[2] = fmaf(dZ, tqr, acc[2]);
+                acc[3] = fmaf(dZ, tkr, acc[3]);
+            }
+        }
+    }
+    block_sum<4>(acc, S.red, partials + ((size_t)blockIdx.x * g.G + hg) * 4);
+}
+
+// bn_similarity backward finalisation: coef[grp][SC][3] = (e, u, w) with dS_x = e*dZ + u*S_x + w
+__global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __restrict__ partials, int tpg, int groups,
+                                                              int G, int SC, double count, BnStats ss,
+                                                              const float* __restrict__ weight, int training,
+                                                              float* __restrict__ coef, float* __restrict__ dweight,
+                                                              float* __restrict__ dbias) {
+    const int ch = blockIdx.x, lane = threadIdx.x;          // ch = x*G + hg
+    const int x = ch / G, hg = ch - x * G;
+    double dg = 0.0, db = 0.0;
+    for (int grp = 0; grp < groups; ++grp) {
+        double a0 = 0.0, ax = 0.0;
+        for (int p = lane; p < tpg; p += 64) {
+            const float* q = partials + ((size_t)(grp * tpg + p) * G + hg) * 4;
+            a0 += (double)q[0];
+            ax += (double)q[1 + x];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); ax += __shfl_xor(ax, o, 64); }
+        const double mean = ss.mean[grp * SC + ch], rstd = ss.rstd[grp * SC + ch];
+        const double sxh = rstd * (ax - mean * a0);          // sum dZ * xhat
+        dg += sxh;
+        db += a0;
+        if (lane == 0) {
+            const double e = (double)weight[ch] * rstd;
+            float* cf = coef + ((size_t)grp * SC + ch) * 3;
+            cf[0] = (float)e;
+            if (training) {
+                const double m1 = a0 / count, m2 = sxh / count;
+                const double u = -e * rstd * m2;
+                cf[1] = (float)u;
+                cf[2] = (float)(-e * m1 - u * mean);
+            } else {
+                cf[1] = 0.f;
+                cf[2] = 0.f;
+            }
+        }
+    }
+    if (lane == 0) {
+        dweight[ch] = (float)dg;
+        dbias[ch] = (float)db;
+    }
+}
+
+int axial_sim_bwd_finalize(const AxialGeom& g, const float* partials, BnStats sim, const float* weight, int training,
+                           float* coef, float* dweight, float* dbias, hipStream_t s) {
+    hipLaunchKernelGGL(sim_bwd_finalize_kernel, dim3(g.SC), dim3(64), 0, s, partials, g.tpg, g.groups, g.G, g.SC,
+                       g.sim_count, sim, weight, training, coef, dweight, dbias);
+    return launch_status("sim_bwd_finalize");
+}
+
+// --------------------------------------------------------------------------- //
+// backward pass B: dq (row-oriented), dk / dv (column-oriented), table and gate gradients
+// --------------------------------------------------------------------------- //
+template <int GP, bool POS, int AXIS>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
+    AxialGeom g, const float* __restrict__ qkv_raw, BnStats qs, BnStats ss, const float* __restrict__ sim_coef,
+    const float* __restrict__ relative, GatePtrs gates, const float* __restrict__ stacked,
+    const float* __restrict__ lse, const float* __restrict__ dy, const float* __restrict__ out_coef, int pool,
+    float* __restrict__ dqkv, float* __restrict__ qkv_partials, float* __restrict__ rel_partials,
+    float* __restrict__ gate_partials) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    BwdLds<GP, POS> S(smem, g);
+    const int L = g.L, TL = S.TL;
+    const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
+    TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
+    if (POS)
+        for (int e = threadIdx.x; e < NCH * TL; e += MEDT_THREADS) S.dtq[e] = 0.f;      // dtq|dtk|dtv contiguous
+    float rawv[NCH];
+    bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv);
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const float* cq = sim_coef + ((size_t)grp * g.SC + hg) * 3;
+    const float* cr = sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
+    const float* ck = sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
+    const float b_qk = cq[0], u_qk = cq[1], w_qk = cq[2];
+    const float b_qr = POS ? cr[0] : 0.f, u_qr = POS ? cr[1] : 0.f, w_qr = POS ? cr[2] : 0.f;
+    const float b_kr = POS ? ck[0] : 0.f, u_kr = POS ? ck[1] : 0.f, w_kr = POS ? ck[2] : 0.f;
+    const float e_qk = b_qk * MEDT_LOG2E, e_qr = b_qr * MEDT_LOG2E, e_kr = b_kr * MEDT_LOG2E;
+    const int ls = threadIdx.x / L, idx = threadIdx.x - ls * L;
+    const bool active = ls < t.nseq;
+    float dqkv_v[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) dqkv_v[ch] = 0.f;
+    float gacc[4] = {0.f, 0.f, 0.f, 0.f};       // f_qr, f_kr, f_sve, f_sv
+    if (active) {
+        const float* qp = S.reg + ls * S.RS;
+        const float* kp = qp + HQ * L;
+        const float* vp = qp + GP * L;
+        const float* g2 = S.g2 + ls * S.R2;
+        const float* lsep = S.g3 + ls * S.R3 + GP * L;
+        const float* delp = lsep + L;
+        // ---------------- row-oriented: thread owns query row i = idx ----------------
+        {
+            const int i = idx;
+            float q[HQ], dsv[GP], dse[GP], dq[HQ];
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) { q[c] = qp[c * L + i]; dq[c] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                dsv[c] = g2[(POS ? 2 * c : c) * L + i];
+                dse[c] = POS ? g2[(2 * c + 1) * L + i] : 0.f;
+            }
+            const float lse_i = lsep[i], delta = delp[i];
+            for (int j = 0; j < L; ++j) {
+                const int d = i - j + L - 1;
+                float tqk = 0.f, rq = 0.f, rk = 0.f;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    const float kc = kp[c * L + j];
+                    tqk = fmaf(q[c], kc, tqk);
+                    if (POS) {
+                        rq = fmaf(q[c], S.tq[c * TL + d], rq);
+                        rk = fmaf(kc, S.tk[c * TL + d], rk);
+                    }
+                }
+                const float tqr = f_qr * rq, tkr = f_kr * rk;
+                const float z = fmaf(e_qk, tqk, fmaf(e_qr, tqr, e_kr * tkr));
+                const float P = __builtin_amdgcn_exp2f(z - lse_i);
+                float dPv = 0.f, dPe = 0.f;
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    dPv = fmaf(dsv[c], vp[c * L + j], dPv);
+                    if (POS) dPe = fmaf(dse[c], S.tv[c * TL + d], dPe);
+                }
+                const float dP = POS ? fmaf(f_sv, dPv, f_sve * dPe) : dPv;
+                const float dZ = P * (dP - delta);
+                const float dSqk = fmaf(b_qk, dZ, fmaf(u_qk, tqk, w_qk));
+                if (POS) {
+                    const float dSqr = fmaf(b_qr, dZ, fmaf(u_qr, tqr, w_qr));
+                    const float dSkr = fmaf(b_kr, dZ, fmaf(u_kr, tkr, w_kr));
+                    const float gq = f_qr * dSqr, gk = f_kr * dSkr, gv = f_sve * P;
+                    gacc[0] = fmaf(dSqr, rq, gacc[0]);
+                    gacc[1] = fmaf(dSkr, rk, gacc[1]);
+                    gacc[2] = fmaf(P, dPe, gacc[2]);
+                    gacc[3] = fmaf(P, dPv, gacc[3]);
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) {
+                        const float kc = kp[c * L + j];
+                        dq[c] = fmaf(dSqk, kc, fmaf(gq, S.tq[c * TL + d], dq[c]));
+                        atomicAdd(&S.dtq[c * TL + d], gq * q[c]);
+                        atomicAdd(&S.dtk[c * TL + d], gk * kc);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GP; ++c) atomicAdd(&S.dtv[c * TL + d], gv * dse[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) dq[c] = fmaf(dSqk, kp[c * L + j], dq[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) dqkv_v[c] = dq[c];
+        }
+        // ---------------- column-oriented: thread owns key column j = idx ----------------
+        {
+            const int j = idx;
+            float k[HQ], v[GP], dk[HQ], dv[GP];
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) { k[c] = kp[c * L + j]; dk[c] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) { v[c] = vp[c * L + j]; dv[c] = 0.f; }
+            for (int i = 0; i < L; ++i) {
+                const int d = i - j + L - 1;
+                float tqk = 0.f, rq = 0.f, rk = 0.f;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    const float qc = qp[c * L + i];
+                    tqk = fmaf(qc, k[c], tqk);
+                    if (POS) {
+                        rq = fmaf(qc, S.tq[c * TL + d], rq);
+                        rk = fmaf(k[c], S.tk[c * TL + d], rk);
+                    }
+                }
+                const float tqr = f_qr * rq, tkr = f_kr * rk;
+                const float z = fmaf(e_qk, tqk, fmaf(e_qr, tqr, e_kr * tkr));
+                const float P = __builtin_amdgcn_exp2f(z - lsep[i]);
+                float dPv = 0.f, dPe = 0.f;
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    dPv = fmaf(g2[(POS ? 2 * c : c) * L + i], v[c], dPv);
+                    if (POS) dPe = fmaf(g2[(2 * c + 1) * L + i], S.tv[c * TL + d], dPe);
+                }
+                const float dP = POS ? fmaf(f_sv, dPv, f_sve * dPe) : dPv;
+                const float dZ = P * (dP - delp[i]);
+                const float dSqk = fmaf(b_qk, dZ, fmaf(u_qk, tqk, w_qk));
+                const float gk = POS ? f_kr * fmaf(b_kr, dZ, fmaf(u_kr, tkr, w_kr)) : 0.f;
+                const float pv = (POS ? f_sv : 1.f) * P;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    dk[c] = fmaf(dSqk, qp[c * L + i], dk[c]);
+                    if (POS) dk[c] = fmaf(gk, S.tk[c * TL + d], dk[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < GP; ++c) dv[c] = fmaf(pv, g2[(POS ? 2 * c : c) * L + i], dv[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) dqkv_v[HQ + c] = dk[c];
+#pragma unroll
+            for (int c = 0; c < GP; ++c) dqkv_v[GP + c] = dv[c];
+        }
+    }
+    __syncthreads();                                    // all reads of reg / tables / atomics done
+    if (active) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) S.reg[ls * S.RS + ch * L + idx] = dqkv_v[ch];
+    }
+    __syncthreads();
+    tile_store<AXIS>(S.reg, S.RS, 0, dqkv, 2 * g.C, hg * NCH, NCH, t);
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (POS) {
+        float* rp = rel_partials + blk * NCH * TL;
+        for (int e = threadIdx.x; e < HQ * TL; e += MEDT_THREADS) {
+            const int c = e / TL, d = e - c * TL;
+            rp[e] = S.dtq[e];
+            rp[(HQ + c) * TL + d] = S.dtk[c * TL + (TL - 1 - d)];
+        }
+        for (int e = threadIdx.x; e < GP * TL; e += MEDT_THREADS) rp[GP * TL + e] = S.dtv[e];
+        if (gate_partials) block_sum<4>(gacc, S.red, gate_partials + blk * 4);
+    }
+    // bn_qkv backward statistics: sum d, sum d * xhat  per channel of this head
+    {
+        const float* mean = qs.mean + grp * 2 * g.C + hg * NCH;
+        const float* rstd = qs.rstd + grp * 2 * g.C + hg * NCH;
+        float v[2 * NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            v[2 * ch] = dqkv_v[ch];
+            v[2 * ch + 1] = dqkv_v[ch] * ((rawv[ch] - mean[ch]) * rstd[ch]);
+        }
+        block_sum<2 * NCH>(v, S.red, qkv_partials + ((size_t)blockIdx.x * 2 * g.C + hg * NCH) * 2);
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// launchers
+// --------------------------------------------------------------------------- //
+#define MEDT_DISPATCH(KERNEL, ...)                                                                            \
+    do {                                                                                                      \
+        const dim3 grid(g.groups * g.tpg, g.G), block(MEDT_THREADS);                                          \
+        if (lds > 160 * 1024) { set_error(#KERNEL ": needs %zu B of LDS", lds); return MEDT_EUNSUPPORTED; }    \
+        switch (g.gp * 4 + g.pos * 2 + g.axis) {                                                              \
+            case 2 * 4 + 0: hipLaunchKernelGGL((KERNEL<2, false, 0>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 2 * 4 + 1: hipLaunchKernelGGL((KERNEL<2, false, 1>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 2 * 4 + 2: hipLaunchKernelGGL((KERNEL<2, true, 0>), grid, block, lds, s, __VA_ARGS__); break;   \
+            case 2 * 4 + 3: hipLaunchKernelGGL((KERNEL<2, true, 1>), grid, block, lds, s, __VA_ARGS__); break;   \
+            case 4 * 4 + 0: hipLaunchKernelGGL((KERNEL<4, false, 0>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 4 * 4 + 1: hipLaunchKernelGGL((KERNEL<4, false, 1>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 4 * 4 + 2: hipLaunchKernelGGL((KERNEL<4, true, 0>), grid, block, lds, s, __VA_ARGS__); break;   \
+            case 4 * 4 + 3: hipLaunchKernelGGL((KERNEL<4, true, 1>), grid, block, lds, s, __VA_ARGS__); break;   \
+            case 8 * 4 + 0: hipLaunchKernelGGL((KERNEL<8, false, 0>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 8 * 4 + 1: hipLaunchKernelGGL((KERNEL<8, false, 1>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 8 * 4 + 2: hipLaunchKernelGGL((KERNEL<8, true, 0>), grid, block, lds, s, __VA_ARGS__); break;   \
+            case 8 * 4 + 3: hipLaunchKernelGGL((KERNEL<8, true, 1>), grid, block, lds, s, __VA_ARGS__); break;   \
+            case 16 * 4 + 0: hipLaunchKernelGGL((KERNEL<16, false, 0>), grid, block, lds, s, __VA_ARGS__); break; \
+            case 16 * 4 + 1: hipLaunchKernelGGL((KERNEL<16, false, 1>), grid, block, lds, s, __VA_ARGS__); break; \
+            case 16 * 4 + 2: hipLaunchKernelGGL((KERNEL<16, true, 0>), grid, block, lds, s, __VA_ARGS__); break;  \
+            case 16 * 4 + 3: hipLaunchKernelGGL((KERNEL<16, true, 1>), grid, block, lds, s, __VA_ARGS__); break;  \
+            default: set_error(#KERNEL ": no instantiation"); return MEDT_EUNSUPPORTED;                       \
+        }                                                                                                     \
+        return launch_status(#KERNEL);                                                                        \
+    } while (0)
+
+int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
+                      float* partials, hipStream_t s) {
+    const size_t lds = axial_core_lds_bytes(g, false);
+    MEDT_DISPATCH(logit_stats_kernel, g, qkv_raw, qkv, relative, gates, partials);
+}
+
+int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                   GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s) {
+    const size_t lds = axial_core_lds_bytes(g, false);
+    MEDT_DISPATCH(attn_fwd_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials);
+}
+
+int axial_attn_bwd_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                         GatePtrs gates, const float* stacked, const float* lse, const float* dy,
+                         const float* out_coef, int stride, float* partials, hipStream_t s) {
+    const size_t lds = axial_core_lds_bytes(g, true);
+    MEDT_DISPATCH(attn_bwd_stats_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, dy, out_coef, stride,
+                  partials);
+}
+
+int axial_attn_bwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* sim_coef,
+                   const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
+                   const float* out_coef, int stride, float* dqkv, float* qkv_partials, float* rel_partials,
+                   float* gate_partials, hipStream_t s) {
+    const size_t lds = axial_core_lds_bytes(g, true);
+    MEDT_DISPATCH(attn_bwd_kernel, g, qkv_raw, qkv, sim, sim_coef, relative, gates, stacked, lse, dy, out_coef, stride,
+                  dqkv, qkv_partials, rel_partials, gate_partials);
+}
+
+}  // namespace medt

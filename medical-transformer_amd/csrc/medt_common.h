@@ -1,0 +1,69 @@
+// medt_common.h -- shared host/device helpers for libmedt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "medt_abi.h"
+
+#define MEDT_THREADS 256            // 4 wave64 per workgroup everywhere
+#define MEDT_WAVES (MEDT_THREADS / 64)
+#define MEDT_LOG2E 1.4426950408889634f
+
+namespace medt {
+
+// ---- host side ------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int  launch_status(const char* what);          // hipGetLastError -> MEDT_ELAUNCH
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int    cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Bump allocator over the caller's workspace (256-byte aligned carves).
+struct Carver {
+    char*  base;
+    size_t cap, off;
+    Carver(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+    template <class T> T* take(size_t count) {
+        size_t o = align_up(off, 256);
+        off = o + count * sizeof(T);
+        return (T*)(base ? base + o : nullptr);
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// Per-BatchNorm statistics block inside medt_axial_saved.stats: 4 arrays of groups*CH floats.
+struct BnStats {
+    float *mean, *rstd, *scale, *shift;        // scale = weight*rstd, shift = bias - mean*scale
+    __host__ __device__ BnStats() : mean(nullptr), rstd(nullptr), scale(nullptr), shift(nullptr) {}
+    __host__ __device__ BnStats(float* p, int n) : mean(p), rstd(p + n), scale(p + 2 * n), shift(p + 3 * n) {}
+};
+
+// ---- device side ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum K per-thread values over the 256-thread workgroup.  Result valid in threads [0,K)
+// of wave 0 as the return of the k-th slot: out[k] for tid==k.  `red` is MEDT_WAVES*K floats of LDS.
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* red, float* dst, int dst_stride = 1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float s = wave_sum(v[k]);
+        if (lane == 0) red[wave * K + k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += MEDT_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MEDT_WAVES; ++w) s += red[w * K + k];
+        dst[k * dst_stride] = s;
+    }
+    __syncthreads();
+}
+
+}  // namespace medt

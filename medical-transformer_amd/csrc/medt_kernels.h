@@ -1,0 +1,77 @@
+// medt_kernels.h -- internal launchers shared between the .hip translation units.
+#pragma once
+#include "medt_common.h"
+
+namespace medt {
+
+// ---- pointwise.hip ----------------------------------------------------------
+// 1x1 convolution on NCHW:  y[n,o,p] = sum_c w[o,c] * x[n,c,p].
+// partials (optional): per-(n, pixel-tile) [sum, sum of squares] of every output channel,
+// laid out [n][ptile][Cout][2]  ==  [group][part][Cout][2] with part = (n in group, ptile).
+int conv1x1_ptiles(int HW);
+int conv1x1_fwd(const float* x, const float* w, float* y, float* partials,
+                int N, int Cin, int Cout, int HW, hipStream_t s);
+// dx[n,c,p] = sum_o w[o,c] * val[n,o,p],  val = coef ? c0*dy + c1*raw + c2 : dy   (coef [group][Cout][3])
+int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const float* w, float* dx,
+                     int N, int Cin, int Cout, int HW, int groups, hipStream_t s);
+// dw[o,c] = sum_{n,p} val[n,o,p] * x[n,c,p];  scratch holds conv1x1_bwd_weight_splits()*Cout*Cin floats.
+int conv1x1_bwd_weight_splits(int N, int HW);
+int conv1x1_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
+                       int N, int Cin, int Cout, int HW, int groups, hipStream_t s);
+
+// Batch-norm statistics: partials [group][parts_per_group][CH][2] -> mean/rstd/scale/shift per (group, ch),
+// running-stat recurrence over the groups in order.  training==0: fold the running stats instead.
+int bn_finalize(const float* partials, int parts_per_group, int groups, int CH, double count,
+                const medt_bn_ptrs& bn, float momentum, float eps, int training, BnStats out, hipStream_t s);
+// Backward: partials [group][parts][CH][2] = [sum d, sum d*xhat] (d still to be multiplied by dscale).
+// Writes coef[group][CH][3] with  dx = c0*d + c1*x + c2,  and dweight[CH], dbias[CH].
+int bn_bwd_finalize(const float* partials, int parts_per_group, int groups, int CH, double count, float dscale,
+                    BnStats st, const float* weight, int training, float* coef, float* dweight, float* dbias,
+                    hipStream_t s);
+
+// bn_output apply + pair-sum + AvgPool2d(stride):  stacked (N,OC,H,W) -> y (N,C,H/s,W/s)
+int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s);
+// partials [n][ptile][OC][2] of [sum dstk, sum dstk*xhat] with dstk = dy (un-pooled, unscaled)
+int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st,
+                        float* partials, hipStream_t s);
+
+// out[k] = sum_p in[p][k]
+int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
+
+// ---- axial_core.hip ---------------------------------------------------------
+struct AxialGeom {
+    int N, C, H, W, G, gp, hq, L, Bo, axis, pos, OC, OCg, SC;
+    int groups, npg;        // BN groups, images per group
+    int spg;                // sequences per group = npg * Bo
+    int S_T;                // sequences per workgroup tile
+    int tpg;                // tiles per group
+    int HW;
+    double sim_count;       // elements per bn_similarity channel per group = spg * L * L
+    double row_count;       // elements per bn_qkv / bn_output channel per group = spg * L
+};
+int  axial_geom(const medt_axial_desc& d, AxialGeom* g);   // validates, returns MEDT_E*
+size_t axial_core_lds_bytes(const AxialGeom& g, bool backward);
+
+struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; };
+
+// logit statistics: partials [group][tile][SC][2]
+int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
+                      float* partials, hipStream_t s);
+// fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
+int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                   GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s);
+// backward pass A: partials [group][tile][G][4] = sum dZ*{S_qk,S_qr,S_kr,1}
+int axial_attn_bwd_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                         GatePtrs gates, const float* stacked, const float* lse, const float* dy,
+                         const float* out_coef, int stride, float* partials, hipStream_t s);
+// sim backward coefficients [group][SC][3] (e,u,w) + dweight/dbias of bn_similarity
+int axial_sim_bwd_finalize(const AxialGeom& g, const float* partials, BnStats sim, const float* weight, int training,
+                           float* coef, float* dweight, float* dbias, hipStream_t s);
+// backward pass B: dqkv (wrt normalised qkv), bn_qkv bwd partials [group][tile][2C][2],
+// relative-table partials [blocks][2gp*(2L-1)], gate partials [blocks][4]
+int axial_attn_bwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* sim_coef,
+                   const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
+                   const float* out_coef, int stride, float* dqkv, float* qkv_partials, float* rel_partials,
+                   float* gate_partials, hipStream_t s);
+
+}  // namespace medt

@@ -1,0 +1,385 @@
+// pointwise.hip -- channel-mixing and per-channel kernels around the attention core:
+//   1x1 convolution (qkv_transform, reference lib/models/utils.py:4-5 + axialnet.py:151) fwd / bwd,
+//   BatchNorm statistics finalisation (nn.BatchNorm1d/2d semantics, axialnet.py:116-118),
+//   bn_output apply + pair-sum + AvgPool (axialnet.py:179-187) and its backward statistics.
+// HBM-bound streaming kernels: lanes run along the contiguous pixel dimension, weights and
+// per-channel constants come through the scalar path (wave-uniform addresses).
+#include "medt_kernels.h"
+
+namespace medt {
+
+// --------------------------------------------------------------------------- //
+// 1x1 convolution forward (+ per-channel sum / sum-of-squares partials)
+// --------------------------------------------------------------------------- //
+template <int OT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv1x1_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ partials,
+    int Cin, int Cout, int HW) {
+    __shared__ float red[MEDT_WAVES * OT * 2];
+    const int  p  = blockIdx.x * MEDT_THREADS + threadIdx.x;
+    const int  n  = blockIdx.y;
+    const int  o0 = blockIdx.z * OT;
+    const bool ok = p < HW;
+    const float* xp = x + (size_t)n * Cin * HW + (ok ? p : 0);
+    float acc[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) acc[o] = 0.f;
+    for (int c = 0; c < Cin; ++c) {
+        const float xv = ok ? xp[(size_t)c * HW] : 0.f;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[o] = fmaf(w[(o0 + o) * Cin + c], xv, acc[o]);
+    }
+    if (ok) {
+        float* yp = y + ((size_t)n * Cout + o0) * HW + p;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) yp[(size_t)o * HW] = acc[o];
+    }
+    if (partials) {
+        float v[2 * OT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) { v[2 * o] = acc[o]; v[2 * o + 1] = acc[o] * acc[o]; }
+        block_sum<2 * OT>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * Cout + o0) * 2);
+    }
+}
+
+int conv1x1_ptiles(int HW) { return cdiv(HW, MEDT_THREADS); }
+
+int conv1x1_fwd(const float* x, const float* w, float* y, float* partials, int N, int Cin, int Cout, int HW,
+                hipStream_t s) {
+    const int pt = conv1x1_ptiles(HW);
+    if (Cout % 16 == 0) {
+        hipLaunchKernelGGL(conv1x1_fwd_kernel<16>, dim3(pt, N, Cout / 16), dim3(MEDT_THREADS), 0, s, x, w, y, partials,
+                           Cin, Cout, HW);
+    } else if (Cout % 8 == 0) {
+        hipLaunchKernelGGL(conv1x1_fwd_kernel<8>, dim3(pt, N, Cout / 8), dim3(MEDT_THREADS), 0, s, x, w, y, partials,
+                           Cin, Cout, HW);
+    } else if (Cout % 2 == 0) {
+        hipLaunchKernelGGL(conv1x1_fwd_kernel<2>, dim3(pt, N, Cout / 2), dim3(MEDT_THREADS), 0, s, x, w, y, partials,
+                           Cin, Cout, HW);
+    } else {
+        hipLaunchKernelGGL(conv1x1_fwd_kernel<1>, dim3(pt, N, Cout), dim3(MEDT_THREADS), 0, s, x, w, y, partials, Cin,
+                           Cout, HW);
+    }
+    return launch_status("conv1x1_fwd");
+}
+
+// --------------------------------------------------------------------------- //
+// 1x1 convolution backward-data, with the BatchNorm-backward affine applied on load
+// --------------------------------------------------------------------------- //
+template <int CT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ w, float* __restrict__ dx, int Cin, int Cout, int HW, int npg) {
+    const int  p  = blockIdx.x * MEDT_THREADS + threadIdx.x;
+    const int  n  = blockIdx.y;
+    const int  c0 = blockIdx.z * CT;
+    const bool ok = p < HW;
+    const size_t base = (size_t)n * Cout * HW + (ok ? p : 0);
+    const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    for (int o = 0; o < Cout; ++o) {
+        float v = ok ? dy[base + (size_t)o * HW] : 0.f;
+        if (cf) {
+            const float r = ok ? raw[base + (size_t)o * HW] : 0.f;
+            v = fmaf(cf[o * 3 + 0], v, fmaf(cf[o * 3 + 1], r, cf[o * 3 + 2]));
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = fmaf(w[o * Cin + c0 + c], v, acc[c]);
+    }
+    if (ok) {
+        float* dp = dx + ((size_t)n * Cin + c0) * HW + p;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) dp[(size_t)c * HW] = acc[c];
+    }
+}
+
+int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const float* w, float* dx, int N, int Cin,
+                     int Cout, int HW, int groups, hipStream_t s) {
+    const int pt = conv1x1_ptiles(HW), npg = N / groups;
+    if (Cin % 16 == 0)
+        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<16>, dim3(pt, N, Cin / 16), dim3(MEDT_THREADS), 0, s, dy, raw, coef,
+                           w, dx, Cin, Cout, HW, npg);
+    else if (Cin % 8 == 0)
+        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<8>, dim3(pt, N, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w,
+                           dx, Cin, Cout, HW, npg);
+    else
+        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<1>, dim3(pt, N, Cin), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx,
+                           Cin, Cout, HW, npg);
+    return launch_status("conv1x1_bwd_data");
+}
+
+// --------------------------------------------------------------------------- //
+// 1x1 convolution backward-weight:  dw[o,c] = sum_{n,p} val[n,o,p] * x[n,c,p]
+// 32x32 output tile per workgroup, split over pixel chunks, 64-pixel LDS steps.
+// --------------------------------------------------------------------------- //
+#define BW_PIX_PER_SPLIT 4096
+__global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_weight_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int Cout, int HW, int npg) {
+    __shared__ float A[32][65];
+    __shared__ float X[32][65];
+    const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const long NP = (long)N * HW;
+    const long q_begin = (long)blockIdx.z * BW_PIX_PER_SPLIT;
+    const long q_end = q_begin + BW_PIX_PER_SPLIT < NP ? q_begin + BW_PIX_PER_SPLIT : NP;
+    const int to = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+        // stage 32 rows x 64 pixels of val and of x (lanes along pixels)
+        for (int e = threadIdx.x; e < 32 * 64; e += MEDT_THREADS) {
+            const int r = e >> 6, j = e & 63;
+            const long q = q0 + j;
+            float a = 0.f, b = 0.f;
+            if (q < q_end) {
+                const int n = (int)(q / HW), p = (int)(q - (long)n * HW);
+                if (o0 + r < Cout) {
+                    const size_t idx = ((size_t)n * Cout + o0 + r) * HW + p;
+                    a = dy[idx];
+                    if (coef) {
+                        const float* cf = coef + ((size_t)(n / npg) * Cout + o0 + r) * 3;
+                        a = fmaf(cf[0], a, fmaf(cf[1], raw[idx], cf[2]));
+                    }
+                }
+                if (c0 + r < Cin) b = x[((size_t)n * Cin + c0 + r) * HW + p];
+            }
+            A[r][j] = a;
+            X[r][j] = b;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const float a0 = A[to][j], a1 = A[to + 16][j], b0 = X[tc][j], b1 = X[tc + 16][j];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]);
+            acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]);
+            acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)blockIdx.z * Cout * Cin;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int o = o0 + to + 16 * a, c = c0 + tc + 16 * b;
+            if (o < Cout && c < Cin) out[o * Cin + c] = acc[a][b];
+        }
+}
+
+int conv1x1_bwd_weight_splits(int N, int HW) { return cdiv(N * HW, BW_PIX_PER_SPLIT); }
+
+int conv1x1_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
+                       int N, int Cin, int Cout, int HW, int groups, hipStream_t s) {
+    const int splits = conv1x1_bwd_weight_splits(N, HW);
+    hipLaunchKernelGGL(conv1x1_bwd_weight_kernel, dim3(cdiv(Cout, 32), cdiv(Cin, 32), splits), dim3(MEDT_THREADS), 0, s,
+                       dy, raw, coef, x, scratch, N, Cin, Cout, HW, N / groups);
+    int rc = launch_status("conv1x1_bwd_weight");
+    if (rc) return rc;
+    return reduce_rows(scratch, splits, Cout * Cin, dw, s);
+}
+
+// --------------------------------------------------------------------------- //
+// out[k] = sum_p in[p][k]      (deterministic: fixed order, no atomics)
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_kernel(const float* __restrict__ in, int P, int K,
+                                                                   float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    float s = 0.f;
+    if (k < K)
+        for (int p = slice; p < P; p += 4) s += in[(size_t)p * K + k];
+    red[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && k < K) out[k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(K, 64)), dim3(MEDT_THREADS), 0, s, in, P, K, out);
+    return launch_status("reduce_rows");
+}
+
+// --------------------------------------------------------------------------- //
+// BatchNorm statistics finalisation.  One wave per channel; double accumulation.
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partials, int ppg, int groups, int CH,
+                                                         double count, const float* __restrict__ weight,
+                                                         const float* __restrict__ bias, float* running_mean,
+                                                         float* running_var, int64_t* nbt, float momentum, float eps,
+                                                         int training, BnStats out) {
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    const float g = weight[ch], b = bias[ch];
+    if (!training) {
+        const float  mean = running_mean[ch];
+        const float  rstd = (float)(1.0 / sqrt((double)running_var[ch] + (double)eps));
+        for (int grp = lane; grp < groups; grp += 64) {
+            out.mean[grp * CH + ch]  = mean;
+            out.rstd[grp * CH + ch]  = rstd;
+            out.scale[grp * CH + ch] = g * rstd;
+            out.shift[grp * CH + ch] = b - mean * g * rstd;
+        }
+        return;
+    }
+    double rm = running_mean ? (double)running_mean[ch] : 0.0, rv = running_var ? (double)running_var[ch] : 0.0;
+    for (int grp = 0; grp < groups; ++grp) {
+        double s = 0.0, ss = 0.0;
+        for (int p = lane; p < ppg; p += 64) {
+            const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
+            s += (double)q[0];
+            ss += (double)q[1];
+        }
+        s = wave_sum_d(s);
+        ss = wave_sum_d(ss);
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        if (lane == 0) {
+            out.mean[grp * CH + ch]  = (float)mean;
+            out.rstd[grp * CH + ch]  = (float)rstd;
+            out.scale[grp * CH + ch] = (float)(g * rstd);
+            out.shift[grp * CH + ch] = (float)(b - mean * g * rstd);
+        }
+        rm = (1.0 - momentum) * rm + momentum * mean;
+        rv = (1.0 - momentum) * rv + momentum * var * (count / (count - 1.0));
+    }
+    if (lane == 0) {
+        if (running_mean) running_mean[ch] = (float)rm;
+        if (running_var) running_var[ch] = (float)rv;
+        if (ch == 0 && nbt) *nbt += groups;
+    }
+}
+
+int bn_finalize(const float* partials, int ppg, int groups, int CH, double count, const medt_bn_ptrs& bn,
+                float momentum, float eps, int training, BnStats out, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(CH), dim3(64), 0, s, partials, ppg, groups, CH, count, bn.weight,
+                       bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, momentum, eps, training, out);
+    return launch_status("bn_finalize");
+}
+
+// Backward finalisation:  dx = A*(d - m1 - xhat*m2), xhat = (x-mean)*rstd, A = weight*rstd
+//   => dx = c0*d_raw + c1*x + c2 with d = dscale*d_raw.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int ppg, int groups,
+                                                             int CH, double count, float dscale, BnStats st,
+                                                             const float* __restrict__ weight, int training,
+                                                             float* __restrict__ coef, float* __restrict__ dweight,
+                                                             float* __restrict__ dbias) {
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    double dg = 0.0, db = 0.0;
+    for (int grp = 0; grp < groups; ++grp) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = lane; p < ppg; p += 64) {
+            const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
+            s1 += (double)q[0];
+            s2 += (double)q[1];
+        }
+        s1 = wave_sum_d(s1) * dscale;
+        s2 = wave_sum_d(s2) * dscale;
+        dg += s2;
+        db += s1;
+        if (lane == 0) {
+            const double mean = st.mean[grp * CH + ch], rstd = st.rstd[grp * CH + ch];
+            const double A = (double)weight[ch] * rstd;
+            float* cf = coef + ((size_t)grp * CH + ch) * 3;
+            if (training) {
+                const double m1 = s1 / count, m2 = s2 / count;
+                cf[0] = (float)(A * dscale);
+                cf[1] = (float)(-A * rstd * m2);
+                cf[2] = (float)(A * (rstd * mean * m2 - m1));
+            } else {
+                cf[0] = (float)(A * dscale);
+                cf[1] = 0.f;
+                cf[2] = 0.f;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (dweight) dweight[ch] = (float)dg;
+        if (dbias) dbias[ch] = (float)db;
+    }
+}
+
+int bn_bwd_finalize(const float* partials, int ppg, int groups, int CH, double count, float dscale, BnStats st,
+                    const float* weight, int training, float* coef, float* dweight, float* dbias, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(CH), dim3(64), 0, s, partials, ppg, groups, CH, count, dscale, st,
+                       weight, training, coef, dweight, dbias);
+    return launch_status("bn_bwd_finalize");
+}
+
+// --------------------------------------------------------------------------- //
+// bn_output apply + pair-sum + AvgPool2d(stride)        (axialnet.py:179-187)
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float* __restrict__ stk, BnStats st,
+                                                                     float* __restrict__ y, int N, int C, int H, int W,
+                                                                     int OC, int stride, int npg) {
+    const int Ho = H / stride, Wo = W / stride;
+    const size_t total = (size_t)N * C * Ho * Wo;
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int wo = (int)(idx % Wo);
+    const int ho = (int)((idx / Wo) % Ho);
+    const int c  = (int)((idx / ((size_t)Wo * Ho)) % C);
+    const int n  = (int)(idx / ((size_t)Wo * Ho * C));
+    const int grp = n / npg;
+    const int per = OC / C;                     // 2 (sv|sve pair) or 1 (wopos)
+    float acc = 0.f;
+    for (int t = 0; t < per; ++t) {
+        const int ch = c * per + t;
+        const float sc = st.scale[grp * OC + ch], sh = st.shift[grp * OC + ch];
+        const float* src = stk + ((size_t)n * OC + ch) * H * W;
+        float a = 0.f;
+        for (int dh = 0; dh < stride; ++dh)
+            for (int dw = 0; dw < stride; ++dw) a += fmaf(sc, src[(size_t)(ho * stride + dh) * W + wo * stride + dw], sh);
+        acc += a;
+    }
+    y[idx] = acc * (1.f / (float)(stride * stride));
+}
+
+int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s) {
+    const int OC = d.has_pos ? 2 * d.C : d.C;
+    const size_t total = (size_t)d.N * d.C * (d.H / d.stride) * (d.W / d.stride);
+    hipLaunchKernelGGL(axial_out_fwd_kernel, dim3((unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS)),
+                       dim3(MEDT_THREADS), 0, s, stacked, st, y, d.N, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups);
+    return launch_status("axial_out_fwd");
+}
+
+// partials[n][ptile][OC][2] = [sum dstk, sum dstk*xhat], dstk = dy at the pooled position (x 1/s^2 later)
+__global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const float* __restrict__ stk,
+                                                                           const float* __restrict__ dy, BnStats st,
+                                                                           float* __restrict__ partials, int C, int H,
+                                                                           int W, int OC, int stride, int npg) {
+    __shared__ float red[MEDT_WAVES * 2];
+    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, ch = blockIdx.z;
+    const int HW = H * W, Ho = H / stride, Wo = W / stride;
+    const int c = ch / (OC / C), grp = n / npg;
+    float v[2] = {0.f, 0.f};
+    if (p < HW) {
+        const int h = p / W, w = p - h * W;
+        const int ho = h / stride, wo = w / stride;
+        if (ho < Ho && wo < Wo) {
+            const float d = dy[((size_t)(n * C + c) * Ho + ho) * Wo + wo];
+            const float xh = (stk[((size_t)n * OC + ch) * HW + p] - st.mean[grp * OC + ch]) * st.rstd[grp * OC + ch];
+            v[0] = d;
+            v[1] = d * xh;
+        }
+    }
+    block_sum<2>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * OC + ch) * 2);
+}
+
+int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, float* partials,
+                        hipStream_t s) {
+    const int OC = d.has_pos ? 2 * d.C : d.C;
+    hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(conv1x1_ptiles(d.H * d.W), d.N, OC), dim3(MEDT_THREADS), 0, s,
+                       stacked, dy, st, partials, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups);
+    return launch_status("axial_out_bwd_stats");
+}
+
+}  // namespace medt

@@ -1,0 +1,7 @@
+"""medt_amd -- MI355X-native runtime under the Medical-Transformer module surface.
+
+`lib.models.axialnet` (the drop-in mirror of the reference's module surface)
+binds its forward/backward to libmedt_hip.so through this package.
+"""
+from ._lib import MedtError, lib  # noqa: F401
+from .axial import axial_attention  # noqa: F401

@@ -1,0 +1,141 @@
+"""Host side of the axial-attention layer: torch.autograd.Function over the C ABI.
+
+Mirrors what AxialAttention{,_dynamic,_wopos}.forward computes
+(reference lib/models/axialnet.py:52-92, 142-189, 222-253) and its autograd
+backward; PyTorch only supplies device memory, the stream and the autograd
+graph.  CPU tensors are rejected -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+class AxialConfig:
+    """Static geometry + BatchNorm buffers of one attention layer."""
+    __slots__ = ("groups", "axis", "has_pos", "stride", "bn_groups", "eps", "momentum",
+                 "bn_qkv", "bn_similarity", "bn_output")
+
+    def __init__(self, groups, axis, has_pos, stride, bn_qkv, bn_similarity, bn_output, bn_groups=1,
+                 eps=1e-5, momentum=0.1):
+        self.groups, self.axis, self.has_pos, self.stride = groups, axis, has_pos, stride
+        self.bn_groups, self.eps, self.momentum = bn_groups, eps, momentum
+        self.bn_qkv, self.bn_similarity, self.bn_output = bn_qkv, bn_similarity, bn_output
+
+
+def _require_device(x: torch.Tensor):
+    if not x.is_cuda:
+        raise L.MedtError("medt_amd runs on MI355X only: got a CPU tensor and there is no CPU fallback "
+                          "(the CPU restatement under oracle/ is test infrastructure)")
+    if x.dtype != torch.float32:
+        raise L.MedtError(f"medt_amd: float32 activations expected, got {x.dtype}")
+
+
+def _bn_ptrs(bn, training: bool) -> L.BnPtrs:
+    track = bn.running_mean is not None
+    return L.BnPtrs(L.ptr(bn.weight), L.ptr(bn.bias),
+                    L.ptr(bn.running_mean) if track else None, L.ptr(bn.running_var) if track else None,
+                    L.ptr(bn.num_batches_tracked) if (track and training) else None)
+
+
+def _desc(x, cfg: AxialConfig, training: bool) -> L.AxialDesc:
+    N, Cc, H, W = x.shape
+    return L.AxialDesc(N, Cc, H, W, cfg.groups, cfg.axis, int(cfg.has_pos), cfg.stride, int(training),
+                       cfg.bn_groups, cfg.eps, cfg.momentum)
+
+
+def _params(cfg, w_qkv, relative, gates, training) -> L.AxialParams:
+    g = [L.ptr(t) for t in gates] if gates is not None else [None] * 4
+    return L.AxialParams(L.ptr(w_qkv), _bn_ptrs(cfg.bn_qkv, training), _bn_ptrs(cfg.bn_similarity, training),
+                         _bn_ptrs(cfg.bn_output, training), L.ptr(relative), g[0], g[1], g[2], g[3])
+
+
+class AxialAttentionFn(torch.autograd.Function):
+    """y = axial_attention(x).  Argument order = gradient order."""
+
+    @staticmethod
+    def forward(ctx, x, w_qkv, bnq_w, bnq_b, bns_w, bns_b, bno_w, bno_b, relative, f_qr, f_kr, f_sve, f_sv,
+                cfg: AxialConfig, training: bool):
+        _require_device(x)
+        lib = L.lib()
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        desc = _desc(x, cfg, training)
+        gates = None if f_qr is None else (f_qr, f_kr, f_sve, f_sv)
+        params = _params(cfg, w_qkv, relative, gates, training)
+        OC = 2 * Cc if cfg.has_pos else Cc
+        dev = x.device
+        qkv_raw = torch.empty((N, 2 * Cc, H, W), device=dev, dtype=torch.float32)
+        stacked = torch.empty((N, OC, H, W), device=dev, dtype=torch.float32)
+        lse = torch.empty((N, cfg.groups, H, W), device=dev, dtype=torch.float32)
+        nstats = lib.medt_axial_stats_floats(C.byref(desc))
+        if nstats == 0:
+            raise L.MedtError("axial attention: " + lib.medt_last_error().decode())
+        stats = torch.empty((nstats,), device=dev, dtype=torch.float32)
+        ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+        y = torch.empty((N, Cc, H // cfg.stride, W // cfg.stride), device=dev, dtype=torch.float32)
+        saved = L.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
+        stream = torch.cuda.current_stream().cuda_stream
+        L.check(lib.medt_axial_layer_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
+                                         ws.data_ptr(), ws_bytes, stream), "medt_axial_layer_fwd")
+        ctx.cfg, ctx.training, ctx.has_gates = cfg, training, gates is not None
+        ctx.save_for_backward(x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats = ctx.saved_tensors
+        cfg, training = ctx.cfg, ctx.training
+        dy = dy.contiguous()
+        desc = _desc(x, cfg, training)
+        gates = (f_qr, f_kr, f_sve, f_sv) if ctx.has_gates else None
+        params = _params(cfg, w_qkv, relative, gates, False)      # no running-stat update in backward
+        dev = x.device
+        Cc = x.shape[1]
+        SC = (3 if cfg.has_pos else 1) * cfg.groups
+        OC = (2 if cfg.has_pos else 1) * Cc
+        # one flat buffer for all the small parameter gradients
+        sizes = [2 * Cc * Cc, 2 * Cc, 2 * Cc, SC, SC, OC, OC, relative.numel() if relative is not None else 0, 4]
+        flat = torch.empty((sum(sizes),), device=dev, dtype=torch.float32)
+        parts = list(torch.split(flat, sizes))
+        want_gates = ctx.has_gates and any(ctx.needs_input_grad[9:13])
+        dx = torch.empty_like(x)
+        grads = L.AxialGrads(*[p.data_ptr() for p in parts[:7]],
+                             parts[7].data_ptr() if relative is not None else None,
+                             parts[8].data_ptr() if want_gates else None)
+        saved = L.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
+        ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+        stream = torch.cuda.current_stream().cuda_stream
+        L.check(lib.medt_axial_layer_bwd(C.byref(desc), C.byref(params), x.data_ptr(), dy.data_ptr(), C.byref(saved),
+                                         dx.data_ptr(), C.byref(grads), ws.data_ptr(), ws_bytes, stream),
+                "medt_axial_layer_bwd")
+        dw = parts[0].view_as(w_qkv)
+        drel = parts[7].view_as(relative) if relative is not None else None
+        if want_gates:
+            gg = parts[8]
+            dg = [gg[0].reshape(()), gg[1].reshape(()), gg[2].reshape(()), gg[3].reshape(())]
+        else:
+            dg = [None] * 4
+        return (dx, dw, parts[1], parts[2], parts[3], parts[4], parts[5], parts[6], drel, dg[0], dg[1], dg[2], dg[3],
+                None, None)
+
+
+def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: Optional[torch.Tensor],
+                    gates, groups: int, width: bool, stride: int, training: bool, bn_groups: int = 1):
+    """Functional entry: modules from lib.models.axialnet pass their own parameters/buffers.
+
+    gates = (f_qr, f_kr, f_sve, f_sv) 0-d tensors or None (ungated: all ones).
+    """
+    cfg = AxialConfig(groups, 1 if width else 0, relative is not None, stride, bn_qkv, bn_similarity, bn_output,
+                      bn_groups, bn_qkv.eps, bn_qkv.momentum if bn_qkv.momentum is not None else 0.1)
+    g = gates if gates is not None else (None, None, None, None)
+    return AxialAttentionFn.apply(x, qkv_weight, bn_qkv.weight, bn_qkv.bias, bn_similarity.weight,
+                                  bn_similarity.bias, bn_output.weight, bn_output.bias, relative,
+                                  g[0], g[1], g[2], g[3], cfg, training)

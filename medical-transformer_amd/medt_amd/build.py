@@ -1,0 +1,57 @@
+"""Build libmedt_hip.so (hipcc, gfx950 only) in-tree.
+
+The library is a plain C-ABI shared object (include/medt_abi.h); it is built with
+hipcc directly -- no torch headers, no cmake.  `python -m medt_amd.build` or
+`__graft_entry__.build()` calls this; the GPU box uses the prebuilt .so that
+travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # medical-transformer_amd/
+REPO_ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libmedt_hip.so")
+SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip"]
+HEADERS = ["medt_common.h", "medt_kernels.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for s in SOURCES:                      # one hipcc per translation unit, in parallel
+        o = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO_ROOT, "include"),
+               "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB_PATH)

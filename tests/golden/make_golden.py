@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference ships no tests / golden vectors for this path, so
+the fixtures are produced by importing the reference's own
+lib/models/axialnet.py (oracle/ref_loader.py), running it on CPU in float64 on
+seeded inputs with a seeded, non-trivial state_dict (oracle.randomize_state),
+and recording outputs, loss, gradients and updated BatchNorm buffers.
+
+Everything an fixture consumer needs to rebuild the inputs is a (seed, shape)
+pair: tests regenerate x / y / state_dict with the same CPU generators and
+compare against the stored results; a checksum of x guards the RNG contract.
+Full gradients would be ~6 MB per model, so model-level fixtures store, per
+parameter, [L2 norm, <grad, r>] with r a seeded N(0,1) vector, plus the full
+gradient of a few small tensors; layer-level fixtures store everything.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import medt_oracle as O      # noqa: E402
+from oracle import ref_loader            # noqa: E402
+
+
+def seeded_input(seed, N, C, S, classes=2):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, C, S, S, generator=g, dtype=torch.float32)
+    y = torch.randint(0, classes, (N, S, S), generator=g)
+    return x, y
+
+
+def probe_vector(name: str, numel: int, seed: int) -> torch.Tensor:
+    h = (sum(ord(c) * (i + 1) for i, c in enumerate(name)) + seed) % (2 ** 31)
+    g = torch.Generator().manual_seed(h)
+    return torch.randn(numel, generator=g, dtype=torch.float64)
+
+
+FULL_GRAD_KEYS = ("relative", "f_qr", "f_kr", "f_sv", "f_sve", "bn_similarity.weight", "adjust.weight", "adjust.bias")
+
+
+def model_fixture(model_name, S, N, seed, training):
+    torch.manual_seed(seed)
+    ref = ref_loader.factory(model_name)(img_size=S, imgchan=3)
+    sd = O.randomize_state(ref.state_dict(), seed)
+    ref.load_state_dict(sd)
+    ref = ref.double()
+    for p in ref.parameters():
+        p.requires_grad_(True)           # gates too (train.py:169-171 after epoch 10)
+    ref.train(training)
+    x, y = seeded_input(seed + 1, N, 3, S)
+    out = ref(x.double())
+    fx = {
+        "meta": np.array([S, N, seed, int(training)]),
+        "x_checksum": np.array([x.double().sum().item(), (x.double() ** 2).sum().item()]),
+        "logits": out.detach().float().numpy(),
+    }
+    if training:
+        loss = ref_loader.load_metrics().LogNLLLoss()(out, y)
+        loss.backward()
+        fx["loss"] = np.array([loss.item()])
+        names, summ = [], []
+        for k, p in ref.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.reshape(-1)
+            names.append(k)
+            summ.append([g.norm().item(), torch.dot(g, probe_vector(k, g.numel(), seed)).item()])
+            if k.endswith(FULL_GRAD_KEYS) and g.numel() <= 4096:
+                fx["grad/" + k] = p.grad.detach().numpy()
+        fx["grad_names"] = np.array(names)
+        fx["grad_summary"] = np.array(summ)
+        bnames, bsumm = [], []
+        for k, b in ref.state_dict().items():
+            if k.endswith(("running_mean", "running_var")):
+                v = b.reshape(-1).double()
+                bnames.append(k)
+                bsumm.append([v.norm().item(), torch.dot(v, probe_vector(k, v.numel(), seed)).item()])
+            elif k.endswith("num_batches_tracked"):
+                bnames.append(k)
+                bsumm.append([float(b.item()), 0.0])
+        fx["buf_names"] = np.array(bnames)
+        fx["buf_summary"] = np.array(bsumm)
+    return fx
+
+
+def layer_fixture(kind, C, L, width, stride, N, seed):
+    """One attention layer of the reference, everything stored in full (float64)."""
+    ax = ref_loader.load()
+    cls = {"dynamic": ax.AxialAttention_dynamic, "plain": ax.AxialAttention, "wopos": ax.AxialAttention_wopos}[kind]
+    torch.manual_seed(seed)
+    layer = cls(C, C, groups=8, kernel_size=L, stride=stride, width=width)
+    sd = O.randomize_state(layer.state_dict(), seed)
+    layer.load_state_dict(sd)
+    layer = layer.double()
+    for p in layer.parameters():
+        p.requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 1)
+    other = 6                                        # the non-attended spatial extent
+    shape = (N, C, other, L) if width else (N, C, L, other)
+    x = torch.randn(shape, generator=g, dtype=torch.float64).requires_grad_(True)
+    fx = {"meta": np.array([C, L, int(width), stride, N, seed]), "x": x.detach().numpy()}
+    import json
+    fx["state_layout"] = np.array(json.dumps([[k, list(v.shape), str(v.dtype).replace("torch.", "")]
+                                              for k, v in sd.items()]))
+    layer.eval()
+    fx["out_eval"] = layer(x).detach().numpy()
+    layer.train()
+    out = layer(x)
+    w = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    fx["dout"] = w.numpy()
+    (out * w).sum().backward()
+    fx["out_train"] = out.detach().numpy()
+    fx["dx"] = x.grad.numpy()
+    for k, p in layer.named_parameters():
+        fx["grad/" + k] = p.grad.numpy()
+    for k, b in layer.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            fx["buf/" + k] = b.numpy()
+    return fx
+
+
+def manifest():
+    """state_dict key / shape / dtype manifest of every factory (the drop-in contract)."""
+    import json
+    out = {}
+    for name, S in (("gatedaxialunet", 128), ("axialunet", 128), ("MedT", 128), ("logo", 128),
+                    ("gatedaxialunet", 256), ("MedT", 256), ("gatedaxialunet", 64), ("axialunet", 64)):
+        for chan in (3, 1):
+            m = ref_loader.factory(name)(img_size=S, imgchan=chan)
+            out[f"{name}/{S}/{chan}"] = {
+                "state": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()],
+                "params": [[k, bool(p.requires_grad)] for k, p in m.named_parameters()],
+            }
+    with open(os.path.join(HERE, "state_manifest.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote state_manifest.json")
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    manifest()
+    layer_cases = [
+        ("dynamic", 16, 16, False, 1, 2, 11),
+        ("dynamic", 32, 8, True, 2, 2, 12),
+        ("plain", 16, 8, True, 1, 2, 13),
+        ("wopos", 16, 16, False, 1, 2, 14),
+        ("wopos", 32, 8, True, 2, 2, 15),
+        ("dynamic", 64, 32, True, 2, 1, 16),
+    ]
+    for case in layer_cases:
+        kind, C, L, width, stride, N, seed = case
+        fx = layer_fixture(*case)
+        fn = f"layer_{kind}_C{C}_L{L}_{'w' if width else 'h'}_s{stride}.npz"
+        np.savez_compressed(os.path.join(HERE, fn), **fx)
+        print("wrote", fn)
+    model_cases = [
+        ("gatedaxialunet", 128, 2, 101, True),
+        ("gatedaxialunet", 128, 2, 101, False),
+        ("MedT", 128, 2, 102, True),
+        ("MedT", 128, 2, 102, False),
+        ("axialunet", 64, 2, 103, True),
+        ("logo", 128, 1, 104, True),
+        ("MedT", 256, 1, 105, False),
+    ]
+    for name, S, N, seed, training in model_cases:
+        fx = model_fixture(name, S, N, seed, training)
+        fn = f"model_{name}_S{S}_N{N}_{'train' if training else 'eval'}.npz"
+        np.savez_compressed(os.path.join(HERE, fn), **fx)
+        print("wrote", fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()
