@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py -- training images/s of MedT (3x128x128) on N MI355X, plus the attention-kernel roofline
+and the CPU baseline.  Contract: see the task description / DESIGN.md "Measurement".
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + cross-entropy + backward + (N>1: gradient all-reduce) + Adam on one synthetic batch
+already resident in HBM (reference train.py:140,156-161).  Weak scaling: 4 images per GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "medical-transformer_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+PER_GPU_BATCH = 4               # BASELINE.json configs[2]/[3]: MedT imgsize=128 bs=4 per GPU
+IMG = 128
+
+
+def build_model(name, img, device):
+    import lib as droplib
+    f = {"MedT": droplib.models.axialnet.MedT, "gatedaxialunet": droplib.models.axialnet.gated,
+         "axialunet": droplib.models.axialunet, "logo": droplib.models.axialnet.logo}[name]
+    return f(img_size=img, imgchan=3).to(device)
+
+
+# --------------------------------------------------------------------------- #
+# roofline leg: the fused attention kernel on a shape whose traffic exceeds the 256 MB Infinity Cache
+# --------------------------------------------------------------------------- #
+def roofline_leg(device, C=16, L=64, images=256, iters=20):
+    """layer-1 geometry (C=16, G=8, L=64) with B* = images*L = 16384 sequences.
+    Algorithmic bytes of the main pass = qkv read once + sv|sve written once = 4*C*4*M (M = B* x L);
+    statistics pass = q,k read once = C*4*M."""
+    from medt_amd import _lib as ML
+    from medt_amd.axial import AxialConfig, _desc, _params
+    import lib as droplib
+    lib = ML.lib()
+    layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=True).to(device)
+    layer.train()
+    N, H, W = images, L, L
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn((N, C, H, W), generator=g).to(device)
+    cfg = AxialConfig(8, 1, True, 1, layer.bn_qkv, layer.bn_similarity, layer.bn_output)
+    desc = _desc(x, cfg, True)
+    gates = (layer.f_qr, layer.f_kr, layer.f_sve, layer.f_sv)
+    params = _params(cfg, layer.qkv_transform.weight, layer.relative, gates, True)
+    qkv_raw = torch.empty((N, 2 * C, H, W), device=device)
+    stacked = torch.empty((N, 2 * C, H, W), device=device)
+    lse = torch.empty((N, 8, H, W), device=device)
+    stats = torch.empty((lib.medt_axial_stats_floats(ctypes.byref(desc)),), device=device)
+    ws_bytes = lib.medt_axial_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty((ws_bytes,), device=device, dtype=torch.uint8)
+    y = torch.empty((N, C, H, W), device=device)
+    saved = ML.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream          # kernels are launched on torch's current stream
+    ML.check(lib.medt_axial_layer_fwd(ctypes.byref(desc), ctypes.byref(params), x.data_ptr(), y.data_ptr(),
+                                      ctypes.byref(saved), ws.data_ptr(), ws_bytes, stream), "layer_fwd")
+    torch.cuda.synchronize()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    t_main = timed(lambda: ML.check(lib.medt_axial_core_fwd(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
+                                                            ws.data_ptr(), ws_bytes, stream), "core_fwd"))
+    t_stats = timed(lambda: ML.check(lib.medt_axial_core_stats(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
+                                                               ws.data_ptr(), ws_bytes, stream), "core_stats"))
+    M = N * H * W
+    bytes_main = 4 * C * 4 * M
+    bytes_stats = C * 4 * M
+    flops_main = 7.0 * M * L * C
+    roof = {"bound": "hbm", "kernel": "attn_fwd_kernel<GP=2,POS,AXIS=1>",
+            "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main},
+            "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+            "launch_ms": t_main * 1e3, "valu_tflops": flops_main / t_main / 1e12,
+            "stats_kernel": {"achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
+                             "bytes_per_launch": bytes_stats}}
+    tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
+    if os.path.exists(tf):
+        try:
+            roof["traffic"] = json.load(open(tf)).get("attn_fwd_bytes_per_launch")
+        except Exception:
+            pass
+    return roof
+
+
+# --------------------------------------------------------------------------- #
+# CPU baseline leg: the oracle (a port of the reference's algorithm) on the host cores
+# --------------------------------------------------------------------------- #
+def cpu_baseline_leg(steps=3):
+    from oracle import medt_oracle as O
+    import lib as droplib
+    O.set_fast_bn(True)                                  # aten's fused BatchNorm, like the reference's nn.BatchNorm
+    torch.manual_seed(3000)
+    # Host threads: all cores up to MEDT_CPU_THREADS (default 32).  The reference's tensors are small
+    # (a few MB); beyond a few tens of OpenMP threads aten's CPU kernels get slower, not faster.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("MEDT_CPU_THREADS", "32")))
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} threads of {os.cpu_count()} cores")
+    sd = droplib.models.axialnet.MedT(img_size=IMG, imgchan=3).state_dict()
+    st = {k: v.clone() for k, v in sd.items()}
+    leaves = []
+    for k, v in st.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) and not k.endswith(("f_qr", "f_kr", "f_sve", "f_sv")):
+            v.requires_grad_(True)
+            leaves.append(v)
+    opt = torch.optim.Adam(leaves, lr=1e-3, weight_decay=1e-5)
+    x = torch.rand(PER_GPU_BATCH, 3, IMG, IMG)
+    y = torch.randint(0, 2, (PER_GPU_BATCH, IMG, IMG))
+
+    def step():
+        out = O.medt(x, st, True)                       # literal 16-iteration patch loop, like the reference
+        loss = O.log_nll_loss(out, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for k in st:                                    # running stats were re-bound by the oracle; keep them detached
+            if not st[k].requires_grad and st[k].is_floating_point():
+                st[k] = st[k].detach()
+
+    t0 = time.perf_counter()
+    step()
+    log(f"cpu baseline: warm-up step {time.perf_counter() - t0:.1f}s")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    log(f"cpu baseline: {dt:.2f} s/step")
+    O.set_fast_bn(False)
+    return {"value": PER_GPU_BATCH / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps (1 warm-up) of MedT imgsize={IMG} bs={PER_GPU_BATCH} fp32 through oracle/medt_oracle.py "
+                      f"(torch CPU, {cores} threads), fwd+CE+backward+Adam", "s_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="MedT")
+    ap.add_argument("--imgsize", type=int, default=IMG)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only the attention-kernel microbenchmark (for rocprofv3)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    if args.roofline_only:
+        print(json.dumps({"roofline": roofline_leg(device)}))
+        return
+
+    from medt_amd import dp
+    torch.manual_seed(3000)                              # train.py:118
+    model = build_model(args.model, args.imgsize, device)
+    model.train()
+    dp.broadcast_parameters(model)
+    opt = torch.optim.Adam(list(model.parameters()), lr=1e-3, weight_decay=1e-5)     # train.py:111-112
+    g = torch.Generator().manual_seed(3000 + rank)
+    x = torch.rand(args.batch, 3, args.imgsize, args.imgsize, generator=g).to(device)
+    y = torch.randint(0, 2, (args.batch, args.imgsize, args.imgsize), generator=g).to(device)
+    bucket = None
+
+    def step():
+        nonlocal bucket
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if world > 1:
+            bucket = dp.allreduce_gradients(model, bucket)
+        opt.step()
+        return loss
+
+    log("model built; warm-up")
+    for _ in range(args.warmup):
+        step()
+    log("warm-up done; timing")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    log(f"{args.steps} steps in {elapsed:.3f}s")
+
+    result = {
+        "metric": "training images/sec (MedT, 3x128x128)", "value": world * args.batch * args.steps / elapsed,
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} imgsize={args.imgsize} bs={args.batch}/GPU train step (fwd+CE+bwd+Adam), "
+                               f"BASELINE.json configs[2]" + ("" if world == 1 else f" x{world} data-parallel, flat-bucket all-reduce"),
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+        "final_loss": final_loss,
+    }
+    if rank == 0 and world == 1:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                model(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                model(x)
+            torch.cuda.synchronize()
+            result["fwd_ms_per_image"] = (time.perf_counter() - t1) / 10 / args.batch * 1e3
+        log(f"eval fwd {result['fwd_ms_per_image']:.3f} ms/image")
+        if not args.no_roofline:
+            result["roofline"] = roofline_leg(device)
+            log("roofline leg done")
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_leg()
+            result["vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

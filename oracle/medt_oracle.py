@@ -41,6 +41,17 @@ BN_EPS = 1e-5        # nn.BatchNorm default, used everywhere in axialnet.py
 BN_MOMENTUM = 0.1    # nn.BatchNorm default
 GROUPS = 8           # axialnet.py:400,512 (groups=8 for every attention layer)
 
+# bench.py's cpu_baseline leg times this restatement as a stand-in for the reference's CPU path.
+# The spelled-out BatchNorm below is ~3x slower on CPU than the fused aten kernel the reference's
+# nn.BatchNorm modules hit, which would flatter the GPU/CPU ratio; FAST_BN=True routes batch_norm()
+# through torch.nn.functional.batch_norm (same arithmetic, checked equal in tests/test_oracle_golden.py).
+FAST_BN = False
+
+
+def set_fast_bn(flag: bool) -> None:
+    global FAST_BN
+    FAST_BN = bool(flag)
+
 
 # --------------------------------------------------------------------------- #
 # BatchNorm, spelled out
@@ -63,6 +74,13 @@ def batch_norm(x: torch.Tensor, st: State, prefix: str, training: bool,
     if not training:
         mean, var = st[prefix + ".running_mean"], st[prefix + ".running_var"]
         return (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS) * w.view(shape) + b.view(shape)
+    if FAST_BN:
+        outs = []
+        for xg in x.chunk(bn_groups, dim=0):
+            rm, rv = st[prefix + ".running_mean"], st[prefix + ".running_var"]
+            outs.append(F.batch_norm(xg, rm, rv, w, b, True, BN_MOMENTUM, BN_EPS))      # updates rm / rv in place
+            st[prefix + ".num_batches_tracked"] = st[prefix + ".num_batches_tracked"] + 1
+        return torch.cat(outs, 0) if bn_groups > 1 else outs[0]
     outs = []
     for xg in x.chunk(bn_groups, dim=0):
         dims = [d for d in range(xg.dim()) if d != 1]

@@ -1,0 +1,119 @@
+"""Whole-network parity on the GPU: HIP path vs the reference-generated fixtures and the CPU oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import medt_oracle as O
+
+pytestmark = pytest.mark.gpu
+MODEL_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(H.GOLDEN, "model_*.npz")))
+TOL = 1e-3
+
+
+def build(name, S, device, chan=3):
+    import lib as droplib
+    f = {"axialunet": droplib.models.axialunet, "gatedaxialunet": droplib.models.axialnet.gated,
+         "MedT": droplib.models.axialnet.MedT, "logo": droplib.models.axialnet.logo}[name]
+    return f(img_size=S, imgchan=chan).to(device)
+
+
+@pytest.mark.parametrize("fn", MODEL_FILES)
+def test_model_vs_reference_fixture(fn, device):
+    """Tolerances.  eval / evalgrad (running statistics): 1e-3 relative, everything.
+    train (batch statistics): logits 1e-3 or 3x the reference's own fp32-vs-fp64 discrepancy, whichever
+    is larger; gradients within 3x max(reference fp32 noise, 5 % of the norm) -- the whole-network
+    training-mode backward is ill-conditioned in fp32 for the reference itself (fixture 'grad_noise',
+    DESIGN.md 'parity floor'); the exact backward wiring is pinned by the evalgrad fixtures and by the
+    layer-level tests at 1e-3."""
+    fx = H.load_golden(fn)
+    name = fn.split("_")[1]
+    S, N, seed, _ = [int(v) for v in fx["meta"]]
+    mode = str(fx["mode"])
+    model = build(name, S, device)
+    model.load_state_dict(H.seeded_state(name, S, seed))
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.train(mode == "train")
+    x, y = H.seeded_input(seed + 1, N, 3, S)
+    if mode == "eval":
+        with torch.no_grad():
+            out = model(x.to(device))
+    else:
+        out = model(x.to(device))
+    want = torch.from_numpy(fx["logits"])
+    err = H.rel_err(out, want)
+    ltol = max(TOL, 3 * float(fx["logits_noise"][0])) if mode == "train" else TOL
+    assert err < ltol, err
+    if mode != "train":
+        # label maps (reference thresholds logits at 0.5, train.py:144-145) and argmax: bit-exact away from ties
+        o = out.detach().double().cpu()
+        safe = (want.double() - 0.5).abs() > 1e-3 * want.abs().max()
+        assert torch.equal((o >= 0.5)[safe], (want >= 0.5)[safe])
+        margin = (want[:, 1] - want[:, 0]).abs() > 1e-3 * want.abs().max()
+        assert torch.equal(o.argmax(1)[margin], want.argmax(1)[margin])
+    if mode == "eval":
+        return
+    loss = torch.nn.functional.cross_entropy(out, y.to(device))
+    assert abs(loss.item() - fx["loss"][0]) < (1e-4 if mode == "evalgrad" else 1e-3)
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    names, summ, noise = list(fx["grad_names"]), fx["grad_summary"], fx["grad_noise"]
+    gmax = summ[:, 0].max()
+    bad = []
+    for k, (norm, dot), (nz, _) in zip(names, summ, noise):
+        g = params[k].grad.double().cpu().reshape(-1)
+        scale = max(norm, 1e-3 * gmax)
+        tol_abs = TOL * scale if mode == "evalgrad" else 3 * max(nz, 0.05 * scale)
+        if abs(g.norm().item() - norm) > tol_abs:
+            bad.append((k, "norm", g.norm().item(), norm))
+        d = torch.dot(g, H.probe_vector(k, g.numel(), seed)).item()
+        if abs(d - dot) > 5 * tol_abs:
+            bad.append((k, "dot", d, dot))
+    assert not bad, bad[:8]
+    for k in fx:
+        if k.startswith("grad/"):
+            w = torch.from_numpy(fx[k])
+            scale = max(w.abs().max().item(), 1e-3 * gmax)
+            tol_abs = TOL * scale if mode == "evalgrad" else 4 * max(float(fx["gradnoise/" + k[5:]][0]), 0.05 * scale)
+            assert (params[k[5:]].grad.double().cpu() - w).abs().max().item() < tol_abs, k
+    if mode == "train":
+        sd = model.state_dict()
+        for k, (norm, dot), nz in zip(list(fx["buf_names"]), fx["buf_summary"], fx["buf_noise"]):
+            v = sd[k].double().cpu().reshape(-1)
+            if k.endswith("num_batches_tracked"):
+                assert float(v.item()) == norm, k
+            else:
+                tol_abs = max(TOL * max(norm, 1e-3), 4 * nz)          # reference's own fp32 noise on this buffer
+                assert abs(v.norm().item() - norm) < tol_abs, k
+                assert abs(torch.dot(v, H.probe_vector(k, v.numel(), seed)).item() - dot) < 5 * tol_abs, k
+
+
+def test_gated_evalgrad_vs_oracle_full(device):
+    """Running-statistics mode, every gradient tensor compared in full against the live fp64 oracle."""
+    name, S, N = "gatedaxialunet", 64, 2
+    model = build(name, S, device)
+    st = O.randomize_state({k: v.cpu() for k, v in model.state_dict().items()}, 21)
+    model.load_state_dict(st)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.eval()
+    x, y = H.seeded_input(22, N, 3, S)
+    out = model(x.to(device))
+    torch.nn.functional.cross_entropy(out, y.to(device)).backward()
+    ost = O.clone_state(st, torch.float64, requires_grad=True)
+    oout = O.forward(name, x.double(), ost, False)
+    O.log_nll_loss(oout, y).backward()
+    assert H.rel_err(out, oout) < 1e-4
+    gmax = max(v.grad.abs().max().item() for v in ost.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        g = ost[k].grad
+        if g is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0, k
+            continue
+        scale = max(g.abs().max().item(), 1e-3 * gmax)
+        assert (p.grad.double().cpu() - g).abs().max().item() / scale < TOL, k

@@ -65,13 +65,14 @@ def test_model_oracle_matches_reference_fixture(fn):
     fx = H.load_golden(fn)
     name = fn.split("_")[1]
     S, N, seed, training = [int(v) for v in fx["meta"]]
+    mode = str(fx["mode"])
     x, y = H.seeded_input(seed + 1, N, 3, S)
     xs = x.double()
     assert abs(xs.sum().item() - fx["x_checksum"][0]) < 1e-6, "CPU RNG contract changed: regenerate fixtures"
-    st = O.clone_state(H.seeded_state(name, S, seed), torch.float64, requires_grad=bool(training))
-    out = O.forward(name, xs, st, bool(training))
+    st = O.clone_state(H.seeded_state(name, S, seed), torch.float64, requires_grad=(mode != "eval"))
+    out = O.forward(name, xs, st, mode == "train")
     assert H.rel_err(out, fx["logits"]) < 1e-6            # fixture logits are stored as float32
-    if not training:
+    if mode == "eval":
         return
     loss = O.log_nll_loss(out, y)
     assert abs(loss.item() - fx["loss"][0]) < 1e-10
@@ -85,12 +86,13 @@ def test_model_oracle_matches_reference_fixture(fn):
     for k in fx:
         if k.startswith("grad/"):
             assert (st[k[5:]].grad - torch.from_numpy(fx[k])).abs().max().item() < 1e-9 * gmax + 1e-12, k
-    for k, (norm, dot) in zip(list(fx["buf_names"]), fx["buf_summary"]):
-        v = st[k].reshape(-1).double()
-        if k.endswith("num_batches_tracked"):
-            assert float(v.item()) == norm, k
-        else:
-            assert abs(v.norm().item() - norm) < 1e-9 * max(norm, 1.0), k
+    if mode == "train":
+        for k, (norm, dot) in zip(list(fx["buf_names"]), fx["buf_summary"]):
+            v = st[k].reshape(-1).double()
+            if k.endswith("num_batches_tracked"):
+                assert float(v.item()) == norm, k
+            else:
+                assert abs(v.norm().item() - norm) < 1e-9 * max(norm, 1.0), k
 
 
 def test_medt_batched_patches_equals_loop():
@@ -101,6 +103,24 @@ def test_medt_batched_patches_equals_loop():
     b = O.clone_state(st0, torch.float64)
     ya = O.medt(x.double(), a, True, batch_patches=False)
     yb = O.medt(x.double(), b, True, batch_patches=True)
+    assert H.rel_err(yb, ya) < 1e-10
+    for k in a:
+        if "running" in k or "num_batches" in k:
+            assert H.rel_err(b[k].double(), a[k].double()) < 1e-10, k
+
+
+def test_fast_bn_mode_is_the_same_arithmetic():
+    """bench.py's cpu_baseline leg runs the oracle with aten's fused BatchNorm; it must be the same function."""
+    st0 = H.seeded_state("gatedaxialunet", 64, 8)
+    x, _ = H.seeded_input(9, 2, 3, 64)
+    a = O.clone_state(st0, torch.float64)
+    b = O.clone_state(st0, torch.float64)
+    ya = O.forward("gatedaxialunet", x.double(), a, True)
+    O.set_fast_bn(True)
+    try:
+        yb = O.forward("gatedaxialunet", x.double(), b, True)
+    finally:
+        O.set_fast_bn(False)
     assert H.rel_err(yb, ya) < 1e-10
     for k in a:
         if "running" in k or "num_batches" in k:
