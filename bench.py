@@ -186,26 +186,24 @@ def main():
         print(json.dumps({"roofline": roofline_leg(device)}))
         return
 
+    import medt_amd
     from medt_amd import dp
+    from medt_amd.optim import FlatAdam
     torch.manual_seed(3000)                              # train.py:118
     model = build_model(args.model, args.imgsize, device)
     model.train()
     dp.broadcast_parameters(model)
-    opt = torch.optim.Adam(list(model.parameters()), lr=1e-3, weight_decay=1e-5)     # train.py:111-112
+    opt = FlatAdam(list(model.parameters()), lr=1e-3, weight_decay=1e-5)             # train.py:111-112
     g = torch.Generator().manual_seed(3000 + rank)
     x = torch.rand(args.batch, 3, args.imgsize, args.imgsize, generator=g).to(device)
     y = torch.randint(0, 2, (args.batch, args.imgsize, args.imgsize), generator=g).to(device)
-    bucket = None
 
     def step():
-        nonlocal bucket
         out = model(x)
-        loss = torch.nn.functional.cross_entropy(out, y)
-        opt.zero_grad(set_to_none=True)
+        loss = medt_amd.cross_entropy(out, y)            # LogNLLLoss (metrics.py:17-20)
+        opt.zero_grad()
         loss.backward()
-        if world > 1:
-            bucket = dp.allreduce_gradients(model, bucket)
-        opt.step()
+        opt.step()                                       # pack grads -> flat bucket, all-reduce (N>1), fused Adam
         return loss
 
     log("model built; warm-up")

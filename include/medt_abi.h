@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 1
+#define MEDT_ABI_VERSION 2
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -62,6 +62,7 @@ typedef struct medt_axial_desc {
                                stats receive the groups' updates in order.        */
     float   eps;            /* 1e-5 */
     float   momentum;       /* 0.1  */
+    int32_t out_relu;       /* 1: fuse the block's ReLU after the width layer (:333) into the output pass */
 } medt_axial_desc;
 
 typedef struct medt_bn_ptrs {
@@ -113,9 +114,9 @@ int medt_axial_layer_fwd(const medt_axial_desc*, const medt_axial_params*, const
 /* dy (N,C,H/stride,W/stride) -> dx (N,C,H,W) + parameter gradients.  Training-mode
  * statistics are differentiated through (the reference's autograd does); with
  * desc.training == 0 the BatchNorms are the affine maps of their running stats. */
-int medt_axial_layer_bwd(const medt_axial_desc*, const medt_axial_params*, const float* x, const float* dy,
-                         const medt_axial_saved*, float* dx, const medt_axial_grads*,
-                         void* workspace, size_t workspace_bytes, void* stream);
+int medt_axial_layer_bwd(const medt_axial_desc*, const medt_axial_params*, const float* x, const float* y,
+                         const float* dy, const medt_axial_saved*, float* dx, const medt_axial_grads*,
+                         void* workspace, size_t workspace_bytes, void* stream);   /* y: forward output, needed iff out_relu */
 
 /* The two L x L stages on their own, for benchmarks / profiling (bench.py's roofline leg).
  * qkv_raw -> [logit statistics partials] and qkv_raw -> stacked, lse, given the BN
@@ -124,6 +125,65 @@ int medt_axial_core_stats(const medt_axial_desc*, const medt_axial_params*, cons
                           void* workspace, size_t workspace_bytes, void* stream);
 int medt_axial_core_fwd(const medt_axial_desc*, const medt_axial_params*, const medt_axial_saved*,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Convolution block:  y = act( BN( conv2d(x, w) + bias ) + res )
+ *   replaces the nn.Conv2d / nn.BatchNorm2d / ReLU / residual-add sequences of
+ *   AxialBlock*.forward (lib/models/axialnet.py:285-300, 327-342, 373-389), the stems
+ *   (:475-483, :623-632, :666-678), downsample (:450-454), decoders / adjust (:434-439, :493-502).
+ * ------------------------------------------------------------------------- */
+typedef struct medt_conv_desc {
+    int32_t N, Cin, H, W, Cout;
+    int32_t K, stride, pad;       /* square kernels: 1, 3 or 7                                   */
+    int32_t has_bias;             /* nn.Conv2d bias                                              */
+    int32_t has_bn;               /* BatchNorm2d on the conv output                              */
+    int32_t has_res;              /* residual added after BN (block identity / downsample)       */
+    int32_t relu;                 /* ReLU last                                                   */
+    int32_t training, bn_groups;  /* as in medt_axial_desc                                       */
+    float   eps, momentum;
+} medt_conv_desc;
+
+size_t medt_conv_stats_floats(const medt_conv_desc*);      /* 4*bn_groups*Cout if has_bn else 0 */
+size_t medt_conv_workspace_bytes(const medt_conv_desc*);   /* max over fwd and bwd              */
+
+/* z: conv output (N,Cout,Ho,Wo), kept for backward when has_bn (pass z == y otherwise). */
+int medt_conv_block_fwd(const medt_conv_desc*, const float* x, const float* w, const float* bias,
+                        const medt_bn_ptrs* bn, const float* res, float* z, float* y, float* stats,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* dx, dbias, dres may be NULL (not needed).  dw, dbn_weight, dbn_bias are written, not accumulated. */
+int medt_conv_block_bwd(const medt_conv_desc*, const float* x, const float* w, const medt_bn_ptrs* bn,
+                        const float* z, const float* y, const float* stats, const float* dy,
+                        float* dx, float* dw, float* dbias, float* dbn_weight, float* dbn_bias, float* dres,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = relu(bilinear_x2(x)) + skip       F.interpolate(scale_factor=(2,2), mode='bilinear') + relu + torch.add
+ * (lib/models/axialnet.py:493-501, 650-652, 690-698).  x (NC,H,W) -> y (NC,2H,2W); skip may be NULL.
+ * Backward: dskip = dy (aliased by the caller), dx via medt_up2x_relu_bwd (needs x to rebuild the ReLU mask). */
+int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream);
+int medt_up2x_relu_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, void* stream);
+
+/* LoGo local branch plumbing (lib/models/axialnet.py:658-702): gather the G x G grid of P-px patches of
+ * x (N,C,S,S) into (G*G*N, C, P, P), patch-major;  y = x + x_loc with x_loc = x overwritten by the patches. */
+int medt_patch_gather(const float* x, float* xp, int N, int C, int S, int P, int G, void* stream);
+int medt_logo_merge_fwd(const float* x, const float* yp, float* y, int N, int C, int S, int P, int G, void* stream);
+int medt_logo_merge_bwd(const float* dy, float* dx, float* dyp, int N, int C, int S, int P, int G, void* stream);
+
+/* LogNLLLoss.forward == F.cross_entropy(mean, ignore_index) (metrics.py:17-20).  logits (N,K,HW) float,
+ * target (N,HW) int64.  loss_out: 2 floats [mean loss, number of counted pixels].  partials: medt_ce_partials() floats. */
+size_t medt_ce_partials(int N, int HW);
+int medt_ce_fwd(const float* logits, const int64_t* target, float* partials, float* loss_out, int N, int K, int HW,
+                int ignore_index, void* stream);
+int medt_ce_bwd(const float* logits, const int64_t* target, const float* loss_out, const float* dloss, float* dlogits,
+                int N, int K, int HW, int ignore_index, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) over one flat buffer (train.py:111-112,161).
+ * state: 3 device floats [step, 1-b1^step, 1-b2^step], zero-initialised; advanced on the device so a captured
+ * hipGraph replays the right bias correction.  g is multiplied by gscale first (1/world_size after all-reduce). */
+int medt_adam_step(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float gscale, void* stream);
+
+/* out = a * (y > 0) elementwise (ReLU backward by output sign). */
+int medt_relu_mask(const float* a, const float* y, float* out, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

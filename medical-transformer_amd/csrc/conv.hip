@@ -1,0 +1,271 @@
+// conv.hip -- direct NCHW fp32 convolutions for the encoder/decoder around the attention layers
+// (reference lib/models/axialnet.py:416-419, 434-439, 557-562, 581-588: 7x7 s2, 3x3 s1/s2, 1x1 s1/s2).
+//
+// The reference dispatches these to cuDNN/MIOpen; at this model's sizes (8..256 channels on 2x2..128x128
+// maps) MIOpen falls back to naive / badly-shaped solvers (rocprof: 0.5-1.1 ms per call), so they are
+// written directly: lanes run along output pixels (coalesced NCHW rows), every lane keeps OT output
+// channels in registers, the K*K taps of one input channel are loaded once per lane and the weights
+// arrive through the scalar path (wave-uniform addresses, K*K contiguous floats per (o,c) pair).
+#include "medt_kernels.h"
+
+namespace medt {
+
+// --------------------------------------------------------------------------- //
+// forward:  y[n,o,ho,wo] = bias[o] + sum_{c,kh,kw} w[o,c,kh,kw] * x[n,c,ho*s-p+kh,wo*s-p+kw]
+// optional per-channel [sum, sum^2] partials laid out [n][ptile][Cout][2] (BatchNorm statistics)
+// --------------------------------------------------------------------------- //
+template <int K, int OT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu) {
+    constexpr int KK = K * K;
+    __shared__ float red[MEDT_WAVES * OT * 2];
+    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, o0 = blockIdx.z * OT;
+    const bool ok = p < Ho * Wo;
+    const int ho = ok ? p / Wo : 0, wo = ok ? p - ho * Wo : 0;
+    const int h0 = ho * stride - pad, w0 = wo * stride - pad;
+    float acc[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) acc[o] = bias ? bias[o0 + o] : 0.f;
+    const float* xn = x + (size_t)n * Cin * H * W;
+    for (int c = 0; c < Cin; ++c) {
+        float xv[KK];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int h = h0 + kh, ww = w0 + kw;
+                xv[kh * K + kw] = (ok && h >= 0 && h < H && ww >= 0 && ww < W) ? xn[((size_t)c * H + h) * W + ww] : 0.f;
+            }
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            const float* wp = w + ((size_t)(o0 + o) * Cin + c) * KK;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[o] = fmaf(wp[t], xv[t], acc[o]);
+        }
+    }
+    if (ok) {
+        float* yp = y + ((size_t)n * Cout + o0) * Ho * Wo + p;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) yp[(size_t)o * Ho * Wo] = relu ? fmaxf(acc[o], 0.f) : acc[o];
+    }
+    if (partials) {
+        float v[2 * OT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            const float a = ok ? acc[o] : 0.f;
+            v[2 * o] = a;
+            v[2 * o + 1] = a * a;
+        }
+        block_sum<2 * OT>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * Cout + o0) * 2);
+    }
+}
+
+template <int K>
+static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin,
+                        int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, hipStream_t s) {
+    const int pt = cdiv(Ho * Wo, MEDT_THREADS);
+    constexpr int OTmax = K == 7 ? 8 : 16;
+    if (Cout % OTmax == 0)
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, OTmax>), dim3(pt, N, Cout / OTmax), dim3(MEDT_THREADS), 0, s, x, w, bias,
+                           y, partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+    else if (Cout % 8 == 0)
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 8>), dim3(pt, N, Cout / 8), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
+                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+    else if (Cout % 2 == 0)
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 2>), dim3(pt, N, Cout / 2), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
+                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+    else
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 1>), dim3(pt, N, Cout), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
+                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+    return launch_status("conv2d_fwd");
+}
+
+int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
+               int W, int Cout, int K, int stride, int pad, int relu, hipStream_t s) {
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    switch (K) {
+        case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, s);
+        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, s);
+        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, s);
+    }
+    set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K);
+    return MEDT_EUNSUPPORTED;
+}
+
+// --------------------------------------------------------------------------- //
+// backward-data:  dx[n,c,h,w] = sum_{o,kh,kw} w[o,c,kh,kw] * dy[n,o,(h+p-kh)/s,(w+p-kw)/s]
+// --------------------------------------------------------------------------- //
+template <int K, int CT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
+    const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin, int H, int W, int Cout,
+    int Ho, int Wo, int stride, int pad) {
+    constexpr int KK = K * K;
+    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c0 = blockIdx.z * CT;
+    const bool ok = p < H * W;
+    const int h = ok ? p / W : 0, ww = ok ? p - h * W : 0;
+    // per-tap source coordinates are channel-independent: precompute offsets (-1 = no contribution)
+    int off[KK];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int hh = h + pad - kh, wq = ww + pad - kw;
+            int o = -1;
+            if (ok && hh >= 0 && wq >= 0 && hh % stride == 0 && wq % stride == 0) {
+                const int ho = hh / stride, wo = wq / stride;
+                if (ho < Ho && wo < Wo) o = ho * Wo + wo;
+            }
+            off[kh * K + kw] = o;
+        }
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
+    for (int o = 0; o < Cout; ++o) {
+        float dv[KK];
+#pragma unroll
+        for (int t = 0; t < KK; ++t) dv[t] = off[t] >= 0 ? dyn[(size_t)o * Ho * Wo + off[t]] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float* wp = w + ((size_t)o * Cin + c0 + c) * KK;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
+        }
+    }
+    if (ok) {
+        float* dp = dx + ((size_t)n * Cin + c0) * H * W + p;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) dp[(size_t)c * H * W] = acc[c];
+    }
+}
+
+template <int K>
+static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int Ho,
+                             int Wo, int stride, int pad, hipStream_t s) {
+    const int pt = cdiv(H * W, MEDT_THREADS);
+    constexpr int CTmax = K == 7 ? 4 : 16;
+    if (Cin % CTmax == 0)
+        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CTmax>), dim3(pt, N, Cin / CTmax), dim3(MEDT_THREADS), 0, s, dy, w,
+                           dx, Cin, H, W, Cout, Ho, Wo, stride, pad);
+    else if (Cin % 8 == 0 && K != 7)
+        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 8>), dim3(pt, N, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, w, dx, Cin,
+                           H, W, Cout, Ho, Wo, stride, pad);
+    else
+        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 1>), dim3(pt, N, Cin), dim3(MEDT_THREADS), 0, s, dy, w, dx, Cin, H,
+                           W, Cout, Ho, Wo, stride, pad);
+    return launch_status("conv2d_bwd_data");
+}
+
+int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int K,
+                    int stride, int pad, hipStream_t s) {
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    switch (K) {
+        case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
+        case 3: return conv2d_bwd_data_k<3>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
+        case 7: return conv2d_bwd_data_k<7>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
+    }
+    set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K);
+    return MEDT_EUNSUPPORTED;
+}
+
+// --------------------------------------------------------------------------- //
+// backward-weight:  dw[o,c,kh,kw] = sum_{n,ho,wo} dy[n,o,ho,wo] * x[n,c,ho*s-p+kh,wo*s-p+kw]
+// One workgroup = one tap (kh,kw) x one 64(o) x 64(c) tile x one chunk of output pixels;
+// 64-pixel LDS steps, 4x4 register tile per lane; chunk partials reduced by reduce_rows.
+// --------------------------------------------------------------------------- //
+#define CW_PIX_PER_SPLIT 1024
+__global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_weight_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H,
+    int W, int Cout, int Ho, int Wo, int K, int stride, int pad) {
+    __shared__ float A[64][65];
+    __shared__ float X[64][65];
+    const int KK = K * K;
+    const int o0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tap = blockIdx.z % KK, split = blockIdx.z / KK;
+    const int kh = tap / K, kw = tap - kh * K;
+    const int HoWo = Ho * Wo;
+    const long NP = (long)N * HoWo;
+    const long q_begin = (long)split * CW_PIX_PER_SPLIT;
+    const long q_end = q_begin + CW_PIX_PER_SPLIT < NP ? q_begin + CW_PIX_PER_SPLIT : NP;
+    const int to = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+        for (int e = threadIdx.x; e < 64 * 64; e += MEDT_THREADS) {
+            const int r = e >> 6, j = e & 63;
+            const long q = q0 + j;
+            float a = 0.f, b = 0.f;
+            if (q < q_end) {
+                const int n = (int)(q / HoWo), p = (int)(q - (long)n * HoWo);
+                if (o0 + r < Cout) a = dy[((size_t)n * Cout + o0 + r) * HoWo + p];
+                if (c0 + r < Cin) {
+                    const int ho = p / Wo, wo = p - ho * Wo;
+                    const int h = ho * stride - pad + kh, ww = wo * stride - pad + kw;
+                    if (h >= 0 && h < H && ww >= 0 && ww < W) b = x[(((size_t)n * Cin + c0 + r) * H + h) * W + ww];
+                }
+            }
+            A[r][j] = a;
+            X[r][j] = b;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < 64; ++j) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = A[to + 16 * a][j];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = X[tc + 16 * b][j];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(av[a], bv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)split * Cout * Cin * KK;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int o = o0 + to + 16 * a, c = c0 + tc + 16 * b;
+            if (o < Cout && c < Cin) out[((size_t)o * Cin + c) * KK + tap] = acc[a][b];
+        }
+}
+
+int conv2d_bwd_weight_splits(int N, int Ho, int Wo) { return cdiv(N * Ho * Wo, CW_PIX_PER_SPLIT); }
+
+int conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int N, int Cin, int H, int W, int Cout,
+                      int K, int stride, int pad, hipStream_t s) {
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    const int splits = conv2d_bwd_weight_splits(N, Ho, Wo);
+    hipLaunchKernelGGL(conv2d_bwd_weight_kernel, dim3(cdiv(Cout, 64), cdiv(Cin, 64), K * K * splits), dim3(MEDT_THREADS),
+                       0, s, dy, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad);
+    int rc = launch_status("conv2d_bwd_weight");
+    if (rc) return rc;
+    return reduce_rows(scratch, splits, Cout * Cin * K * K, dw, s);
+}
+
+// per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients)
+__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                   int N, int C, int HW) {
+    __shared__ float red[MEDT_WAVES];
+    const int c = blockIdx.x;
+    float v[1] = {0.f};
+    const long total = (long)N * HW;
+    for (long q = threadIdx.x; q < total; q += MEDT_THREADS) {
+        const int n = (int)(q / HW), p = (int)(q - (long)n * HW);
+        v[0] += x[((size_t)n * C + c) * HW + p];
+    }
+    block_sum<1>(v, red, out + c);
+}
+
+int channel_sum(const float* x, float* out, int N, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(MEDT_THREADS), 0, s, x, out, N, C, HW);
+    return launch_status("channel_sum");
+}
+
+}  // namespace medt

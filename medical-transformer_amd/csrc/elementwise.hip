@@ -1,0 +1,385 @@
+// elementwise.hip -- the streaming kernels between the convolutions and the attention layers:
+//   BatchNorm2d apply (+residual, +ReLU) and its backward   (axialnet.py:285-300, 475-483)
+//   bilinear x2 upsample + ReLU + skip-add                   (axialnet.py:493-501, 650-652, 690-698)
+//   LoGo patch gather / merge                                (axialnet.py:658-702)
+//   cross-entropy loss                                       (metrics.py:17-20)
+//   Adam with coupled L2 weight decay over a flat buffer     (train.py:111-112,161)
+// All HBM-bound: one element per lane, NCHW rows coalesced, per-channel constants via scalar loads.
+#include "medt_kernels.h"
+
+namespace medt {
+
+static inline unsigned grid1d(size_t total) { return (unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS); }
+
+// y = [relu]( z*scale[g,c] + shift[g,c] [+ res] )         grid (ptiles, N, C)
+__global__ __launch_bounds__(MEDT_THREADS) void bn_apply_act_kernel(const float* __restrict__ z, BnStats st,
+                                                                    const float* __restrict__ res,
+                                                                    float* __restrict__ y, int C, int HW, int npg,
+                                                                    int relu) {
+    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c = blockIdx.z;
+    if (p >= HW) return;
+    const int gc = (n / npg) * C + c;
+    const size_t idx = ((size_t)n * C + c) * HW + p;
+    float v = fmaf(z[idx], st.scale[gc], st.shift[gc]);
+    if (res) v += res[idx];
+    if (relu) v = fmaxf(v, 0.f);
+    y[idx] = v;
+}
+
+int bn_apply_act(const float* z, BnStats st, const float* res, float* y, int N, int C, int HW, int groups, int relu,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(bn_apply_act_kernel, dim3(cdiv(HW, MEDT_THREADS), N, C), dim3(MEDT_THREADS), 0, s, z, st, res, y,
+                       C, HW, N / groups, relu);
+    return launch_status("bn_apply_act");
+}
+
+// g = dy * (y > 0 if relu) ; partials[n][ptile][C][2] = [sum g, sum g*zhat]       grid (ptiles, N, C)
+__global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_stats_kernel(const float* __restrict__ dy,
+                                                                        const float* __restrict__ y,
+                                                                        const float* __restrict__ z, BnStats st,
+                                                                        float* __restrict__ g,
+                                                                        float* __restrict__ partials, int C, int HW,
+                                                                        int npg, int relu) {
+    __shared__ float red[MEDT_WAVES * 2];
+    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c = blockIdx.z;
+    float v[2] = {0.f, 0.f};
+    if (p < HW) {
+        const int gc = (n / npg) * C + c;
+        const size_t idx = ((size_t)n * C + c) * HW + p;
+        float d = dy[idx];
+        if (relu && !(y[idx] > 0.f)) d = 0.f;
+        if (g) g[idx] = d;
+        v[0] = d;
+        v[1] = d * ((z[idx] - st.mean[gc]) * st.rstd[gc]);
+    }
+    block_sum<2>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * C + c) * 2);
+}
+
+int bn_act_bwd_stats(const float* dy, const float* y, const float* z, BnStats st, float* g, float* partials, int N, int C,
+                     int HW, int groups, int relu, hipStream_t s) {
+    hipLaunchKernelGGL(bn_act_bwd_stats_kernel, dim3(cdiv(HW, MEDT_THREADS), N, C), dim3(MEDT_THREADS), 0, s, dy, y, z,
+                       st, g, partials, C, HW, N / groups, relu);
+    return launch_status("bn_act_bwd_stats");
+}
+
+// dz = c0*g + c1*z + c2   (coef [group][C][3])
+__global__ __launch_bounds__(MEDT_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ g,
+                                                                    const float* __restrict__ z,
+                                                                    const float* __restrict__ coef,
+                                                                    float* __restrict__ dz, int C, int HW, int npg) {
+    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c = blockIdx.z;
+    if (p >= HW) return;
+    const float* cf = coef + ((size_t)(n / npg) * C + c) * 3;
+    const size_t idx = ((size_t)n * C + c) * HW + p;
+    dz[idx] = fmaf(cf[0], g[idx], fmaf(cf[1], z[idx], cf[2]));
+}
+
+int bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, int N, int C, int HW, int groups,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(HW, MEDT_THREADS), N, C), dim3(MEDT_THREADS), 0, s, g, z, coef, dz,
+                       C, HW, N / groups);
+    return launch_status("bn_bwd_apply");
+}
+
+// out = a * (y > 0)            (ReLU backward by output sign)
+__global__ __launch_bounds__(MEDT_THREADS) void relu_mask_kernel(const float* __restrict__ a, const float* __restrict__ y,
+                                                                 float* __restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (i < total) out[i] = y[i] > 0.f ? a[i] : 0.f;
+}
+
+int relu_mask(const float* a, const float* y, float* out, size_t total, hipStream_t s) {
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, a, y, out, total);
+    return launch_status("relu_mask");
+}
+
+// y = relu(x)  /  y = relu(x) in place of a previous ReLU-free tensor
+__global__ __launch_bounds__(MEDT_THREADS) void relu_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            size_t total) {
+    const size_t i = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (i < total) y[i] = fmaxf(x[i], 0.f);
+}
+
+int relu_fwd(const float* x, float* y, size_t total, hipStream_t s) {
+    hipLaunchKernelGGL(relu_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, x, y, total);
+    return launch_status("relu");
+}
+
+// --------------------------------------------------------------------------- //
+// bilinear x2 (align_corners=False) + ReLU + skip-add
+// --------------------------------------------------------------------------- //
+struct Lerp { int i0, i1; float l; };
+__device__ __forceinline__ Lerp src_index(int o, int n_in) {
+    float s = 0.5f * ((float)o + 0.5f) - 0.5f;         // aten area_pixel_compute_source_index, scale = 1/2
+    if (s < 0.f) s = 0.f;
+    Lerp r;
+    r.i0 = (int)s;
+    r.i1 = r.i0 + (r.i0 < n_in - 1 ? 1 : 0);
+    r.l = s - (float)r.i0;
+    return r;
+}
+
+__device__ __forceinline__ float up_sample(const float* __restrict__ xp, int H, int W, int ho, int wo) {
+    const Lerp a = src_index(ho, H), b = src_index(wo, W);
+    const float v00 = xp[a.i0 * W + b.i0], v01 = xp[a.i0 * W + b.i1], v10 = xp[a.i1 * W + b.i0], v11 = xp[a.i1 * W + b.i1];
+    const float h0 = 1.f - a.l, w0 = 1.f - b.l;
+    return h0 * (w0 * v00 + b.l * v01) + a.l * (w0 * v10 + b.l * v11);
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void up2x_relu_add_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ skip,
+                                                                     float* __restrict__ y, int H, int W, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int Wo = 2 * W, Ho = 2 * H;
+    const int wo = (int)(idx % Wo), ho = (int)((idx / Wo) % Ho);
+    const size_t nc = idx / ((size_t)Wo * Ho);
+    float v = fmaxf(up_sample(x + nc * H * W, H, W, ho, wo), 0.f);
+    if (skip) v += skip[idx];
+    y[idx] = v;
+}
+
+int up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)NC * 4 * H * W;
+    hipLaunchKernelGGL(up2x_relu_add_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, x, skip, y, H, W, total);
+    return launch_status("up2x_relu_add");
+}
+
+// dx[h,w] = sum over the (<=16) output pixels whose interpolation touches (h,w) of weight * dy * [up(x) > 0]
+__global__ __launch_bounds__(MEDT_THREADS) void up2x_relu_bwd_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ dy,
+                                                                     float* __restrict__ dx, int H, int W, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % W), h = (int)((idx / W) % H);
+    const size_t nc = idx / ((size_t)W * H);
+    const float* xp = x + nc * H * W;
+    const float* dp = dy + nc * 4 * H * W;
+    const int Ho = 2 * H, Wo = 2 * W;
+    float acc = 0.f;
+    for (int ho = 2 * h - 1; ho <= 2 * h + 2; ++ho) {
+        if (ho < 0 || ho >= Ho) continue;
+        const Lerp a = src_index(ho, H);
+        const float wh = (a.i0 == h ? 1.f - a.l : 0.f) + (a.i1 == h ? a.l : 0.f);
+        if (wh == 0.f) continue;
+        for (int wo = 2 * w - 1; wo <= 2 * w + 2; ++wo) {
+            if (wo < 0 || wo >= Wo) continue;
+            const Lerp b = src_index(wo, W);
+            const float ww = (b.i0 == w ? 1.f - b.l : 0.f) + (b.i1 == w ? b.l : 0.f);
+            if (ww == 0.f) continue;
+            if (up_sample(xp, H, W, ho, wo) > 0.f) acc = fmaf(wh * ww, dp[(size_t)ho * Wo + wo], acc);
+        }
+    }
+    dx[idx] = acc;
+}
+
+int up2x_relu_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)NC * H * W;
+    hipLaunchKernelGGL(up2x_relu_bwd_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, x, dy, dx, H, W, total);
+    return launch_status("up2x_relu_bwd");
+}
+
+// --------------------------------------------------------------------------- //
+// LoGo patches: gather (N,C,S,S) -> (G*G*N, C, P, P) patch-major; merge y = x + x_loc
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(MEDT_THREADS) void patch_gather_kernel(const float* __restrict__ x, float* __restrict__ xp,
+                                                                    int N, int C, int S, int P, int G, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % P), h = (int)((idx / P) % P);
+    const int c = (int)((idx / ((size_t)P * P)) % C);
+    const int b = (int)(idx / ((size_t)P * P * C));         // b = patch*N + n
+    const int patch = b / N, n = b - patch * N;
+    const int pi = patch / G, pj = patch - pi * G;
+    xp[idx] = x[(((size_t)n * C + c) * S + pi * P + h) * S + pj * P + w];
+}
+
+int patch_gather(const float* x, float* xp, int N, int C, int S, int P, int G, hipStream_t s) {
+    const size_t total = (size_t)G * G * N * C * P * P;
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, x, xp, N, C, S, P, G, total);
+    return launch_status("patch_gather");
+}
+
+// y = x + x_loc, x_loc = x with the G x G grid of P-px patches (top-left G*P square) overwritten by yp   (:658,:700-702)
+__global__ __launch_bounds__(MEDT_THREADS) void logo_merge_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ yp, float* __restrict__ y,
+                                                                  int N, int C, int S, int P, int G, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % S), h = (int)((idx / S) % S);
+    const int c = (int)((idx / ((size_t)S * S)) % C);
+    const int n = (int)(idx / ((size_t)S * S * C));
+    const float xv = x[idx];
+    float loc = xv;
+    if (h < G * P && w < G * P) {
+        const int patch = (h / P) * G + (w / P);
+        loc = yp[((((size_t)patch * N + n) * C + c) * P + (h % P)) * P + (w % P)];
+    }
+    y[idx] = xv + loc;
+}
+
+int logo_merge_fwd(const float* x, const float* yp, float* y, int N, int C, int S, int P, int G, hipStream_t s) {
+    const size_t total = (size_t)N * C * S * S;
+    hipLaunchKernelGGL(logo_merge_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, x, yp, y, N, C, S, P, G, total);
+    return launch_status("logo_merge");
+}
+
+// dx = dy * (inside patches ? 1 : 2);  dyp = gather(dy)
+__global__ __launch_bounds__(MEDT_THREADS) void logo_merge_bwd_kernel(const float* __restrict__ dy,
+                                                                      float* __restrict__ dx, float* __restrict__ dyp,
+                                                                      int N, int C, int S, int P, int G, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % S), h = (int)((idx / S) % S);
+    const int c = (int)((idx / ((size_t)S * S)) % C);
+    const int n = (int)(idx / ((size_t)S * S * C));
+    const float d = dy[idx];
+    if (h < G * P && w < G * P) {
+        const int patch = (h / P) * G + (w / P);
+        dyp[((((size_t)patch * N + n) * C + c) * P + (h % P)) * P + (w % P)] = d;
+        dx[idx] = d;
+    } else {
+        dx[idx] = 2.f * d;
+    }
+}
+
+int logo_merge_bwd(const float* dy, float* dx, float* dyp, int N, int C, int S, int P, int G, hipStream_t s) {
+    const size_t total = (size_t)N * C * S * S;
+    hipLaunchKernelGGL(logo_merge_bwd_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, dy, dx, dyp, N, C, S, P, G,
+                       total);
+    return launch_status("logo_merge_bwd");
+}
+
+// --------------------------------------------------------------------------- //
+// cross entropy (mean over non-ignored pixels), K classes on dim 1
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(MEDT_THREADS) void ce_fwd_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ target,
+                                                              float* __restrict__ partials, int K, int HW, int ignore,
+                                                              size_t total) {
+    __shared__ float red[MEDT_WAVES * 2];
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;     // over N*HW
+    float v[2] = {0.f, 0.f};
+    if (idx < total) {
+        const size_t n = idx / HW, p = idx - n * HW;
+        const int64_t t = target[idx];
+        if (t != ignore && t >= 0 && t < K) {
+            const float* lp = logits + n * K * HW + p;
+            float m = lp[0];
+            for (int k = 1; k < K; ++k) m = fmaxf(m, lp[(size_t)k * HW]);
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) sum += __expf(lp[(size_t)k * HW] - m);
+            v[0] = m + __logf(sum) - lp[(size_t)t * HW];
+            v[1] = 1.f;
+        }
+    }
+    block_sum<2>(v, red, partials + (size_t)blockIdx.x * 2);
+}
+
+// loss_out[0] = sum/count, loss_out[1] = count
+__global__ __launch_bounds__(64) void ce_finalize_kernel(const float* __restrict__ partials, int nparts,
+                                                         float* __restrict__ loss_out) {
+    double s = 0.0, c = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) {
+        s += (double)partials[2 * p];
+        c += (double)partials[2 * p + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if (threadIdx.x == 0) {
+        loss_out[0] = (float)(s / c);
+        loss_out[1] = (float)c;
+    }
+}
+
+int ce_parts(size_t npix) { return (int)grid1d(npix); }
+
+int ce_fwd(const float* logits, const int64_t* target, float* partials, float* loss_out, int N, int K, int HW, int ignore,
+           hipStream_t s) {
+    const size_t total = (size_t)N * HW;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, logits, target, partials, K, HW,
+                       ignore, total);
+    int rc = launch_status("ce_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, s, partials, (int)grid1d(total), loss_out);
+    return launch_status("ce_finalize");
+}
+
+// dlogits[n,k,p] = (softmax_k - [k == t]) * dloss / count
+__global__ __launch_bounds__(MEDT_THREADS) void ce_bwd_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ target,
+                                                              const float* __restrict__ loss_out,
+                                                              const float* __restrict__ dloss,
+                                                              float* __restrict__ dlogits, int K, int HW, int ignore,
+                                                              size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const size_t n = idx / HW, p = idx - n * HW;
+    const int64_t t = target[idx];
+    const float* lp = logits + n * K * HW + p;
+    float* dp = dlogits + n * K * HW + p;
+    if (t == ignore || t < 0 || t >= K) {
+        for (int k = 0; k < K; ++k) dp[(size_t)k * HW] = 0.f;
+        return;
+    }
+    const float scale = (dloss ? dloss[0] : 1.f) / loss_out[1];
+    float m = lp[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, lp[(size_t)k * HW]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += __expf(lp[(size_t)k * HW] - m);
+    const float inv = 1.f / sum;
+    for (int k = 0; k < K; ++k) {
+        const float pk = __expf(lp[(size_t)k * HW] - m) * inv;
+        dp[(size_t)k * HW] = (pk - (k == t ? 1.f : 0.f)) * scale;
+    }
+}
+
+int ce_bwd(const float* logits, const int64_t* target, const float* loss_out, const float* dloss, float* dlogits, int N,
+           int K, int HW, int ignore, hipStream_t s) {
+    const size_t total = (size_t)N * HW;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, logits, target, loss_out, dloss,
+                       dlogits, K, HW, ignore, total);
+    return launch_status("ce_bwd");
+}
+
+// --------------------------------------------------------------------------- //
+// Adam (torch.optim.Adam semantics, coupled L2 weight decay).  The step counter lives on the device so a
+// captured hipGraph replays correctly: adam_tick advances it and derives the bias corrections.
+//   state[0] = step, state[1] = 1 - b1^step, state[2] = 1 - b2^step
+// --------------------------------------------------------------------------- //
+__global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2) {
+    const float t = state[0] + 1.f;
+    state[0] = t;
+    state[1] = 1.f - powf(b1, t);
+    state[2] = 1.f - powf(b2, t);
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                 float* __restrict__ m, float* __restrict__ v,
+                                                                 const float* __restrict__ state, size_t n, float lr,
+                                                                 float b1, float b2, float eps, float wd,
+                                                                 float gscale) {
+    const size_t i = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float bc1 = state[1], bc2 = state[2];
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i] * gscale);
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+int adam_step(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float b1, float b2,
+              float eps, float wd, float gscale, hipStream_t s) {
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, state, b1, b2);
+    int rc = launch_status("adam_tick");
+    if (rc) return rc;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid1d(n)), dim3(MEDT_THREADS), 0, s, p, g, m, v, state, n, lr, b1, b2, eps,
+                       wd, gscale);
+    return launch_status("adam_step");
+}
+
+}  // namespace medt

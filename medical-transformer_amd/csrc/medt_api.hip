@@ -45,9 +45,10 @@ struct FwdWs {
 };
 
 struct BwdWs {
-    float *part_ob, *coef_out, *part_sb, *coef_sim, *dqkv, *part_qb, *coef_qkv, *rel_part, *gate_part, *dw_scratch;
+    float *part_ob, *coef_out, *part_sb, *coef_sim, *dqkv, *part_qb, *coef_qkv, *rel_part, *gate_part, *dw_scratch,
+        *dy_masked;
     size_t nblocks;
-    BwdWs(Carver& c, const AxialGeom& g) {
+    BwdWs(Carver& c, const AxialGeom& g, int stride, int out_relu) {
         const int pt = conv1x1_ptiles(g.HW), TL = 2 * g.L - 1;
         nblocks = (size_t)g.groups * g.tpg * g.G;
         part_ob = c.take<float>((size_t)g.N * pt * g.OC * 2);
@@ -60,6 +61,7 @@ struct BwdWs {
         rel_part = c.take<float>(g.pos ? nblocks * 2 * g.gp * TL : 0);
         gate_part = c.take<float>(g.pos ? nblocks * 4 : 0);
         dw_scratch = c.take<float>((size_t)conv1x1_bwd_weight_splits(g.N, g.HW) * 2 * g.C * g.C);
+        dy_masked = c.take<float>(out_relu ? (size_t)g.N * g.C * (g.H / stride) * (g.W / stride) : 0);
     }
 };
 
@@ -98,7 +100,7 @@ size_t medt_axial_workspace_bytes(const medt_axial_desc* d) {
     if (!d || axial_geom(*d, &g)) return 0;
     Carver cf(nullptr, 0), cb(nullptr, 0);
     FwdWs f(cf, g);
-    BwdWs b(cb, g);
+    BwdWs b(cb, g, d->stride, d->out_relu);
     return align_up(cf.off > cb.off ? cf.off : cb.off, 256) + 256;
 }
 
@@ -159,9 +161,9 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     return axial_out_fwd(*d, sv->stacked, st.out, y, s);
 }
 
-int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, const float* dy,
-                         const medt_axial_saved* sv, float* dx, const medt_axial_grads* gr, void* ws, size_t ws_bytes,
-                         void* stream) {
+int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, const float* y,
+                         const float* dy, const medt_axial_saved* sv, float* dx, const medt_axial_grads* gr, void* ws,
+                         size_t ws_bytes, void* stream) {
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
@@ -170,13 +172,18 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         !gr->bn_out_weight || !gr->bn_out_bias || (g.pos && !gr->relative)) {
         set_error("null gradient pointer"); return MEDT_EINVAL;
     }
+    if (d->out_relu && !y) { set_error("out_relu backward needs the forward output y"); return MEDT_EINVAL; }
     Carver c(ws, ws_bytes);
-    BwdWs w(c, g);
+    BwdWs w(c, g, d->stride, d->out_relu);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
     const int tr = d->training ? 1 : 0, pt = conv1x1_ptiles(g.HW), TL = 2 * g.L - 1;
+    if (d->out_relu) {               // fused ReLU after the layer: mask the incoming gradient by the output sign
+        if ((rc = relu_mask(dy, y, w.dy_masked, (size_t)g.N * g.C * (g.H / d->stride) * (g.W / d->stride), s))) return rc;
+        dy = w.dy_masked;
+    }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
     if ((rc = axial_out_bwd_stats(*d, sv->stacked, dy, st.out, w.part_ob, s))) return rc;
     if ((rc = bn_bwd_finalize(w.part_ob, g.npg * pt, g.groups, g.OC, g.row_count, 1.f / (float)(d->stride * d->stride),
@@ -203,6 +210,158 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, s))) return rc;
     }
     return MEDT_OK;
+}
+
+
+// ------------------------------------------------------------------------- //
+// convolution block
+// ------------------------------------------------------------------------- //
+}  // extern "C"  (helpers below are C++)
+
+namespace medt {
+struct ConvGeom { int Ho, Wo, HoWo, pt, splits; size_t out_elems; };
+static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
+    if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->stride < 1 || d->pad < 0) {
+        set_error("conv: bad descriptor"); return MEDT_EINVAL;
+    }
+    if (d->K != 1 && d->K != 3 && d->K != 7) { set_error("conv: kernel size %d unsupported (1, 3, 7)", d->K); return MEDT_EUNSUPPORTED; }
+    if (d->has_bn && (d->bn_groups < 1 || d->N % d->bn_groups)) { set_error("conv: bad bn_groups"); return MEDT_EINVAL; }
+    if (d->has_bn && d->has_bias) { set_error("conv: bias followed by BatchNorm is not on the reference's path"); return MEDT_EUNSUPPORTED; }
+    if (!d->has_bn && d->has_res) { set_error("conv: residual without BatchNorm is not on the reference's path"); return MEDT_EUNSUPPORTED; }
+    g->Ho = (d->H + 2 * d->pad - d->K) / d->stride + 1;
+    g->Wo = (d->W + 2 * d->pad - d->K) / d->stride + 1;
+    if (g->Ho <= 0 || g->Wo <= 0) { set_error("conv: empty output"); return MEDT_EINVAL; }
+    g->HoWo = g->Ho * g->Wo;
+    g->pt = cdiv(g->HoWo, MEDT_THREADS);
+    g->splits = conv2d_bwd_weight_splits(d->N, g->Ho, g->Wo);
+    g->out_elems = (size_t)d->N * d->Cout * g->HoWo;
+    return MEDT_OK;
+}
+struct ConvWs {
+    float *partials, *coef, *gbuf, *dz, *dw_scratch;
+    ConvWs(Carver& c, const medt_conv_desc* d, const ConvGeom& g) {
+        partials = c.take<float>(d->has_bn ? (size_t)d->N * g.pt * d->Cout * 2 : 0);
+        coef = c.take<float>(d->has_bn ? (size_t)d->bn_groups * d->Cout * 3 : 0);
+        gbuf = c.take<float>(g.out_elems);
+        dz = c.take<float>(d->has_bn ? g.out_elems : 0);
+        dw_scratch = c.take<float>((size_t)g.splits * d->Cout * d->Cin * d->K * d->K);
+    }
+};
+}  // namespace medt
+
+extern "C" {
+
+size_t medt_conv_stats_floats(const medt_conv_desc* d) {
+    return (d && d->has_bn) ? (size_t)4 * d->bn_groups * d->Cout : 0;
+}
+
+size_t medt_conv_workspace_bytes(const medt_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g)) return 0;
+    Carver c(nullptr, 0);
+    ConvWs w(c, d, g);
+    return align_up(c.off, 256) + 256;
+}
+
+int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w, const float* bias,
+                        const medt_bn_ptrs* bn, const float* res, float* z, float* y, float* stats, void* ws,
+                        size_t ws_bytes, void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g);
+    if (rc) return rc;
+    if (!x || !w || !y || (d->has_bias && !bias) || (d->has_bn && (!bn || !z || !stats)) || (d->has_res && !res)) {
+        set_error("conv fwd: null pointer"); return MEDT_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (!d->has_bn)
+        return conv2d_fwd(x, w, d->has_bias ? bias : nullptr, y, nullptr, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
+                          d->stride, d->pad, d->relu, s);
+    Carver c(ws, ws_bytes);
+    ConvWs cw(c, d, g);
+    if (!ws || !c.ok()) { set_error("conv workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    const int tr = d->training ? 1 : 0;
+    if (!tr && (!bn->running_mean || !bn->running_var)) { set_error("conv fwd: eval mode needs running statistics"); return MEDT_EINVAL; }
+    BnStats st(stats, d->bn_groups * d->Cout);
+    if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
+                         d->pad, 0, s))) return rc;
+    if ((rc = bn_finalize(cw.partials, (d->N / d->bn_groups) * g.pt, d->bn_groups, d->Cout,
+                          (double)(d->N / d->bn_groups) * g.HoWo, *bn, d->momentum, d->eps, tr, st, s))) return rc;
+    return bn_apply_act(z, st, d->has_res ? res : nullptr, y, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s);
+}
+
+int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w, const medt_bn_ptrs* bn, const float* z,
+                        const float* y, const float* stats, const float* dy, float* dx, float* dw, float* dbias,
+                        float* dbn_weight, float* dbn_bias, float* dres, void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g);
+    if (rc) return rc;
+    if (!x || !w || !dy || !dw || (d->relu && !y) || (d->has_bn && (!bn || !z || !stats || !dbn_weight || !dbn_bias)) ||
+        (d->has_bias && !dbias)) { set_error("conv bwd: null pointer"); return MEDT_EINVAL; }
+    Carver c(ws, ws_bytes);
+    ConvWs cw(c, d, g);
+    if (!ws || !c.ok()) { set_error("conv workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    const float* grad_out;              // gradient wrt the convolution output
+    if (d->has_bn) {
+        BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
+        float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
+        if ((rc = bn_act_bwd_stats(dy, y, z, st, gb, cw.partials, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s))) return rc;
+        if ((rc = bn_bwd_finalize(cw.partials, (d->N / d->bn_groups) * g.pt, d->bn_groups, d->Cout,
+                                  (double)(d->N / d->bn_groups) * g.HoWo, 1.f, st, bn->weight, d->training ? 1 : 0, cw.coef,
+                                  dbn_weight, dbn_bias, s))) return rc;
+        if ((rc = bn_bwd_apply(gb, z, cw.coef, cw.dz, d->N, d->Cout, g.HoWo, d->bn_groups, s))) return rc;
+        grad_out = cw.dz;
+    } else if (d->relu) {
+        if ((rc = relu_mask(dy, y, cw.gbuf, g.out_elems, s))) return rc;
+        grad_out = cw.gbuf;
+    } else {
+        grad_out = dy;
+    }
+    if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, s))) return rc;
+    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
+    return conv2d_bwd_weight(grad_out, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s);
+}
+
+int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream) {
+    if (!x || !y || NC <= 0 || H <= 0 || W <= 0) { set_error("up2x fwd: bad arguments"); return MEDT_EINVAL; }
+    return up2x_relu_add_fwd(x, skip, y, NC, H, W, (hipStream_t)stream);
+}
+int medt_up2x_relu_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, void* stream) {
+    if (!x || !dy || !dx || NC <= 0 || H <= 0 || W <= 0) { set_error("up2x bwd: bad arguments"); return MEDT_EINVAL; }
+    return up2x_relu_bwd(x, dy, dx, NC, H, W, (hipStream_t)stream);
+}
+int medt_patch_gather(const float* x, float* xp, int N, int C, int S, int P, int G, void* stream) {
+    if (!x || !xp || G * P > S) { set_error("patch_gather: bad arguments"); return MEDT_EINVAL; }
+    return patch_gather(x, xp, N, C, S, P, G, (hipStream_t)stream);
+}
+int medt_logo_merge_fwd(const float* x, const float* yp, float* y, int N, int C, int S, int P, int G, void* stream) {
+    if (!x || !yp || !y || G * P > S) { set_error("logo_merge: bad arguments"); return MEDT_EINVAL; }
+    return logo_merge_fwd(x, yp, y, N, C, S, P, G, (hipStream_t)stream);
+}
+int medt_logo_merge_bwd(const float* dy, float* dx, float* dyp, int N, int C, int S, int P, int G, void* stream) {
+    if (!dy || !dx || !dyp || G * P > S) { set_error("logo_merge bwd: bad arguments"); return MEDT_EINVAL; }
+    return logo_merge_bwd(dy, dx, dyp, N, C, S, P, G, (hipStream_t)stream);
+}
+size_t medt_ce_partials(int N, int HW) { return (size_t)2 * ce_parts((size_t)N * HW); }
+int medt_ce_fwd(const float* logits, const int64_t* target, float* partials, float* loss_out, int N, int K, int HW,
+                int ignore_index, void* stream) {
+    if (!logits || !target || !partials || !loss_out || K < 1) { set_error("ce fwd: bad arguments"); return MEDT_EINVAL; }
+    return ce_fwd(logits, target, partials, loss_out, N, K, HW, ignore_index, (hipStream_t)stream);
+}
+int medt_ce_bwd(const float* logits, const int64_t* target, const float* loss_out, const float* dloss, float* dlogits,
+                int N, int K, int HW, int ignore_index, void* stream) {
+    if (!logits || !target || !loss_out || !dlogits) { set_error("ce bwd: bad arguments"); return MEDT_EINVAL; }
+    return ce_bwd(logits, target, loss_out, dloss, dlogits, N, K, HW, ignore_index, (hipStream_t)stream);
+}
+int medt_adam_step(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float gscale, void* stream) {
+    if (!p || !g || !m || !v || !state) { set_error("adam: null pointer"); return MEDT_EINVAL; }
+    if (n == 0) return MEDT_OK;
+    return adam_step(p, g, m, v, state, n, lr, beta1, beta2, eps, weight_decay, gscale, (hipStream_t)stream);
+}
+int medt_relu_mask(const float* a, const float* y, float* out, size_t n, void* stream) {
+    if (!a || !y || !out) { set_error("relu_mask: null pointer"); return MEDT_EINVAL; }
+    return relu_mask(a, y, out, n, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -38,6 +38,38 @@ int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const fl
 // out[k] = sum_p in[p][k]
 int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
 
+// ---- conv.hip ------------------------------------------------------------------
+int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
+               int W, int Cout, int K, int stride, int pad, int relu, hipStream_t s);
+int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int K,
+                    int stride, int pad, hipStream_t s);
+int conv2d_bwd_weight_splits(int N, int Ho, int Wo);
+int conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int N, int Cin, int H, int W, int Cout,
+                      int K, int stride, int pad, hipStream_t s);
+int channel_sum(const float* x, float* out, int N, int C, int HW, hipStream_t s);
+
+// ---- elementwise.hip -----------------------------------------------------------
+int bn_apply_act(const float* z, BnStats st, const float* res, float* y, int N, int C, int HW, int groups, int relu,
+                 hipStream_t s);
+int bn_act_bwd_stats(const float* dy, const float* y, const float* z, BnStats st, float* g, float* partials, int N, int C,
+                     int HW, int groups, int relu, hipStream_t s);
+int bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, int N, int C, int HW, int groups,
+                 hipStream_t s);
+int relu_mask(const float* a, const float* y, float* out, size_t total, hipStream_t s);
+int relu_fwd(const float* x, float* y, size_t total, hipStream_t s);
+int up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, hipStream_t s);
+int up2x_relu_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, hipStream_t s);
+int patch_gather(const float* x, float* xp, int N, int C, int S, int P, int G, hipStream_t s);
+int logo_merge_fwd(const float* x, const float* yp, float* y, int N, int C, int S, int P, int G, hipStream_t s);
+int logo_merge_bwd(const float* dy, float* dx, float* dyp, int N, int C, int S, int P, int G, hipStream_t s);
+int ce_parts(size_t npix);
+int ce_fwd(const float* logits, const int64_t* target, float* partials, float* loss_out, int N, int K, int HW, int ignore,
+           hipStream_t s);
+int ce_bwd(const float* logits, const int64_t* target, const float* loss_out, const float* dloss, float* dlogits, int N,
+           int K, int HW, int ignore, hipStream_t s);
+int adam_step(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float b1, float b2,
+              float eps, float wd, float gscale, hipStream_t s);
+
 // ---- axial_core.hip ---------------------------------------------------------
 struct AxialGeom {
     int N, C, H, W, G, gp, hq, L, Bo, axis, pos, OC, OCg, SC;

@@ -319,7 +319,7 @@ int bn_bwd_finalize(const float* partials, int ppg, int groups, int CH, double c
 // --------------------------------------------------------------------------- //
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float* __restrict__ stk, BnStats st,
                                                                      float* __restrict__ y, int N, int C, int H, int W,
-                                                                     int OC, int stride, int npg) {
+                                                                     int OC, int stride, int npg, int relu) {
     const int Ho = H / stride, Wo = W / stride;
     const size_t total = (size_t)N * C * Ho * Wo;
     const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
@@ -340,14 +340,16 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float
             for (int dw = 0; dw < stride; ++dw) a += fmaf(sc, src[(size_t)(ho * stride + dh) * W + wo * stride + dw], sh);
         acc += a;
     }
-    y[idx] = acc * (1.f / (float)(stride * stride));
+    acc *= 1.f / (float)(stride * stride);
+    y[idx] = relu ? fmaxf(acc, 0.f) : acc;
 }
 
 int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s) {
     const int OC = d.has_pos ? 2 * d.C : d.C;
     const size_t total = (size_t)d.N * d.C * (d.H / d.stride) * (d.W / d.stride);
     hipLaunchKernelGGL(axial_out_fwd_kernel, dim3((unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS)),
-                       dim3(MEDT_THREADS), 0, s, stacked, st, y, d.N, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups);
+                       dim3(MEDT_THREADS), 0, s, stacked, st, y, d.N, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups,
+                       d.out_relu);
     return launch_status("axial_out_fwd");
 }
 

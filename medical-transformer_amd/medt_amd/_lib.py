@@ -23,6 +23,13 @@ class MedtError(RuntimeError):
 class AxialDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("G", C.c_int32),
                 ("axis", C.c_int32), ("has_pos", C.c_int32), ("stride", C.c_int32), ("training", C.c_int32),
+                ("bn_groups", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float), ("out_relu", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32),
+                ("K", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("has_bias", C.c_int32),
+                ("has_bn", C.c_int32), ("has_res", C.c_int32), ("relu", C.c_int32), ("training", C.c_int32),
                 ("bn_groups", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float)]
 
 
@@ -55,13 +62,35 @@ SIGNATURES = {
     "medt_axial_workspace_bytes": (C.c_size_t, [C.POINTER(AxialDesc)]),
     "medt_axial_layer_fwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.c_void_p, C.c_void_p,
                                        C.POINTER(AxialSaved), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "medt_axial_layer_bwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.c_void_p, C.c_void_p,
+    "medt_axial_layer_bwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(AxialSaved), C.c_void_p, C.POINTER(AxialGrads), C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
     "medt_axial_core_stats": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved),
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_axial_core_fwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved),
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_conv_stats_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "medt_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "medt_conv_block_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BnPtrs),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_conv_block_bwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(BnPtrs), C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_up2x_relu_add_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "medt_up2x_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "medt_patch_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "medt_logo_merge_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    "medt_logo_merge_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    "medt_ce_partials": (C.c_size_t, [C.c_int, C.c_int]),
+    "medt_ce_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_void_p]),
+    "medt_ce_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_void_p]),
+    "medt_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "medt_relu_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 
@@ -77,7 +106,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.medt_abi_version() != 1:
+        if l.medt_abi_version() != 2:
             raise MedtError("libmedt_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -18,12 +18,12 @@ from . import _lib as L
 class AxialConfig:
     """Static geometry + BatchNorm buffers of one attention layer."""
     __slots__ = ("groups", "axis", "has_pos", "stride", "bn_groups", "eps", "momentum",
-                 "bn_qkv", "bn_similarity", "bn_output")
+                 "bn_qkv", "bn_similarity", "bn_output", "out_relu")
 
     def __init__(self, groups, axis, has_pos, stride, bn_qkv, bn_similarity, bn_output, bn_groups=1,
-                 eps=1e-5, momentum=0.1):
+                 eps=1e-5, momentum=0.1, out_relu=False):
         self.groups, self.axis, self.has_pos, self.stride = groups, axis, has_pos, stride
-        self.bn_groups, self.eps, self.momentum = bn_groups, eps, momentum
+        self.bn_groups, self.eps, self.momentum, self.out_relu = bn_groups, eps, momentum, out_relu
         self.bn_qkv, self.bn_similarity, self.bn_output = bn_qkv, bn_similarity, bn_output
 
 
@@ -45,7 +45,7 @@ def _bn_ptrs(bn, training: bool) -> L.BnPtrs:
 def _desc(x, cfg: AxialConfig, training: bool) -> L.AxialDesc:
     N, Cc, H, W = x.shape
     return L.AxialDesc(N, Cc, H, W, cfg.groups, cfg.axis, int(cfg.has_pos), cfg.stride, int(training),
-                       cfg.bn_groups, cfg.eps, cfg.momentum)
+                       cfg.bn_groups, cfg.eps, cfg.momentum, int(cfg.out_relu))
 
 
 def _params(cfg, w_qkv, relative, gates, training) -> L.AxialParams:
@@ -84,13 +84,14 @@ class AxialAttentionFn(torch.autograd.Function):
         L.check(lib.medt_axial_layer_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
                                          ws.data_ptr(), ws_bytes, stream), "medt_axial_layer_fwd")
         ctx.cfg, ctx.training, ctx.has_gates = cfg, training, gates is not None
-        ctx.save_for_backward(x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats)
+        ctx.save_for_backward(x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats,
+                              y if cfg.out_relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
-        x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats = ctx.saved_tensors
+        x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats, y = ctx.saved_tensors
         cfg, training = ctx.cfg, ctx.training
         dy = dy.contiguous()
         desc = _desc(x, cfg, training)
@@ -113,7 +114,7 @@ class AxialAttentionFn(torch.autograd.Function):
         ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         stream = torch.cuda.current_stream().cuda_stream
-        L.check(lib.medt_axial_layer_bwd(C.byref(desc), C.byref(params), x.data_ptr(), dy.data_ptr(), C.byref(saved),
+        L.check(lib.medt_axial_layer_bwd(C.byref(desc), C.byref(params), x.data_ptr(), L.ptr(y), dy.data_ptr(), C.byref(saved),
                                          dx.data_ptr(), C.byref(grads), ws.data_ptr(), ws_bytes, stream),
                 "medt_axial_layer_bwd")
         dw = parts[0].view_as(w_qkv)
@@ -128,13 +129,14 @@ class AxialAttentionFn(torch.autograd.Function):
 
 
 def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: Optional[torch.Tensor],
-                    gates, groups: int, width: bool, stride: int, training: bool, bn_groups: int = 1):
+                    gates, groups: int, width: bool, stride: int, training: bool, bn_groups: int = 1,
+                    out_relu: bool = False):
     """Functional entry: modules from lib.models.axialnet pass their own parameters/buffers.
 
     gates = (f_qr, f_kr, f_sve, f_sv) 0-d tensors or None (ungated: all ones).
     """
     cfg = AxialConfig(groups, 1 if width else 0, relative is not None, stride, bn_qkv, bn_similarity, bn_output,
-                      bn_groups, bn_qkv.eps, bn_qkv.momentum if bn_qkv.momentum is not None else 0.1)
+                      bn_groups, bn_qkv.eps, bn_qkv.momentum if bn_qkv.momentum is not None else 0.1, out_relu)
     g = gates if gates is not None else (None, None, None, None)
     return AxialAttentionFn.apply(x, qkv_weight, bn_qkv.weight, bn_qkv.bias, bn_similarity.weight,
                                   bn_similarity.bias, bn_output.weight, bn_output.bias, relative,

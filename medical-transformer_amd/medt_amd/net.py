@@ -1,15 +1,25 @@
 """Network-level execution for the lib.models.axialnet module surface.
 
 Walks the same dataflow as the reference's block / network forwards
-(lib/models/axialnet.py:324-344, 471-504, 620-708); the modules in
-lib/models/axialnet.py only hold parameters and delegate here.
+(lib/models/axialnet.py:324-344, 471-504, 620-708) with every op bound to
+libmedt_hip.so; the modules in lib/models/axialnet.py only hold parameters and
+delegate here.  MI355X-first differences in *schedule*, not in arithmetic:
+
+  * conv + BatchNorm + residual + ReLU run as one fused block op, bilinear-x2 + ReLU + skip as one kernel,
+    the ReLU after each block's width attention is fused into the attention's output pass;
+  * the reference's 16-iteration Python patch loop (:661-700) becomes ONE pass over a patch-major
+    (16N, C, 32, 32) stack in which every BatchNorm keeps 16 statistic groups and applies the
+    running-stat recurrence in patch order -- the same numbers, 16x fewer launches.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from ._lib import MedtError
+from . import ops
+
+PATCH = 32          # hard-coded in the reference (:664)
+GRID = 4
 
 
 def _require_device(x):
@@ -18,66 +28,71 @@ def _require_device(x):
                         "(the CPU restatement under oracle/ is test infrastructure)")
 
 
-def axial_block_forward(blk, x):
+def axial_block_forward(blk, x, bn_groups: int = 1):
     """AxialBlock{,_dynamic,_wopos}.forward (reference :282-302, :324-344, :368-391)."""
     _require_device(x)
-    out = F.relu(blk.bn1(blk.conv_down(x)))
-    out = blk.hight_block(out)
-    out = blk.width_block(out)
-    out = F.relu(out)
-    out = blk.bn2(blk.conv_up(out))
-    identity = x if blk.downsample is None else blk.downsample(x)
-    return F.relu(out + identity)
+    out = ops.conv_block(x, blk.conv_down, blk.bn1, relu=True, training=blk.bn1.training, bn_groups=bn_groups)
+    out = blk.hight_block.run(out, bn_groups, False)
+    out = blk.width_block.run(out, bn_groups, True)             # + the block's ReLU (:333)
+    if blk.downsample is not None:
+        identity = ops.conv_block(x, blk.downsample[0], blk.downsample[1], relu=False,
+                                  training=blk.downsample[1].training, bn_groups=bn_groups)
+    else:
+        identity = x
+    return ops.conv_block(out, blk.conv_up, blk.bn2, res=identity, relu=True, training=blk.bn2.training,
+                          bn_groups=bn_groups)
 
 
-def _up(x):
-    return F.interpolate(x, scale_factor=(2, 2), mode="bilinear", align_corners=False)
-
-
-def _stem(net, x, sfx=""):
-    g = lambda n: getattr(net, n + sfx)
-    x = F.relu(g("bn1")(g("conv1")(x)))
-    x = F.relu(g("bn2")(g("conv2")(x)))
-    x = F.relu(g("bn3")(g("conv3")(x)))
+def _layer(seq, x, bn_groups=1):
+    for blk in seq:
+        x = axial_block_forward(blk, x, bn_groups)
     return x
 
 
-def _unet_body(net, x, sfx=""):
+def _stem(net, x, sfx="", bn_groups=1):
     g = lambda n: getattr(net, n + sfx)
-    x1 = g("layer1")(x)
-    x2 = g("layer2")(x1)
-    x3 = g("layer3")(x2)
-    x4 = g("layer4")(x3)
-    y = F.relu(_up(g("decoder1")(x4))) + x4
-    y = F.relu(_up(g("decoder2")(y))) + x3
-    y = F.relu(_up(g("decoder3")(y))) + x2
-    y = F.relu(_up(g("decoder4")(y))) + x1
-    y = F.relu(_up(g("decoder5")(y)))
+    for i in ("1", "2", "3"):
+        bn = g("bn" + i)
+        x = ops.conv_block(x, g("conv" + i), bn, relu=True, training=bn.training, bn_groups=bn_groups)
+    return x
+
+
+def _unet_body(net, x, sfx="", bn_groups=1):
+    g = lambda n: getattr(net, n + sfx)
+    x1 = _layer(g("layer1"), x, bn_groups)
+    x2 = _layer(g("layer2"), x1, bn_groups)
+    x3 = _layer(g("layer3"), x2, bn_groups)
+    x4 = _layer(g("layer4"), x3, bn_groups)
+    y = ops.up2x_relu_add(ops.conv_block(x4, g("decoder1")), x4)
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder2")), x3)
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder3")), x2)
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder4")), x1)
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder5")), None)
     return y
 
 
 def unet_forward(net, x):
-    """ResAxialAttentionUNet._forward_impl (reference :471-504)."""
+    """ResAxialAttentionUNet._forward_impl (reference :471-504).  adjust(relu(y)) == adjust(y): y is a ReLU output."""
     _require_device(x)
-    y = _unet_body(net, _stem(net, x))
-    return net.adjust(F.relu(y))
+    y = _unet_body(net, _stem(net, x.contiguous()))
+    return ops.conv_block(y, net.adjust)
 
 
 def medt_forward(net, x):
     """medt_net._forward_impl (reference :620-708)."""
     _require_device(x)
-    xin = x
-    g = _stem(net, x)
-    x1 = net.layer1(g)
-    x2 = net.layer2(x1)
-    y = F.relu(_up(net.decoder4(x2))) + x1
-    y = F.relu(_up(net.decoder5(y)))
-    x_loc = y.clone()
-    for i in range(4):                       # hard-coded 4x4 grid of 32-px patches (:661-664, SURVEY.md Q1)
-        for j in range(4):
-            xp = xin[:, :, 32 * i:32 * i + 32, 32 * j:32 * j + 32]
-            yp = _unet_body(net, _stem(net, xp, "_p"), "_p")
-            x_loc[:, :, 32 * i:32 * i + 32, 32 * j:32 * j + 32] = yp
-    y = y + x_loc
-    y = F.relu(net.decoderf(y))
-    return net.adjust(F.relu(y))
+    xin = x.contiguous()
+    if xin.shape[2] < PATCH * GRID or xin.shape[3] < PATCH * GRID or xin.shape[2] != xin.shape[3]:
+        raise RuntimeError(f"medt_net needs square images of at least {PATCH * GRID} px (4x4 grid of 32-px patches)")
+    g = _stem(net, xin)
+    x1 = _layer(net.layer1, g)
+    x2 = _layer(net.layer2, x1)
+    y = ops.up2x_relu_add(ops.conv_block(x2, net.decoder4), x1)
+    y = ops.up2x_relu_add(ops.conv_block(y, net.decoder5), None)
+    # local branch: all 16 patches at once, patch-major on the batch dim, 16 BatchNorm groups when training
+    xp = ops.patch_gather(xin, PATCH, GRID)
+    groups = GRID * GRID if net.training else 1
+    yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
+    y = ops.logo_merge(y, yp, PATCH, GRID)
+    y = ops.conv_block(y, net.decoderf, relu=True)
+    return ops.conv_block(y, net.adjust)

@@ -1,0 +1,215 @@
+"""autograd.Functions over the C ABI for everything around the attention layers:
+convolution blocks (conv + BatchNorm + residual + ReLU), bilinear-x2 + ReLU + skip,
+the LoGo patch gather / merge and the cross-entropy loss.
+
+Reference lines: lib/models/axialnet.py:285-300, 450-454, 475-502, 623-705; metrics.py:17-20.
+PyTorch supplies device memory, the stream and the autograd graph only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .axial import _bn_ptrs, _require_device
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------- #
+# y = act( BN( conv(x) + bias ) + res )
+# --------------------------------------------------------------------------- #
+class ConvBlockCfg:
+    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups")
+
+    def __init__(self, stride, pad, bn, relu, bn_groups=1):
+        self.stride, self.pad, self.bn, self.relu, self.bn_groups = stride, pad, bn, relu, bn_groups
+
+
+def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDesc:
+    N, Cin, H, W = x.shape
+    bn = cfg.bn
+    return L.ConvDesc(N, Cin, H, W, w.shape[0], w.shape[2], cfg.stride, cfg.pad, int(has_bias), int(bn is not None),
+                      int(has_res), int(cfg.relu), int(training), cfg.bn_groups,
+                      bn.eps if bn is not None else 1e-5,
+                      (bn.momentum if bn is not None and bn.momentum is not None else 0.1))
+
+
+class ConvBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, bn_w, bn_b, res, cfg: ConvBlockCfg, training: bool):
+        _require_device(x)
+        lib = L.lib()
+        x = x.contiguous()
+        if res is not None:
+            res = res.contiguous()
+        desc = _conv_desc(x, w, cfg, bias is not None, res is not None, training)
+        K, s, p = w.shape[2], cfg.stride, cfg.pad
+        N, _, H, W = x.shape
+        Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+        y = torch.empty((N, w.shape[0], Ho, Wo), device=x.device, dtype=torch.float32)
+        has_bn = cfg.bn is not None
+        z = torch.empty_like(y) if has_bn else y
+        stats = torch.empty((max(lib.medt_conv_stats_floats(C.byref(desc)), 1),), device=x.device, dtype=torch.float32)
+        ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
+        if ws_bytes == 0:
+            raise L.MedtError("conv block: " + lib.medt_last_error().decode())
+        ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+        bnp = _bn_ptrs(cfg.bn, training) if has_bn else None
+        L.check(lib.medt_conv_block_fwd(C.byref(desc), x.data_ptr(), w.data_ptr(), L.ptr(bias),
+                                        C.byref(bnp) if has_bn else None, L.ptr(res), z.data_ptr(), y.data_ptr(),
+                                        stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "medt_conv_block_fwd")
+        ctx.cfg, ctx.training, ctx.has_bias, ctx.has_res = cfg, training, bias is not None, res is not None
+        ctx.save_for_backward(x, w, z if has_bn else None, y if (cfg.relu or has_bn) else None,
+                              stats if has_bn else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, w, z, y, stats = ctx.saved_tensors
+        cfg, training = ctx.cfg, ctx.training
+        dy = dy.contiguous()
+        desc = _conv_desc(x, w, cfg, ctx.has_bias, ctx.has_res, training)
+        has_bn = cfg.bn is not None
+        dev = x.device
+        Cout = w.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(w)
+        dbias = torch.empty((Cout,), device=dev, dtype=torch.float32) if ctx.has_bias else None
+        dbn = torch.empty((2, Cout), device=dev, dtype=torch.float32) if has_bn else None
+        dres = torch.empty_like(dy) if ctx.has_res else None
+        ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+        bnp = _bn_ptrs(cfg.bn, False) if has_bn else None
+        L.check(lib.medt_conv_block_bwd(C.byref(desc), x.data_ptr(), w.data_ptr(), C.byref(bnp) if has_bn else None,
+                                        L.ptr(z), L.ptr(y), L.ptr(stats), dy.data_ptr(), L.ptr(dx), dw.data_ptr(),
+                                        L.ptr(dbias), dbn[0].data_ptr() if has_bn else None,
+                                        dbn[1].data_ptr() if has_bn else None, L.ptr(dres), ws.data_ptr(), ws_bytes,
+                                        _stream()), "medt_conv_block_bwd")
+        return (dx, dw, dbias, dbn[0] if has_bn else None, dbn[1] if has_bn else None, dres, None, None)
+
+
+def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups=1):
+    """conv: nn.Conv2d holder, bn: nn.BatchNorm2d holder or None."""
+    cfg = ConvBlockCfg(conv.stride[0], conv.padding[0], bn, relu, bn_groups if bn is not None else 1)
+    return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
+                             bn.bias if bn is not None else None, res, cfg, training)
+
+
+# --------------------------------------------------------------------------- #
+# y = relu(bilinear_x2(x)) + skip
+# --------------------------------------------------------------------------- #
+class UpReluAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip):
+        _require_device(x)
+        lib = L.lib()
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        if skip is not None:
+            skip = skip.contiguous()
+        L.check(lib.medt_up2x_relu_add_fwd(x.data_ptr(), L.ptr(skip), y.data_ptr(), N * Cc, H, W, _stream()),
+                "medt_up2x_relu_add_fwd")
+        ctx.save_for_backward(x)
+        ctx.has_skip = skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Cc, H, W = x.shape
+        dx = torch.empty_like(x)
+        L.check(lib.medt_up2x_relu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N * Cc, H, W, _stream()),
+                "medt_up2x_relu_bwd")
+        return dx, (dy if ctx.has_skip else None)
+
+
+def up2x_relu_add(x, skip=None):
+    return UpReluAddFn.apply(x, skip)
+
+
+# --------------------------------------------------------------------------- #
+# LoGo patches
+# --------------------------------------------------------------------------- #
+def patch_gather(x, P=32, G=4):
+    """(N,C,S,S) image -> (G*G*N, C, P, P) patch-major stack.  Input images carry no gradient."""
+    _require_device(x)
+    x = x.contiguous()
+    N, Cc, S, _ = x.shape
+    xp = torch.empty((G * G * N, Cc, P, P), device=x.device, dtype=torch.float32)
+    L.check(L.lib().medt_patch_gather(x.data_ptr(), xp.data_ptr(), N, Cc, S, P, G, _stream()), "medt_patch_gather")
+    return xp
+
+
+class LogoMergeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, yp, P, G):
+        _require_device(x)
+        x, yp = x.contiguous(), yp.contiguous()
+        N, Cc, S, _ = x.shape
+        y = torch.empty_like(x)
+        L.check(L.lib().medt_logo_merge_fwd(x.data_ptr(), yp.data_ptr(), y.data_ptr(), N, Cc, S, P, G, _stream()),
+                "medt_logo_merge_fwd")
+        ctx.geom = (N, Cc, S, P, G)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, S, P, G = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        dyp = torch.empty((G * G * N, Cc, P, P), device=dy.device, dtype=torch.float32)
+        L.check(L.lib().medt_logo_merge_bwd(dy.data_ptr(), dx.data_ptr(), dyp.data_ptr(), N, Cc, S, P, G, _stream()),
+                "medt_logo_merge_bwd")
+        return dx, dyp, None, None
+
+
+def logo_merge(x, yp, P=32, G=4):
+    return LogoMergeFn.apply(x, yp, P, G)
+
+
+# --------------------------------------------------------------------------- #
+# cross entropy
+# --------------------------------------------------------------------------- #
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        _require_device(logits)
+        lib = L.lib()
+        logits, target = logits.contiguous(), target.contiguous()
+        if target.dtype != torch.int64:
+            raise L.MedtError("cross_entropy: int64 class-index targets expected")
+        N, K = logits.shape[0], logits.shape[1]
+        HW = logits[0, 0].numel()
+        partials = torch.empty((lib.medt_ce_partials(N, HW),), device=logits.device, dtype=torch.float32)
+        out = torch.empty((2,), device=logits.device, dtype=torch.float32)
+        L.check(lib.medt_ce_fwd(logits.data_ptr(), target.data_ptr(), partials.data_ptr(), out.data_ptr(), N, K, HW,
+                                ignore_index, _stream()), "medt_ce_fwd")
+        ctx.save_for_backward(logits, target, out)
+        ctx.ignore_index = ignore_index
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = L.lib()
+        logits, target, out = ctx.saved_tensors
+        N, K = logits.shape[0], logits.shape[1]
+        HW = logits[0, 0].numel()
+        dloss = dloss.contiguous().float()
+        dlogits = torch.empty_like(logits)
+        L.check(lib.medt_ce_bwd(logits.data_ptr(), target.data_ptr(), out.data_ptr(), dloss.data_ptr(),
+                                dlogits.data_ptr(), N, K, HW, ctx.ignore_index, _stream()), "medt_ce_bwd")
+        return dlogits, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    """F.cross_entropy(logits, target) with mean reduction (what LogNLLLoss.forward computes, metrics.py:17-20)."""
+    return CrossEntropyFn.apply(logits, target, ignore_index)

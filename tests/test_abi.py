@@ -39,7 +39,8 @@ def test_binding_table_matches_header(lib):
 def test_struct_layouts_match_header():
     """sizeof of the ctypes mirrors == what the C compiler lays out (checked via the documented field lists)."""
     from medt_amd import _lib
-    assert ctypes.sizeof(_lib.AxialDesc) == 12 * 4
+    assert ctypes.sizeof(_lib.AxialDesc) == 13 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
     assert ctypes.sizeof(_lib.BnPtrs) == 5 * 8
     assert ctypes.sizeof(_lib.AxialParams) == 8 + 3 * 40 + 5 * 8
     assert ctypes.sizeof(_lib.AxialSaved) == 4 * 8
@@ -48,12 +49,21 @@ def test_struct_layouts_match_header():
 
 def test_descriptor_validation_no_gpu_needed(lib):
     from medt_amd import _lib
-    d = _lib.AxialDesc(2, 16, 8, 8, 8, 0, 1, 1, 1, 1, 1e-5, 0.1)
+    d = _lib.AxialDesc(2, 16, 8, 8, 8, 0, 1, 1, 1, 1, 1e-5, 0.1, 0)
     assert lib.medt_axial_workspace_bytes(ctypes.byref(d)) > 0
     assert lib.medt_axial_stats_floats(ctypes.byref(d)) == 4 * (32 + 24 + 32)
-    bad = _lib.AxialDesc(2, 24, 8, 8, 8, 0, 1, 1, 1, 1, 1e-5, 0.1)      # group_planes = 3
+    bad = _lib.AxialDesc(2, 24, 8, 8, 8, 0, 1, 1, 1, 1, 1e-5, 0.1, 0)      # group_planes = 3
     assert lib.medt_axial_workspace_bytes(ctypes.byref(bad)) == 0
     assert b"group_planes" in lib.medt_last_error()
+
+
+def test_conv_descriptor_validation(lib):
+    from medt_amd import _lib
+    d = _lib.ConvDesc(2, 8, 16, 16, 128, 3, 1, 1, 0, 1, 0, 1, 1, 1, 1e-5, 0.1)
+    assert lib.medt_conv_workspace_bytes(ctypes.byref(d)) > 0
+    assert lib.medt_conv_stats_floats(ctypes.byref(d)) == 4 * 128
+    bad = _lib.ConvDesc(2, 8, 16, 16, 128, 5, 1, 2, 0, 1, 0, 1, 1, 1, 1e-5, 0.1)
+    assert lib.medt_conv_workspace_bytes(ctypes.byref(bad)) == 0
 
 
 def test_single_hip_runtime(lib):

@@ -1,0 +1,199 @@
+"""HIP ops around the attention layers (C ABI) vs fp64 torch on the CPU.  Tolerance 2e-4 relative
+(these are well-conditioned single ops; observed errors are ~1e-6)."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _cmp(a, b, tol=TOL, what=""):
+    err = H.rel_err(a, b)
+    assert err < tol, (what, err)
+
+
+def ref_conv_block(x, conv, bn, res, relu, training, groups):
+    """fp64 CPU reference; bn_groups realised as chunked batch_norm with sequential running-stat updates."""
+    z = F.conv2d(x, conv.weight, conv.bias, stride=conv.stride, padding=conv.padding)
+    if bn is not None:
+        outs = []
+        for zc in z.chunk(groups if training else 1, 0):
+            outs.append(F.batch_norm(zc, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps))
+            if training:
+                bn.num_batches_tracked += 1
+        z = torch.cat(outs, 0)
+    if res is not None:
+        z = z + res
+    return F.relu(z) if relu else z
+
+
+CONV_CASES = [
+    # Cin, Cout, K, stride, pad, bias, bn, res, relu, N, H, groups
+    (3, 8, 7, 2, 3, False, True, False, True, 2, 32, 1),        # stem conv1
+    (3, 64, 7, 2, 3, False, True, False, True, 4, 32, 4),       # conv1_p, grouped BN
+    (8, 128, 3, 1, 1, False, True, False, True, 2, 16, 1),      # conv2
+    (128, 8, 3, 1, 1, False, True, False, True, 2, 16, 2),      # conv3
+    (32, 16, 1, 1, 0, False, True, False, True, 2, 16, 1),      # conv_down
+    (16, 32, 1, 1, 0, False, True, True, True, 4, 8, 2),        # conv_up + identity + relu
+    (32, 64, 1, 2, 0, False, True, False, False, 2, 16, 1),     # downsample (stride 2, no relu)
+    (64, 64, 3, 2, 1, True, False, False, False, 2, 4, 1),      # decoder1 (stride 2, bias)
+    (32, 16, 3, 1, 1, True, False, False, False, 2, 16, 1),     # decoder
+    (16, 16, 3, 1, 1, True, False, False, True, 2, 16, 1),      # decoderf + relu
+    (16, 2, 1, 1, 0, True, False, False, False, 2, 16, 1),      # adjust
+    (256, 256, 3, 2, 1, True, False, False, False, 8, 2, 1),    # decoder1_p on 2x2 maps
+    (20, 24, 3, 1, 1, False, True, False, True, 3, 9, 1),       # odd sizes
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(str(int(v)) for v in c))
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_conv_block(case, training, device):
+    from medt_amd import ops
+    Cin, Cout, K, stride, pad, bias, has_bn, has_res, relu, N, S, groups = case
+    torch.manual_seed(Cin * 100 + Cout + K)
+    conv = nn.Conv2d(Cin, Cout, K, stride=stride, padding=pad, bias=bias)
+    bn = nn.BatchNorm2d(Cout) if has_bn else None
+    if bn is not None:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+            bn.running_mean.normal_(0, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(N, Cin, S, S)
+    So = (S + 2 * pad - K) // stride + 1
+    res = torch.randn(N, Cout, So, So) if has_res else None
+    dout = torch.randn(N, Cout, So, So)
+    # reference (fp64, CPU)
+    conv64 = copy.deepcopy(conv).double()
+    bn64 = copy.deepcopy(bn).double() if bn is not None else None
+    x64 = x.double().requires_grad_(True)
+    r64 = res.double().requires_grad_(True) if has_res else None
+    y64 = ref_conv_block(x64, conv64, bn64, r64, relu, training, groups)
+    (y64 * dout.double()).sum().backward()
+    # product
+    convd = copy.deepcopy(conv).to(device)
+    bnd = copy.deepcopy(bn).to(device) if bn is not None else None
+    xd = x.to(device).requires_grad_(True)
+    rd = res.to(device).requires_grad_(True) if has_res else None
+    y = ops.conv_block(xd, convd, bnd, rd, relu, training, groups if training else 1)
+    (y * dout.to(device)).sum().backward()
+    torch.cuda.synchronize()
+    _cmp(y, y64, what="y")
+    _cmp(xd.grad, x64.grad, what="dx")
+    _cmp(convd.weight.grad, conv64.weight.grad, what="dw")
+    if bias:
+        _cmp(convd.bias.grad, conv64.bias.grad, what="dbias")
+    if has_res:
+        _cmp(rd.grad, r64.grad, what="dres")
+    if bn is not None:
+        gs = max(bn64.weight.grad.abs().max().item(), bn64.bias.grad.abs().max().item())
+        assert (bnd.weight.grad.double().cpu() - bn64.weight.grad).abs().max().item() < TOL * gs
+        assert (bnd.bias.grad.double().cpu() - bn64.bias.grad).abs().max().item() < TOL * gs
+        if training:
+            _cmp(bnd.running_mean, bn64.running_mean, what="running_mean")
+            _cmp(bnd.running_var, bn64.running_var, what="running_var")
+            assert int(bnd.num_batches_tracked.item()) == int(bn64.num_batches_tracked.item())
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 1, 1), (2, 4, 2, 2), (1, 5, 7, 3), (2, 16, 16, 16), (1, 2, 64, 64)])
+@pytest.mark.parametrize("with_skip", [True, False])
+def test_up2x_relu_add(shape, with_skip, device):
+    from medt_amd import ops
+    torch.manual_seed(shape[2])
+    x = torch.randn(shape)
+    N, C, Hh, Ww = shape
+    skip = torch.randn(N, C, 2 * Hh, 2 * Ww) if with_skip else None
+    dout = torch.randn(N, C, 2 * Hh, 2 * Ww)
+    x64 = x.double().requires_grad_(True)
+    s64 = skip.double().requires_grad_(True) if with_skip else None
+    y64 = F.relu(F.interpolate(x64, scale_factor=(2, 2), mode="bilinear"))
+    if with_skip:
+        y64 = y64 + s64
+    (y64 * dout.double()).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    sd = skip.to(device).requires_grad_(True) if with_skip else None
+    y = ops.up2x_relu_add(xd, sd)
+    (y * dout.to(device)).sum().backward()
+    _cmp(y, y64, 1e-5, "y")
+    _cmp(xd.grad, x64.grad, 1e-5, "dx")
+    if with_skip:
+        _cmp(sd.grad, s64.grad, 1e-6, "dskip")
+
+
+@pytest.mark.parametrize("S", [128, 256])
+def test_patch_gather_and_merge(S, device):
+    from medt_amd import ops
+    torch.manual_seed(S)
+    N, C = 2, 5
+    img = torch.randn(N, 3, S, S)
+    xp = ops.patch_gather(img.to(device))
+    want = torch.cat([img[:, :, 32 * i:32 * i + 32, 32 * j:32 * j + 32] for i in range(4) for j in range(4)], 0)
+    assert torch.equal(xp.cpu(), want)
+    x = torch.randn(N, C, S, S)
+    yp = torch.randn(16 * N, C, 32, 32)
+    dout = torch.randn(N, C, S, S)
+    x64 = x.double().requires_grad_(True)
+    p64 = yp.double().requires_grad_(True)
+    loc = x64.clone()
+    for p in range(16):
+        i, j = divmod(p, 4)
+        loc[:, :, 32 * i:32 * i + 32, 32 * j:32 * j + 32] = p64[p * N:(p + 1) * N]
+    y64 = x64 + loc
+    (y64 * dout.double()).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    pd = yp.to(device).requires_grad_(True)
+    y = ops.logo_merge(xd, pd)
+    (y * dout.to(device)).sum().backward()
+    _cmp(y, y64, 1e-6)
+    _cmp(xd.grad, x64.grad, 1e-6)
+    _cmp(pd.grad, p64.grad, 1e-6)
+
+
+def test_cross_entropy(device):
+    import medt_amd
+    torch.manual_seed(0)
+    logits = torch.randn(3, 2, 17, 19) * 3
+    target = torch.randint(0, 2, (3, 17, 19))
+    target[0, 0, :5] = -100
+    l64 = logits.double().requires_grad_(True)
+    loss64 = F.cross_entropy(l64, target)
+    (loss64 * 1.7).backward()
+    ld = logits.to(device).requires_grad_(True)
+    loss = medt_amd.cross_entropy(ld, target.to(device))
+    (loss * 1.7).backward()
+    assert abs(loss.item() - loss64.item()) < 1e-5
+    _cmp(ld.grad, l64.grad, 1e-5)
+
+
+def test_flat_adam_matches_torch_adam(device):
+    from medt_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(7, 3), (), (5,), (2, 3, 4, 4)]
+    ps = [torch.randn(s) for s in shapes]
+    ref = [nn.Parameter(p.clone().double()) for p in ps]
+    mine = [nn.Parameter(p.clone().to(device)) for p in ps]
+    unused_ref, unused_mine = nn.Parameter(torch.ones(3).double()), nn.Parameter(torch.ones(3, device=device))
+    late_ref, late_mine = nn.Parameter(torch.tensor(0.1).double()), nn.Parameter(torch.tensor(0.1, device=device))
+    o_ref = torch.optim.Adam(ref + [unused_ref, late_ref], lr=1e-2, weight_decay=1e-2)
+    o_mine = FlatAdam(mine + [unused_mine, late_mine], lr=1e-2, weight_decay=1e-2)
+    for step in range(6):
+        o_ref.zero_grad()
+        o_mine.zero_grad()
+        for a, b in zip(ref, mine):
+            g = torch.randn(a.shape)
+            a.grad = g.double()
+            b.grad = g.to(device)
+        if step >= 3:                                   # the gates join at "epoch 10" with a fresh step counter
+            g = torch.randn(())
+            late_ref.grad = g.double()
+            late_mine.grad = g.to(device)
+        o_ref.step()
+        o_mine.step()
+    for a, b in zip(ref + [unused_ref, late_ref], mine + [unused_mine, late_mine]):
+        _cmp(b, a, 1e-5)
