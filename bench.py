@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--model", default="MedT")
     ap.add_argument("--imgsize", type=int, default=IMG)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch")
+    ap.add_argument("--eager", action="store_true", help="launch kernels from Python every step (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the attention-kernel microbenchmark (for rocprofv3)")
@@ -197,14 +198,12 @@ def main():
     g = torch.Generator().manual_seed(3000 + rank)
     x = torch.rand(args.batch, 3, args.imgsize, args.imgsize, generator=g).to(device)
     y = torch.randint(0, 2, (args.batch, args.imgsize, args.imgsize), generator=g).to(device)
+    from medt_amd.trainer import TrainStep
+    # fwd + LogNLLLoss (metrics.py:17-20) + bwd + gradient packing + fused Adam, captured into one hipGraph
+    train_step = TrainStep(model, opt, medt_amd.cross_entropy, use_graph=not args.eager)
 
     def step():
-        out = model(x)
-        loss = medt_amd.cross_entropy(out, y)            # LogNLLLoss (metrics.py:17-20)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()                                       # pack grads -> flat bucket, all-reduce (N>1), fused Adam
-        return loss
+        return train_step(x, y)
 
     log("model built; warm-up")
     for _ in range(args.warmup):
@@ -235,7 +234,7 @@ def main():
         "config": {"workload": f"{args.model} imgsize={args.imgsize} bs={args.batch}/GPU train step (fwd+CE+bwd+Adam), "
                                f"BASELINE.json configs[2]" + ("" if world == 1 else f" x{world} data-parallel, flat-bucket all-reduce"),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-        "final_loss": final_loss,
+        "final_loss": final_loss, "hip_graph": not args.eager,
     }
     if rank == 0 and world == 1:
         model.eval()

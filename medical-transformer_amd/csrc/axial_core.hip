@@ -506,6 +506,21 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_stats_kernel(
 }
 
 // bn_similarity backward finalisation: coef[grp][SC][3] = (e, u, w) with dS_x = e*dZ + u*S_x + w
+__device__ __forceinline__ void sim_coef(double a0, double sxh, double count, double mean, double rstd, double w,
+                                         int training, float* cf) {
+    const double e = w * rstd;
+    cf[0] = (float)e;
+    if (training) {
+        const double m1 = a0 / count, m2 = sxh / count;
+        const double u = -e * rstd * m2;
+        cf[1] = (float)u;
+        cf[2] = (float)(-e * m1 - u * mean);
+    } else {
+        cf[1] = 0.f;
+        cf[2] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __restrict__ partials, int tpg, int groups,
                                                               int G, int SC, double count, BnStats ss,
                                                               const float* __restrict__ weight, int training,
@@ -514,32 +529,37 @@ __global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __res
     const int ch = blockIdx.x, lane = threadIdx.x;          // ch = x*G + hg
     const int x = ch / G, hg = ch - x * G;
     double dg = 0.0, db = 0.0;
-    for (int grp = 0; grp < groups; ++grp) {
+    if (groups <= 64 && !(groups & (groups - 1))) {
+        const int slots = 64 / groups, g = lane % groups, slot = lane / groups;
         double a0 = 0.0, ax = 0.0;
-        for (int p = lane; p < tpg; p += 64) {
-            const float* q = partials + ((size_t)(grp * tpg + p) * G + hg) * 4;
+        for (int p = slot; p < tpg; p += slots) {
+            const float* q = partials + ((size_t)(g * tpg + p) * G + hg) * 4;
             a0 += (double)q[0];
             ax += (double)q[1 + x];
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); ax += __shfl_xor(ax, o, 64); }
-        const double mean = ss.mean[grp * SC + ch], rstd = ss.rstd[grp * SC + ch];
-        const double sxh = rstd * (ax - mean * a0);          // sum dZ * xhat
-        dg += sxh;
-        db += a0;
-        if (lane == 0) {
-            const double e = (double)weight[ch] * rstd;
-            float* cf = coef + ((size_t)grp * SC + ch) * 3;
-            cf[0] = (float)e;
-            if (training) {
-                const double m1 = a0 / count, m2 = sxh / count;
-                const double u = -e * rstd * m2;
-                cf[1] = (float)u;
-                cf[2] = (float)(-e * m1 - u * mean);
-            } else {
-                cf[1] = 0.f;
-                cf[2] = 0.f;
+        for (int o = groups; o < 64; o <<= 1) { a0 += __shfl_xor(a0, o, 64); ax += __shfl_xor(ax, o, 64); }
+        const int gi = lane < groups ? lane : 0;
+        const double mean = ss.mean[gi * SC + ch], rstd = ss.rstd[gi * SC + ch];
+        const double sxh = rstd * (ax - mean * a0);          // sum dZ * xhat of this lane's group
+        if (lane < groups) sim_coef(a0, sxh, count, mean, rstd, weight[ch], training, coef + ((size_t)lane * SC + ch) * 3);
+        dg = lane < groups ? sxh : 0.0;
+        db = lane < groups ? a0 : 0.0;
+        for (int o = 32; o > 0; o >>= 1) { dg += __shfl_xor(dg, o, 64); db += __shfl_xor(db, o, 64); }
+    } else {
+        for (int grp = 0; grp < groups; ++grp) {
+            double a0 = 0.0, ax = 0.0;
+            for (int p = lane; p < tpg; p += 64) {
+                const float* q = partials + ((size_t)(grp * tpg + p) * G + hg) * 4;
+                a0 += (double)q[0];
+                ax += (double)q[1 + x];
             }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); ax += __shfl_xor(ax, o, 64); }
+            const double mean = ss.mean[grp * SC + ch], rstd = ss.rstd[grp * SC + ch];
+            const double sxh = rstd * (ax - mean * a0);
+            dg += sxh;
+            db += a0;
+            if (lane == 0) sim_coef(a0, sxh, count, mean, rstd, weight[ch], training, coef + ((size_t)grp * SC + ch) * 3);
         }
     }
     if (lane == 0) {

@@ -12,17 +12,24 @@ namespace medt {
 
 // --------------------------------------------------------------------------- //
 // forward:  y[n,o,ho,wo] = bias[o] + sum_{c,kh,kw} w[o,c,kh,kw] * x[n,c,ho*s-p+kh,wo*s-p+kw]
-// optional per-channel [sum, sum^2] partials laid out [n][ptile][Cout][2] (BatchNorm statistics)
+// Lanes run over the flattened (image, output pixel) index *within one BatchNorm group*, so 2x2 / 4x4 maps
+// of the deep LoGo layers still fill the wave.  Optional per-channel [sum, sum^2] partials are laid out
+// [group][part][Cout][2] with part = 256-position chunk inside the group (BatchNorm statistics).
 // --------------------------------------------------------------------------- //
 template <int K, int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu) {
+    float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
+    int npg) {
     constexpr int KK = K * K;
     __shared__ float red[MEDT_WAVES * OT * 2];
-    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, o0 = blockIdx.z * OT;
-    const bool ok = p < Ho * Wo;
-    const int ho = ok ? p / Wo : 0, wo = ok ? p - ho * Wo : 0;
+    const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
+    const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * OT;
+    const int q = part * MEDT_THREADS + threadIdx.x;
+    const bool ok = q < per_group;
+    const int ni = ok ? q / HoWo : 0, p = ok ? q - ni * HoWo : 0;
+    const int n = grp * npg + ni;
+    const int ho = p / Wo, wo = p - ho * Wo;
     const int h0 = ho * stride - pad, w0 = wo * stride - pad;
     float acc[OT];
 #pragma unroll
@@ -45,9 +52,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
         }
     }
     if (ok) {
-        float* yp = y + ((size_t)n * Cout + o0) * Ho * Wo + p;
+        float* yp = y + ((size_t)n * Cout + o0) * HoWo + p;
 #pragma unroll
-        for (int o = 0; o < OT; ++o) yp[(size_t)o * Ho * Wo] = relu ? fmaxf(acc[o], 0.f) : acc[o];
+        for (int o = 0; o < OT; ++o) yp[(size_t)o * HoWo] = relu ? fmaxf(acc[o], 0.f) : acc[o];
     }
     if (partials) {
         float v[2 * OT];
@@ -57,37 +64,41 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
             v[2 * o] = a;
             v[2 * o + 1] = a * a;
         }
-        block_sum<2 * OT>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * Cout + o0) * 2);
+        block_sum<2 * OT>(v, red, partials + ((size_t)blockIdx.x * Cout + o0) * 2);
     }
 }
 
+int conv2d_parts_per_group(int N, int groups, int HoWo) { return cdiv((N / groups) * HoWo, MEDT_THREADS); }
+
 template <int K>
 static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin,
-                        int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, hipStream_t s) {
-    const int pt = cdiv(Ho * Wo, MEDT_THREADS);
+                        int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, int groups,
+                        hipStream_t s) {
+    const int npg = N / groups;
+    const unsigned gx = (unsigned)(groups * conv2d_parts_per_group(N, groups, Ho * Wo));
     constexpr int OTmax = K == 7 ? 8 : 16;
     if (Cout % OTmax == 0)
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, OTmax>), dim3(pt, N, Cout / OTmax), dim3(MEDT_THREADS), 0, s, x, w, bias,
-                           y, partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, OTmax>), dim3(gx, Cout / OTmax), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
+                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
     else if (Cout % 8 == 0)
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 8>), dim3(pt, N, Cout / 8), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
-                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 8>), dim3(gx, Cout / 8), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
+                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
     else if (Cout % 2 == 0)
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 2>), dim3(pt, N, Cout / 2), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
-                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 2>), dim3(gx, Cout / 2), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
+                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
     else
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 1>), dim3(pt, N, Cout), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
-                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu);
+        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 1>), dim3(gx, Cout), dim3(MEDT_THREADS), 0, s, x, w, bias, y, partials,
+                           Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
     return launch_status("conv2d_fwd");
 }
 
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
-               int W, int Cout, int K, int stride, int pad, int relu, hipStream_t s) {
+               int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     switch (K) {
-        case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, s);
-        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, s);
-        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, s);
+        case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
+        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
+        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
     }
     set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K);
     return MEDT_EUNSUPPORTED;
@@ -95,16 +106,19 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
 
 // --------------------------------------------------------------------------- //
 // backward-data:  dx[n,c,h,w] = sum_{o,kh,kw} w[o,c,kh,kw] * dy[n,o,(h+p-kh)/s,(w+p-kw)/s]
+// lanes over the flattened (image, input pixel) index
 // --------------------------------------------------------------------------- //
 template <int K, int CT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
-    const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin, int H, int W, int Cout,
-    int Ho, int Wo, int stride, int pad) {
+    const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int H, int W,
+    int Cout, int Ho, int Wo, int stride, int pad) {
     constexpr int KK = K * K;
-    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c0 = blockIdx.z * CT;
-    const bool ok = p < H * W;
-    const int h = ok ? p / W : 0, ww = ok ? p - h * W : 0;
-    // per-tap source coordinates are channel-independent: precompute offsets (-1 = no contribution)
+    const int HW = H * W;
+    const long q = (long)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    const int c0 = blockIdx.y * CT;
+    const bool ok = q < (long)N * HW;
+    const int n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
+    const int h = p / W, ww = p - h * W;
     int off[KK];
 #pragma unroll
     for (int kh = 0; kh < K; ++kh)
@@ -134,25 +148,25 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
         }
     }
     if (ok) {
-        float* dp = dx + ((size_t)n * Cin + c0) * H * W + p;
+        float* dp = dx + ((size_t)n * Cin + c0) * HW + p;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) dp[(size_t)c * H * W] = acc[c];
+        for (int c = 0; c < CT; ++c) dp[(size_t)c * HW] = acc[c];
     }
 }
 
 template <int K>
 static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int Ho,
                              int Wo, int stride, int pad, hipStream_t s) {
-    const int pt = cdiv(H * W, MEDT_THREADS);
+    const unsigned gx = (unsigned)(((long)N * H * W + MEDT_THREADS - 1) / MEDT_THREADS);
     constexpr int CTmax = K == 7 ? 4 : 16;
     if (Cin % CTmax == 0)
-        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CTmax>), dim3(pt, N, Cin / CTmax), dim3(MEDT_THREADS), 0, s, dy, w,
-                           dx, Cin, H, W, Cout, Ho, Wo, stride, pad);
+        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CTmax>), dim3(gx, Cin / CTmax), dim3(MEDT_THREADS), 0, s, dy, w, dx,
+                           N, Cin, H, W, Cout, Ho, Wo, stride, pad);
     else if (Cin % 8 == 0 && K != 7)
-        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 8>), dim3(pt, N, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, w, dx, Cin,
+        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 8>), dim3(gx, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin,
                            H, W, Cout, Ho, Wo, stride, pad);
     else
-        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 1>), dim3(pt, N, Cin), dim3(MEDT_THREADS), 0, s, dy, w, dx, Cin, H,
+        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 1>), dim3(gx, Cin), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin, H,
                            W, Cout, Ho, Wo, stride, pad);
     return launch_status("conv2d_bwd_data");
 }
@@ -174,7 +188,7 @@ int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, 
 // One workgroup = one tap (kh,kw) x one 64(o) x 64(c) tile x one chunk of output pixels;
 // 64-pixel LDS steps, 4x4 register tile per lane; chunk partials reduced by reduce_rows.
 // --------------------------------------------------------------------------- //
-#define CW_PIX_PER_SPLIT 1024
+#define CW_PIX_PER_SPLIT 256
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_weight_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H,
     int W, int Cout, int Ho, int Wo, int K, int stride, int pad) {

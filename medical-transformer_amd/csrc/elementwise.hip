@@ -11,15 +11,16 @@ namespace medt {
 
 static inline unsigned grid1d(size_t total) { return (unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS); }
 
-// y = [relu]( z*scale[g,c] + shift[g,c] [+ res] )         grid (ptiles, N, C)
+// y = [relu]( z*scale[g,c] + shift[g,c] [+ res] )         one lane per element of (N,C,HW)
 __global__ __launch_bounds__(MEDT_THREADS) void bn_apply_act_kernel(const float* __restrict__ z, BnStats st,
                                                                     const float* __restrict__ res,
                                                                     float* __restrict__ y, int C, int HW, int npg,
-                                                                    int relu) {
-    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c = blockIdx.z;
-    if (p >= HW) return;
+                                                                    int relu, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const size_t nc = idx / HW;
+    const int c = (int)(nc % C), n = (int)(nc / C);
     const int gc = (n / npg) * C + c;
-    const size_t idx = ((size_t)n * C + c) * HW + p;
     float v = fmaf(z[idx], st.scale[gc], st.shift[gc]);
     if (res) v += res[idx];
     if (relu) v = fmaxf(v, 0.f);
@@ -28,12 +29,14 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_apply_act_kernel(const float*
 
 int bn_apply_act(const float* z, BnStats st, const float* res, float* y, int N, int C, int HW, int groups, int relu,
                  hipStream_t s) {
-    hipLaunchKernelGGL(bn_apply_act_kernel, dim3(cdiv(HW, MEDT_THREADS), N, C), dim3(MEDT_THREADS), 0, s, z, st, res, y,
-                       C, HW, N / groups, relu);
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(bn_apply_act_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, z, st, res, y, C, HW,
+                       N / groups, relu, total);
     return launch_status("bn_apply_act");
 }
 
-// g = dy * (y > 0 if relu) ; partials[n][ptile][C][2] = [sum g, sum g*zhat]       grid (ptiles, N, C)
+// g = dy * (y > 0 if relu) ; partials[group][part][C][2] = [sum g, sum g*zhat]     grid (groups*ppg, C),
+// lanes over the flattened (image, pixel) positions of one group and one channel
 __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_stats_kernel(const float* __restrict__ dy,
                                                                         const float* __restrict__ y,
                                                                         const float* __restrict__ z, BnStats st,
@@ -41,24 +44,28 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_stats_kernel(const fl
                                                                         float* __restrict__ partials, int C, int HW,
                                                                         int npg, int relu) {
     __shared__ float red[MEDT_WAVES * 2];
-    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c = blockIdx.z;
+    const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
+    const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, c = blockIdx.y;
+    const int q = part * MEDT_THREADS + threadIdx.x;
     float v[2] = {0.f, 0.f};
-    if (p < HW) {
-        const int gc = (n / npg) * C + c;
-        const size_t idx = ((size_t)n * C + c) * HW + p;
+    if (q < per_group) {
+        const int ni = q / HW, p = q - ni * HW;
+        const int gc = grp * C + c;
+        const size_t idx = ((size_t)(grp * npg + ni) * C + c) * HW + p;
         float d = dy[idx];
         if (relu && !(y[idx] > 0.f)) d = 0.f;
         if (g) g[idx] = d;
         v[0] = d;
         v[1] = d * ((z[idx] - st.mean[gc]) * st.rstd[gc]);
     }
-    block_sum<2>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * C + c) * 2);
+    block_sum<2>(v, red, partials + ((size_t)blockIdx.x * C + c) * 2);
 }
 
 int bn_act_bwd_stats(const float* dy, const float* y, const float* z, BnStats st, float* g, float* partials, int N, int C,
                      int HW, int groups, int relu, hipStream_t s) {
-    hipLaunchKernelGGL(bn_act_bwd_stats_kernel, dim3(cdiv(HW, MEDT_THREADS), N, C), dim3(MEDT_THREADS), 0, s, dy, y, z,
-                       st, g, partials, C, HW, N / groups, relu);
+    const int ppg = cdiv((N / groups) * HW, MEDT_THREADS);
+    hipLaunchKernelGGL(bn_act_bwd_stats_kernel, dim3(groups * ppg, C), dim3(MEDT_THREADS), 0, s, dy, y, z, st, g,
+                       partials, C, HW, N / groups, relu);
     return launch_status("bn_act_bwd_stats");
 }
 
@@ -66,18 +73,21 @@ int bn_act_bwd_stats(const float* dy, const float* y, const float* z, BnStats st
 __global__ __launch_bounds__(MEDT_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ g,
                                                                     const float* __restrict__ z,
                                                                     const float* __restrict__ coef,
-                                                                    float* __restrict__ dz, int C, int HW, int npg) {
-    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, c = blockIdx.z;
-    if (p >= HW) return;
+                                                                    float* __restrict__ dz, int C, int HW, int npg,
+                                                                    size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const size_t nc = idx / HW;
+    const int c = (int)(nc % C), n = (int)(nc / C);
     const float* cf = coef + ((size_t)(n / npg) * C + c) * 3;
-    const size_t idx = ((size_t)n * C + c) * HW + p;
     dz[idx] = fmaf(cf[0], g[idx], fmaf(cf[1], z[idx], cf[2]));
 }
 
 int bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, int N, int C, int HW, int groups,
                  hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(HW, MEDT_THREADS), N, C), dim3(MEDT_THREADS), 0, s, g, z, coef, dz,
-                       C, HW, N / groups);
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, g, z, coef, dz, C, HW,
+                       N / groups, total);
     return launch_status("bn_bwd_apply");
 }
 

@@ -37,8 +37,7 @@ struct LayerStats {
 struct FwdWs {
     float *part_qkv, *part_sim, *part_out;
     FwdWs(Carver& c, const AxialGeom& g) {
-        const int pt = conv1x1_ptiles(g.HW);
-        part_qkv = c.take<float>((size_t)g.N * pt * 2 * g.C * 2);
+        part_qkv = c.take<float>((size_t)g.groups * conv2d_parts_per_group(g.N, g.groups, g.HW) * 2 * g.C * 2);
         part_sim = c.take<float>((size_t)g.groups * g.tpg * g.SC * 2);
         part_out = c.take<float>((size_t)g.groups * g.tpg * g.OC * 2);
     }
@@ -49,9 +48,9 @@ struct BwdWs {
         *dy_masked;
     size_t nblocks;
     BwdWs(Carver& c, const AxialGeom& g, int stride, int out_relu) {
-        const int pt = conv1x1_ptiles(g.HW), TL = 2 * g.L - 1;
+        const int ppg = conv2d_parts_per_group(g.N, g.groups, g.HW), TL = 2 * g.L - 1;
         nblocks = (size_t)g.groups * g.tpg * g.G;
-        part_ob = c.take<float>((size_t)g.N * pt * g.OC * 2);
+        part_ob = c.take<float>((size_t)g.groups * ppg * g.OC * 2);
         coef_out = c.take<float>((size_t)g.groups * g.OC * 3);
         part_sb = c.take<float>((size_t)g.groups * g.tpg * g.G * 4);
         coef_sim = c.take<float>((size_t)g.groups * g.SC * 3);
@@ -143,10 +142,11 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
-    const int tr = d->training ? 1 : 0, pt = conv1x1_ptiles(g.HW);
+    const int tr = d->training ? 1 : 0, ppg = conv2d_parts_per_group(g.N, g.groups, g.HW);
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
-    if ((rc = conv1x1_fwd(x, p->w_qkv, sv->qkv_raw, tr ? w.part_qkv : nullptr, g.N, g.C, 2 * g.C, g.HW, s))) return rc;
-    if ((rc = bn_finalize(w.part_qkv, g.npg * pt, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
+    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, sv->qkv_raw, tr ? w.part_qkv : nullptr, g.N, g.C, g.H, g.W, 2 * g.C, 1, 1, 0,
+                         0, g.groups, s))) return rc;
+    if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
                           st.qkv, s))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
     if (tr && (rc = axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.part_sim, s))) return rc;
@@ -179,14 +179,14 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
-    const int tr = d->training ? 1 : 0, pt = conv1x1_ptiles(g.HW), TL = 2 * g.L - 1;
+    const int tr = d->training ? 1 : 0, ppg = conv2d_parts_per_group(g.N, g.groups, g.HW), TL = 2 * g.L - 1;
     if (d->out_relu) {               // fused ReLU after the layer: mask the incoming gradient by the output sign
         if ((rc = relu_mask(dy, y, w.dy_masked, (size_t)g.N * g.C * (g.H / d->stride) * (g.W / d->stride), s))) return rc;
         dy = w.dy_masked;
     }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
     if ((rc = axial_out_bwd_stats(*d, sv->stacked, dy, st.out, w.part_ob, s))) return rc;
-    if ((rc = bn_bwd_finalize(w.part_ob, g.npg * pt, g.groups, g.OC, g.row_count, 1.f / (float)(d->stride * d->stride),
+    if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, 1.f / (float)(d->stride * d->stride),
                               st.out, p->bn_output.weight, tr, w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s)))
         return rc;
     // bn_similarity backward statistics (pass A), coefficients
@@ -219,7 +219,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
 }  // extern "C"  (helpers below are C++)
 
 namespace medt {
-struct ConvGeom { int Ho, Wo, HoWo, pt, splits; size_t out_elems; };
+struct ConvGeom { int Ho, Wo, HoWo, ppg, splits; size_t out_elems; };
 static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->stride < 1 || d->pad < 0) {
         set_error("conv: bad descriptor"); return MEDT_EINVAL;
@@ -232,7 +232,7 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     g->Wo = (d->W + 2 * d->pad - d->K) / d->stride + 1;
     if (g->Ho <= 0 || g->Wo <= 0) { set_error("conv: empty output"); return MEDT_EINVAL; }
     g->HoWo = g->Ho * g->Wo;
-    g->pt = cdiv(g->HoWo, MEDT_THREADS);
+    g->ppg = conv2d_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo);
     g->splits = conv2d_bwd_weight_splits(d->N, g->Ho, g->Wo);
     g->out_elems = (size_t)d->N * d->Cout * g->HoWo;
     return MEDT_OK;
@@ -240,7 +240,7 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
 struct ConvWs {
     float *partials, *coef, *gbuf, *dz, *dw_scratch;
     ConvWs(Carver& c, const medt_conv_desc* d, const ConvGeom& g) {
-        partials = c.take<float>(d->has_bn ? (size_t)d->N * g.pt * d->Cout * 2 : 0);
+        partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * g.ppg * d->Cout * 2 : 0);
         coef = c.take<float>(d->has_bn ? (size_t)d->bn_groups * d->Cout * 3 : 0);
         gbuf = c.take<float>(g.out_elems);
         dz = c.take<float>(d->has_bn ? g.out_elems : 0);
@@ -275,7 +275,7 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
     hipStream_t s = (hipStream_t)stream;
     if (!d->has_bn)
         return conv2d_fwd(x, w, d->has_bias ? bias : nullptr, y, nullptr, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
-                          d->stride, d->pad, d->relu, s);
+                          d->stride, d->pad, d->relu, 1, s);
     Carver c(ws, ws_bytes);
     ConvWs cw(c, d, g);
     if (!ws || !c.ok()) { set_error("conv workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
@@ -283,8 +283,8 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
     if (!tr && (!bn->running_mean || !bn->running_var)) { set_error("conv fwd: eval mode needs running statistics"); return MEDT_EINVAL; }
     BnStats st(stats, d->bn_groups * d->Cout);
     if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
-                         d->pad, 0, s))) return rc;
-    if ((rc = bn_finalize(cw.partials, (d->N / d->bn_groups) * g.pt, d->bn_groups, d->Cout,
+                         d->pad, 0, d->bn_groups, s))) return rc;
+    if ((rc = bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout,
                           (double)(d->N / d->bn_groups) * g.HoWo, *bn, d->momentum, d->eps, tr, st, s))) return rc;
     return bn_apply_act(z, st, d->has_res ? res : nullptr, y, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s);
 }
@@ -306,7 +306,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
         float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
         if ((rc = bn_act_bwd_stats(dy, y, z, st, gb, cw.partials, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s))) return rc;
-        if ((rc = bn_bwd_finalize(cw.partials, (d->N / d->bn_groups) * g.pt, d->bn_groups, d->Cout,
+        if ((rc = bn_bwd_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout,
                                   (double)(d->N / d->bn_groups) * g.HoWo, 1.f, st, bn->weight, d->training ? 1 : 0, cw.coef,
                                   dbn_weight, dbn_bias, s))) return rc;
         if ((rc = bn_bwd_apply(gb, z, cw.coef, cw.dz, d->N, d->Cout, g.HoWo, d->bn_groups, s))) return rc;

@@ -39,8 +39,10 @@ int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const fl
 int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
 
 // ---- conv.hip ------------------------------------------------------------------
+// partials (optional): [group][part][Cout][2], part = 256-position chunk of the group's npg*Ho*Wo positions
+int conv2d_parts_per_group(int N, int groups, int HoWo);
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
-               int W, int Cout, int K, int stride, int pad, int relu, hipStream_t s);
+               int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int K,
                     int stride, int pad, hipStream_t s);
 int conv2d_bwd_weight_splits(int N, int Ho, int Wo);

@@ -69,12 +69,12 @@ int conv1x1_fwd(const float* x, const float* w, float* y, float* partials, int N
 template <int CT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
-    const float* __restrict__ w, float* __restrict__ dx, int Cin, int Cout, int HW, int npg) {
-    const int  p  = blockIdx.x * MEDT_THREADS + threadIdx.x;
-    const int  n  = blockIdx.y;
-    const int  c0 = blockIdx.z * CT;
-    const bool ok = p < HW;
-    const size_t base = (size_t)n * Cout * HW + (ok ? p : 0);
+    const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int Cout, int HW, int npg) {
+    const long q = (long)blockIdx.x * MEDT_THREADS + threadIdx.x;     // flattened (image, pixel)
+    const int  c0 = blockIdx.y * CT;
+    const bool ok = q < (long)N * HW;
+    const int  n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
+    const size_t base = (size_t)n * Cout * HW + p;
     const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
     float acc[CT];
 #pragma unroll
@@ -97,15 +97,16 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_kernel(
 
 int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const float* w, float* dx, int N, int Cin,
                      int Cout, int HW, int groups, hipStream_t s) {
-    const int pt = conv1x1_ptiles(HW), npg = N / groups;
+    const int npg = N / groups;
+    const unsigned gx = (unsigned)(((long)N * HW + MEDT_THREADS - 1) / MEDT_THREADS);
     if (Cin % 16 == 0)
-        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<16>, dim3(pt, N, Cin / 16), dim3(MEDT_THREADS), 0, s, dy, raw, coef,
-                           w, dx, Cin, Cout, HW, npg);
+        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<16>, dim3(gx, Cin / 16), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w,
+                           dx, N, Cin, Cout, HW, npg);
     else if (Cin % 8 == 0)
-        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<8>, dim3(pt, N, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w,
-                           dx, Cin, Cout, HW, npg);
+        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<8>, dim3(gx, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx,
+                           N, Cin, Cout, HW, npg);
     else
-        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<1>, dim3(pt, N, Cin), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx,
+        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<1>, dim3(gx, Cin), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx, N,
                            Cin, Cout, HW, npg);
     return launch_status("conv1x1_bwd_data");
 }
@@ -114,7 +115,7 @@ int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const
 // 1x1 convolution backward-weight:  dw[o,c] = sum_{n,p} val[n,o,p] * x[n,c,p]
 // 32x32 output tile per workgroup, split over pixel chunks, 64-pixel LDS steps.
 // --------------------------------------------------------------------------- //
-#define BW_PIX_PER_SPLIT 4096
+#define BW_PIX_PER_SPLIT 256
 __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_weight_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int Cout, int HW, int npg) {
@@ -210,6 +211,28 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Per-group sums of NV interleaved partial values.  With `groups` a power of two <= 64 the 64 lanes split into
+// groups x (64/groups) slots, every lane streams its slot's parts and a butterfly over the slot bits leaves the
+// group total in every lane of that group (lane % groups == g) -- no serial dependent loads over the groups.
+template <int NV>
+__device__ __forceinline__ bool group_sums(const float* __restrict__ partials, int ppg, int groups, int CH, int ch,
+                                           int stride, const int (&which)[NV], double (&out)[NV]) {
+    const int lane = threadIdx.x;
+    if (groups > 64 || (groups & (groups - 1))) return false;
+    const int slots = 64 / groups, g = lane % groups, slot = lane / groups;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[k] = 0.0;
+    for (int p = slot; p < ppg; p += slots) {
+        const float* q = partials + ((size_t)(g * ppg + p) * CH + ch) * stride;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[k] += (double)q[which[k]];
+    }
+    for (int o = groups; o < 64; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[k] += __shfl_xor(out[k], o, 64);
+    return true;
+}
+
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partials, int ppg, int groups, int CH,
                                                          double count, const float* __restrict__ weight,
                                                          const float* __restrict__ bias, float* running_mean,
@@ -229,27 +252,47 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
         return;
     }
     double rm = running_mean ? (double)running_mean[ch] : 0.0, rv = running_var ? (double)running_var[ch] : 0.0;
-    for (int grp = 0; grp < groups; ++grp) {
-        double s = 0.0, ss = 0.0;
-        for (int p = lane; p < ppg; p += 64) {
-            const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
-            s += (double)q[0];
-            ss += (double)q[1];
-        }
-        s = wave_sum_d(s);
-        ss = wave_sum_d(ss);
-        const double mean = s / count;
-        double var = ss / count - mean * mean;
+    double sums[2];
+    const int which[2] = {0, 1};
+    if (group_sums<2>(partials, ppg, groups, CH, ch, 2, which, sums)) {
+        const double mean = sums[0] / count;
+        double var = sums[1] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
-        if (lane == 0) {
-            out.mean[grp * CH + ch]  = (float)mean;
-            out.rstd[grp * CH + ch]  = (float)rstd;
-            out.scale[grp * CH + ch] = (float)(g * rstd);
-            out.shift[grp * CH + ch] = (float)(b - mean * g * rstd);
+        if (lane < groups) {
+            out.mean[lane * CH + ch]  = (float)mean;
+            out.rstd[lane * CH + ch]  = (float)rstd;
+            out.scale[lane * CH + ch] = (float)(g * rstd);
+            out.shift[lane * CH + ch] = (float)(b - mean * g * rstd);
         }
-        rm = (1.0 - momentum) * rm + momentum * mean;
-        rv = (1.0 - momentum) * rv + momentum * var * (count / (count - 1.0));
+        for (int grp = 0; grp < groups; ++grp) {            // running-stat recurrence in group (= patch) order
+            const double m = __shfl(mean, grp, 64), v = __shfl(var, grp, 64);
+            rm = (1.0 - momentum) * rm + momentum * m;
+            rv = (1.0 - momentum) * rv + momentum * v * (count / (count - 1.0));
+        }
+    } else {
+        for (int grp = 0; grp < groups; ++grp) {
+            double s = 0.0, ss = 0.0;
+            for (int p = lane; p < ppg; p += 64) {
+                const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
+                s += (double)q[0];
+                ss += (double)q[1];
+            }
+            s = wave_sum_d(s);
+            ss = wave_sum_d(ss);
+            const double mean = s / count;
+            double var = ss / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            if (lane == 0) {
+                out.mean[grp * CH + ch]  = (float)mean;
+                out.rstd[grp * CH + ch]  = (float)rstd;
+                out.scale[grp * CH + ch] = (float)(g * rstd);
+                out.shift[grp * CH + ch] = (float)(b - mean * g * rstd);
+            }
+            rm = (1.0 - momentum) * rm + momentum * mean;
+            rv = (1.0 - momentum) * rv + momentum * var * (count / (count - 1.0));
+        }
     }
     if (lane == 0) {
         if (running_mean) running_mean[ch] = (float)rm;
@@ -267,6 +310,20 @@ int bn_finalize(const float* partials, int ppg, int groups, int CH, double count
 
 // Backward finalisation:  dx = A*(d - m1 - xhat*m2), xhat = (x-mean)*rstd, A = weight*rstd
 //   => dx = c0*d_raw + c1*x + c2 with d = dscale*d_raw.
+__device__ __forceinline__ void bn_bwd_coef(double s1, double s2, double count, float dscale, double mean, double rstd,
+                                            double w, int training, float* cf) {
+    const double A = w * rstd;
+    cf[0] = (float)(A * dscale);
+    if (training) {
+        const double m1 = s1 / count, m2 = s2 / count;
+        cf[1] = (float)(-A * rstd * m2);
+        cf[2] = (float)(A * (rstd * mean * m2 - m1));
+    } else {
+        cf[1] = 0.f;
+        cf[2] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int ppg, int groups,
                                                              int CH, double count, float dscale, BnStats st,
                                                              const float* __restrict__ weight, int training,
@@ -274,31 +331,34 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
                                                              float* __restrict__ dbias) {
     const int ch = blockIdx.x, lane = threadIdx.x;
     double dg = 0.0, db = 0.0;
-    for (int grp = 0; grp < groups; ++grp) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int p = lane; p < ppg; p += 64) {
-            const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
-            s1 += (double)q[0];
-            s2 += (double)q[1];
+    double sums[2];
+    const int which[2] = {0, 1};
+    if (group_sums<2>(partials, ppg, groups, CH, ch, 2, which, sums)) {
+        const double s1 = sums[0] * dscale, s2 = sums[1] * dscale;
+        if (lane < groups)
+            bn_bwd_coef(s1, s2, count, dscale, st.mean[lane * CH + ch], st.rstd[lane * CH + ch], weight[ch], training,
+                        coef + ((size_t)lane * CH + ch) * 3);
+        dg = s2;
+        db = s1;
+        for (int o = groups >> 1; o > 0; o >>= 1) {          // sum over the groups (lanes 0..groups-1 differ)
+            dg += __shfl_xor(dg, o, 64);
+            db += __shfl_xor(db, o, 64);
         }
-        s1 = wave_sum_d(s1) * dscale;
-        s2 = wave_sum_d(s2) * dscale;
-        dg += s2;
-        db += s1;
-        if (lane == 0) {
-            const double mean = st.mean[grp * CH + ch], rstd = st.rstd[grp * CH + ch];
-            const double A = (double)weight[ch] * rstd;
-            float* cf = coef + ((size_t)grp * CH + ch) * 3;
-            if (training) {
-                const double m1 = s1 / count, m2 = s2 / count;
-                cf[0] = (float)(A * dscale);
-                cf[1] = (float)(-A * rstd * m2);
-                cf[2] = (float)(A * (rstd * mean * m2 - m1));
-            } else {
-                cf[0] = (float)(A * dscale);
-                cf[1] = 0.f;
-                cf[2] = 0.f;
+    } else {
+        for (int grp = 0; grp < groups; ++grp) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int p = lane; p < ppg; p += 64) {
+                const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
+                s1 += (double)q[0];
+                s2 += (double)q[1];
             }
+            s1 = wave_sum_d(s1) * dscale;
+            s2 = wave_sum_d(s2) * dscale;
+            dg += s2;
+            db += s1;
+            if (lane == 0)
+                bn_bwd_coef(s1, s2, count, dscale, st.mean[grp * CH + ch], st.rstd[grp * CH + ch], weight[ch], training,
+                            coef + ((size_t)grp * CH + ch) * 3);
         }
     }
     if (lane == 0) {
@@ -353,17 +413,21 @@ int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, fl
     return launch_status("axial_out_fwd");
 }
 
-// partials[n][ptile][OC][2] = [sum dstk, sum dstk*xhat], dstk = dy at the pooled position (x 1/s^2 later)
+// partials[group][part][OC][2] = [sum dstk, sum dstk*xhat], dstk = dy at the pooled position (x 1/s^2 later);
+// lanes over the flattened (image, pixel) positions of one group and one stacked channel
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const float* __restrict__ stk,
                                                                            const float* __restrict__ dy, BnStats st,
                                                                            float* __restrict__ partials, int C, int H,
                                                                            int W, int OC, int stride, int npg) {
     __shared__ float red[MEDT_WAVES * 2];
-    const int p = blockIdx.x * MEDT_THREADS + threadIdx.x, n = blockIdx.y, ch = blockIdx.z;
     const int HW = H * W, Ho = H / stride, Wo = W / stride;
-    const int c = ch / (OC / C), grp = n / npg;
+    const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
+    const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, ch = blockIdx.y;
+    const int q = part * MEDT_THREADS + threadIdx.x;
+    const int c = ch / (OC / C);
     float v[2] = {0.f, 0.f};
-    if (p < HW) {
+    if (q < per_group) {
+        const int ni = q / HW, p = q - ni * HW, n = grp * npg + ni;
         const int h = p / W, w = p - h * W;
         const int ho = h / stride, wo = w / stride;
         if (ho < Ho && wo < Wo) {
@@ -373,14 +437,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
             v[1] = d * xh;
         }
     }
-    block_sum<2>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * OC + ch) * 2);
+    block_sum<2>(v, red, partials + ((size_t)blockIdx.x * OC + ch) * 2);
 }
 
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, float* partials,
                         hipStream_t s) {
     const int OC = d.has_pos ? 2 * d.C : d.C;
-    hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(conv1x1_ptiles(d.H * d.W), d.N, OC), dim3(MEDT_THREADS), 0, s,
-                       stacked, dy, st, partials, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups);
+    const int npg = d.N / d.bn_groups, ppg = cdiv(npg * d.H * d.W, MEDT_THREADS);
+    hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(d.bn_groups * ppg, OC), dim3(MEDT_THREADS), 0, s, stacked, dy, st,
+                       partials, d.C, d.H, d.W, OC, d.stride, npg);
     return launch_status("axial_out_bwd_stats");
 }
 

@@ -1,0 +1,84 @@
+"""One training step of reference train.py:140,156-161 as a replayable HIP graph.
+
+    output = model(X); loss = criterion(output, y); optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+At BASELINE.json's batch sizes every kernel of the step moves a few MB at most, so the step is bound by
+launch latency, not by HBM or MFMA.  The whole forward + loss + backward + gradient packing
+(+ the fused Adam when single-GPU) is therefore captured once into a hipGraph (torch.cuda.CUDAGraph drives
+hipStreamBeginCapture; the kernels are enqueued by libmedt_hip.so on the capturing stream) and replayed per
+step.  With several ranks the flat-bucket all-reduce runs between the replay and the Adam launch.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .optim import FlatAdam
+from .ops import cross_entropy
+
+
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class TrainStep:
+    def __init__(self, model, optimizer: FlatAdam, criterion=None, use_graph: bool = True, warmup: int = 3):
+        self.model, self.opt = model, optimizer
+        self.criterion = criterion if criterion is not None else cross_entropy
+        self.use_graph = use_graph
+        self.warmup = warmup
+        self.graph = None
+        self._sig = None
+        self.static_x = self.static_y = self.static_loss = None
+
+    # ---- eager ------------------------------------------------------------
+    def _eager(self, x, y):
+        out = self.model(x)
+        loss = self.criterion(out, y)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.pack_gradients()
+        self.opt.allreduce()
+        self.opt.apply(_world())
+        return loss
+
+    # ---- graph ------------------------------------------------------------
+    def _signature(self, x, y):
+        return (tuple(x.shape), tuple(y.shape), self.model.training,
+                tuple(p.requires_grad for p in self.opt.params))
+
+    def _capture(self, x, y):
+        self.static_x, self.static_y = x.clone(), y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # warm-up: allocator pools, FlatAdam groups, lazy inits
+            for _ in range(self.warmup):
+                self._eager(self.static_x, self.static_y)
+        torch.cuda.current_stream().wait_stream(side)
+        self.opt.zero_grad()
+        self.graph = torch.cuda.CUDAGraph()
+        single = _world() == 1
+        with torch.cuda.graph(self.graph):
+            out = self.model(self.static_x)
+            loss = self.criterion(out, self.static_y)
+            loss.backward()
+            self.opt.pack_gradients()
+            if single:
+                self.opt.apply(1)
+        self.static_loss = loss.detach()
+        self._single = single
+
+    def __call__(self, x, y):
+        if not self.use_graph:
+            return self._eager(x, y)
+        sig = self._signature(x, y)
+        if self.graph is None or sig != self._sig:     # first call, or the gates were switched on (train.py:169-171)
+            self._capture(x, y)
+            self._sig = sig
+        self.static_x.copy_(x)
+        self.static_y.copy_(y)
+        self.graph.replay()
+        if not self._single:
+            self.opt.allreduce()
+            self.opt.apply(_world())
+        return self.static_loss
