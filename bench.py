@@ -94,7 +94,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     bytes_main = 4 * C * 4 * M
     bytes_stats = C * 4 * M
     flops_main = 7.0 * M * L * C
-    roof = {"bound": "hbm", "kernel": "attn_fwd_kernel<GP=2,POS,AXIS=1>",
+    roof = {"bound": "hbm", "kernel": "attn_fwd3_kernel<GP=2,AXIS=1,L=64>",
             "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main},
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,

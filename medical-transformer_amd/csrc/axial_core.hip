@@ -16,9 +16,15 @@
 // the three relative tables by a skewed index d = i - j + L - 1 (consecutive lanes ->
 // consecutive addresses).  All tensors stay NCHW: the reference's permute+contiguous copies
 // (:143-148, :181-184) become address arithmetic.
-#include "medt_kernels.h"
+#include "axial_tiles.h"
+#include <stdlib.h>
 
 namespace medt {
+
+bool fast_path_enabled() {
+    static const bool on = [] { const char* e = getenv("MEDT_DISABLE_FAST"); return !(e && e[0] == '1'); }();
+    return on;
+}
 
 // --------------------------------------------------------------------------- //
 // geometry
@@ -54,6 +60,24 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
     g->S_T = MEDT_THREADS / g->L;
     g->tpg = cdiv(g->spg, g->S_T);
     g->HW = d.H * d.W;
+    g->fast3 = 0;
+    g->fparts = g->tpg;
+    g->nt = 1;
+    if (g->pos && fast_path_enabled()) {
+        int nt = fast3_max_subtiles(gp, g->L);
+        if (nt > 0) {
+            // Persistent workgroups over super-tiles of nt*S_T sequences.  Small problems (the model's own
+            // shapes) keep nt = 1 so there are enough workgroups; big ones amortise the table staging over
+            // up to NT sub-tiles and cap the grid at ~8 workgroups per CU.
+            while (nt > 1 && (long)g->groups * d.G * cdiv(g->spg, g->S_T * nt) < 2048) nt >>= 1;
+            const int nsup = cdiv(g->spg, g->S_T * nt);
+            int cap = 2048 / (g->groups * d.G);
+            if (cap < 1) cap = 1;
+            g->fast3 = 1;
+            g->nt = nt;
+            g->fparts = nsup < cap ? nsup : cap;
+        }
+    }
     g->sim_count = (double)g->spg * g->L * g->L;
     g->row_count = (double)g->spg * g->L;
     return MEDT_OK;
@@ -72,63 +96,6 @@ size_t axial_core_lds_bytes(const AxialGeom& g, bool backward) {
     }
     return fl * sizeof(float);
 }
-
-// --------------------------------------------------------------------------- //
-// tile movers: (channel, sequence, position) <-> NCHW
-// --------------------------------------------------------------------------- //
-struct TileCtx {
-    int L, Bo, W, HW, seq0, nseq;
-};
-
-// lds[ls*stride + (lch0+ch)*L + i] = src[n][ch0+ch][pixel(seq0+ls, i)]
-template <int AXIS>
-__device__ __forceinline__ void tile_load(float* lds, int stride, int lch0, const float* __restrict__ src, int CH,
-                                          int ch0, int nch, const TileCtx& t) {
-    const int per = t.nseq * t.L;
-    for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
-        const int ch = e / per, r = e - ch * per;
-        int ls, i;
-        if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
-        const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
-        const size_t off = ((size_t)n * CH + ch0 + ch) * t.HW + (AXIS == 1 ? s * t.W + i : i * t.W + s);
-        lds[ls * stride + (lch0 + ch) * t.L + i] = src[off];
-    }
-}
-
-template <int AXIS>
-__device__ __forceinline__ void tile_store(const float* lds, int stride, int lch0, float* __restrict__ dst, int CH,
-                                           int ch0, int nch, const TileCtx& t) {
-    const int per = t.nseq * t.L;
-    for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
-        const int ch = e / per, r = e - ch * per;
-        int ls, i;
-        if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
-        const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
-        const size_t off = ((size_t)n * CH + ch0 + ch) * t.HW + (AXIS == 1 ? s * t.W + i : i * t.W + s);
-        dst[off] = lds[ls * stride + (lch0 + ch) * t.L + i];
-    }
-}
-
-// pooled gradient: lds <- dy[n][ch0+ch][h/stride][w/stride] (0 outside the pooled extent)
-template <int AXIS>
-__device__ __forceinline__ void tile_load_pooled(float* lds, int stride, int lch0, const float* __restrict__ dy, int C,
-                                                 int ch0, int nch, int H, int pool, const TileCtx& t) {
-    const int per = t.nseq * t.L;
-    const int Ho = H / pool, Wo = t.W / pool;
-    for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
-        const int ch = e / per, r = e - ch * per;
-        int ls, i;
-        if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
-        const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
-        const int h = AXIS == 1 ? s : i, w = AXIS == 1 ? i : s;
-        const int ho = h / pool, wo = w / pool;
-        float v = 0.f;
-        if (ho < Ho && wo < Wo) v = dy[((size_t)(n * C + ch0 + ch) * Ho + ho) * Wo + wo];
-        lds[ls * stride + (lch0 + ch) * t.L + i] = v;
-    }
-}
-
-__device__ __forceinline__ float gate(const float* p) { return p ? *p : 1.f; }
 
 // --------------------------------------------------------------------------- //
 // forward statistics pass: sum / sum-of-squares of qk, f_qr*qr, f_kr*kr per head
@@ -605,6 +572,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
     const float e_qk = b_qk * MEDT_LOG2E, e_qr = b_qr * MEDT_LOG2E, e_kr = b_kr * MEDT_LOG2E;
     const int ls = threadIdx.x / L, idx = threadIdx.x - ls * L;
     const bool active = ls < t.nseq;
+    // Wrapped-diagonal second pass (no LDS float atomics in the inner loop, which run ~1 lane/clk on gfx950):
+    // needs the L lanes of a sequence inside one wave so column accumulators can rotate between lanes.
+    const bool diag = POS && L <= 64 && (L & (L - 1)) == 0;
     float dqkv_v[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) dqkv_v[ch] = 0.f;
@@ -664,11 +634,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
                     for (int c = 0; c < HQ; ++c) {
                         const float kc = kp[c * L + j];
                         dq[c] = fmaf(dSqk, kc, fmaf(gq, S.tq[c * TL + d], dq[c]));
-                        atomicAdd(&S.dtq[c * TL + d], gq * q[c]);
-                        atomicAdd(&S.dtk[c * TL + d], gk * kc);
+                        if (!diag) {
+                            atomicAdd(&S.dtq[c * TL + d], gq * q[c]);
+                            atomicAdd(&S.dtk[c * TL + d], gk * kc);
+                        }
                     }
+                    if (!diag) {
 #pragma unroll
-                    for (int c = 0; c < GP; ++c) atomicAdd(&S.dtv[c * TL + d], gv * dse[c]);
+                        for (int c = 0; c < GP; ++c) atomicAdd(&S.dtv[c * TL + d], gv * dse[c]);
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < HQ; ++c) dq[c] = fmaf(dSqk, kp[c * L + j], dq[c]);
@@ -677,6 +651,99 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
 #pragma unroll
             for (int c = 0; c < HQ; ++c) dqkv_v[c] = dq[c];
         }
+        // ---------------- wrapped diagonals: lane delta visits (i, j = (i - delta) mod L) ----------------
+        // All pairs a lane visits share one of two table entries (d = delta+L-1 while i >= delta, delta-1
+        // after the wrap), so the relative-table gradients accumulate in lane-private registers; the dk/dv
+        // accumulators belong to a column and hop to the next lane every step (one cross-lane move each).
+        if (diag) {
+            const int dl = idx, Lm = L - 1;
+            const int d_hi = dl + L - 1, d_lo = dl > 0 ? dl - 1 : 0;
+            const int src_lane = (threadIdx.x & 63 & ~Lm) | ((dl - 1) & Lm);
+            float tq_hi[HQ], tq_lo[HQ], tk_hi[HQ], tk_lo[HQ], tv_hi[GP], tv_lo[GP];
+            float aq_hi[HQ], aq_lo[HQ], ak_hi[HQ], ak_lo[HQ], av_hi[GP], av_lo[GP];
+            float dk[HQ], dv[GP];
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                tq_hi[c] = S.tq[c * TL + d_hi]; tq_lo[c] = S.tq[c * TL + d_lo];
+                tk_hi[c] = S.tk[c * TL + d_hi]; tk_lo[c] = S.tk[c * TL + d_lo];
+                aq_hi[c] = aq_lo[c] = ak_hi[c] = ak_lo[c] = 0.f;
+                dk[c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                tv_hi[c] = S.tv[c * TL + d_hi]; tv_lo[c] = S.tv[c * TL + d_lo];
+                av_hi[c] = av_lo[c] = 0.f;
+                dv[c] = 0.f;
+            }
+            for (int i = 0; i < L; ++i) {
+                const int j = (i - dl) & Lm;
+                const bool hi = i >= dl;
+                float tqk = 0.f, rq = 0.f, rk = 0.f, kj[HQ], qi[HQ];
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    qi[c] = qp[c * L + i];
+                    kj[c] = kp[c * L + j];
+                    tqk = fmaf(qi[c], kj[c], tqk);
+                    rq = fmaf(qi[c], hi ? tq_hi[c] : tq_lo[c], rq);
+                    rk = fmaf(kj[c], hi ? tk_hi[c] : tk_lo[c], rk);
+                }
+                const float tqr = f_qr * rq, tkr = f_kr * rk;
+                const float z = fmaf(e_qk, tqk, fmaf(e_qr, tqr, e_kr * tkr));
+                const float P = __builtin_amdgcn_exp2f(z - lsep[i]);
+                float dPv = 0.f, dPe = 0.f, dsv_i[GP], dse_i[GP];
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    dsv_i[c] = g2[(2 * c) * L + i];
+                    dse_i[c] = g2[(2 * c + 1) * L + i];
+                    dPv = fmaf(dsv_i[c], vp[c * L + j], dPv);
+                    dPe = fmaf(dse_i[c], hi ? tv_hi[c] : tv_lo[c], dPe);
+                }
+                const float dZ = P * (fmaf(f_sv, dPv, f_sve * dPe) - delp[i]);
+                const float dSqk = fmaf(b_qk, dZ, fmaf(u_qk, tqk, w_qk));
+                const float gq = f_qr * fmaf(b_qr, dZ, fmaf(u_qr, tqr, w_qr));
+                const float gk = f_kr * fmaf(b_kr, dZ, fmaf(u_kr, tkr, w_kr));
+                const float gv = f_sve * P, pv = f_sv * P;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    dk[c] = fmaf(dSqk, qi[c], fmaf(gk, hi ? tk_hi[c] : tk_lo[c], dk[c]));
+                    const float cq = gq * qi[c], ck2 = gk * kj[c];
+                    aq_hi[c] += hi ? cq : 0.f;  aq_lo[c] += hi ? 0.f : cq;
+                    ak_hi[c] += hi ? ck2 : 0.f; ak_lo[c] += hi ? 0.f : ck2;
+                }
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    dv[c] = fmaf(pv, dsv_i[c], dv[c]);
+                    const float cv = gv * dse_i[c];
+                    av_hi[c] += hi ? cv : 0.f;  av_lo[c] += hi ? 0.f : cv;
+                }
+                if (i + 1 < L) {                          // hand the column accumulators to the next lane
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) dk[c] = __shfl(dk[c], src_lane, 64);
+#pragma unroll
+                    for (int c = 0; c < GP; ++c) dv[c] = __shfl(dv[c], src_lane, 64);
+                }
+            }
+            // after step L-1 lane delta holds column (L-1-delta) mod L: park the values, the owner lane reads them
+            const int owner = (threadIdx.x & 63 & ~Lm) | ((L - 1 - dl) & Lm);
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) dqkv_v[HQ + c] = __shfl(dk[c], owner, 64);
+#pragma unroll
+            for (int c = 0; c < GP; ++c) dqkv_v[GP + c] = __shfl(dv[c], owner, 64);
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                atomicAdd(&S.dtq[c * TL + d_hi], aq_hi[c]);
+                atomicAdd(&S.dtk[c * TL + d_hi], ak_hi[c]);
+                if (dl > 0) {
+                    atomicAdd(&S.dtq[c * TL + d_lo], aq_lo[c]);
+                    atomicAdd(&S.dtk[c * TL + d_lo], ak_lo[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                atomicAdd(&S.dtv[c * TL + d_hi], av_hi[c]);
+                if (dl > 0) atomicAdd(&S.dtv[c * TL + d_lo], av_lo[c]);
+            }
+        } else
         // ---------------- column-oriented: thread owns key column j = idx ----------------
         {
             const int j = idx;
@@ -788,12 +855,20 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
 
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
                       float* partials, hipStream_t s) {
+    if (fast_path_enabled()) {
+        const int rc = axial_logit_stats_fast(g, qkv_raw, qkv, relative, gates, partials, s);
+        if (rc <= 0) return rc;
+    }
     const size_t lds = axial_core_lds_bytes(g, false);
     MEDT_DISPATCH(logit_stats_kernel, g, qkv_raw, qkv, relative, gates, partials);
 }
 
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                    GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s) {
+    if (fast_path_enabled()) {
+        const int rc = axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, s);
+        if (rc <= 0) return rc;
+    }
     const size_t lds = axial_core_lds_bytes(g, false);
     MEDT_DISPATCH(attn_fwd_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials);
 }

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
 #pragma unroll
     for (int o = 0; o < OT; ++o) acc[o] = bias ? bias[o0 + o] : 0.f;
     const float* xn = x + (size_t)n * Cin * H * W;
+#pragma unroll(K == 1 ? 4 : 1)
     for (int c = 0; c < Cin; ++c) {
         float xv[KK];
 #pragma unroll
@@ -70,25 +71,32 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
 
 int conv2d_parts_per_group(int N, int groups, int HoWo) { return cdiv((N / groups) * HoWo, MEDT_THREADS); }
 
+// Output-channel tile per lane: 16 when there are enough workgroups to fill the chip, else smaller tiles
+// (more workgroups, less register reuse) -- the deep LoGo layers have as few as 64 output positions.
+static int pick_tile(int C, int max_tile, long position_blocks) {
+    int t = max_tile;
+    while (t > 1 && (C % t != 0 || position_blocks * (C / t) < 512)) t >>= 1;
+    while (C % t != 0) t >>= 1;
+    return t;
+}
+
 template <int K>
 static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin,
                         int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, int groups,
                         hipStream_t s) {
     const int npg = N / groups;
     const unsigned gx = (unsigned)(groups * conv2d_parts_per_group(N, groups, Ho * Wo));
-    constexpr int OTmax = K == 7 ? 8 : 16;
-    if (Cout % OTmax == 0)
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, OTmax>), dim3(gx, Cout / OTmax), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
-                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
-    else if (Cout % 8 == 0)
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 8>), dim3(gx, Cout / 8), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
-                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
-    else if (Cout % 2 == 0)
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 2>), dim3(gx, Cout / 2), dim3(MEDT_THREADS), 0, s, x, w, bias, y,
-                           partials, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
-    else
-        hipLaunchKernelGGL((conv2d_fwd_kernel<K, 1>), dim3(gx, Cout), dim3(MEDT_THREADS), 0, s, x, w, bias, y, partials,
-                           Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg);
+#define MEDT_LAUNCH_FWD(OT)                                                                                        \
+    hipLaunchKernelGGL((conv2d_fwd_kernel<K, OT>), dim3(gx, Cout / OT), dim3(MEDT_THREADS), 0, s, x, w, bias, y, partials, \
+                       Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg)
+    switch (pick_tile(Cout, K == 7 ? 8 : 16, gx)) {
+        case 16: if constexpr (K != 7) { MEDT_LAUNCH_FWD(16); } break;
+        case 8: MEDT_LAUNCH_FWD(8); break;
+        case 4: MEDT_LAUNCH_FWD(4); break;
+        case 2: MEDT_LAUNCH_FWD(2); break;
+        default: MEDT_LAUNCH_FWD(1); break;
+    }
+#undef MEDT_LAUNCH_FWD
     return launch_status("conv2d_fwd");
 }
 
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
     const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
+#pragma unroll(K == 1 ? 4 : 1)
     for (int o = 0; o < Cout; ++o) {
         float dv[KK];
 #pragma unroll
@@ -158,16 +167,17 @@ template <int K>
 static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int Ho,
                              int Wo, int stride, int pad, hipStream_t s) {
     const unsigned gx = (unsigned)(((long)N * H * W + MEDT_THREADS - 1) / MEDT_THREADS);
-    constexpr int CTmax = K == 7 ? 4 : 16;
-    if (Cin % CTmax == 0)
-        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CTmax>), dim3(gx, Cin / CTmax), dim3(MEDT_THREADS), 0, s, dy, w, dx,
-                           N, Cin, H, W, Cout, Ho, Wo, stride, pad);
-    else if (Cin % 8 == 0 && K != 7)
-        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 8>), dim3(gx, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin,
-                           H, W, Cout, Ho, Wo, stride, pad);
-    else
-        hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, 1>), dim3(gx, Cin), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin, H,
-                           W, Cout, Ho, Wo, stride, pad);
+#define MEDT_LAUNCH_BWD(CT)                                                                                       \
+    hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CT>), dim3(gx, Cin / CT), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin, \
+                       H, W, Cout, Ho, Wo, stride, pad)
+    switch (pick_tile(Cin, K == 7 ? 4 : 16, gx)) {
+        case 16: if constexpr (K != 7) { MEDT_LAUNCH_BWD(16); } break;
+        case 8: if constexpr (K != 7) { MEDT_LAUNCH_BWD(8); } break;
+        case 4: MEDT_LAUNCH_BWD(4); break;
+        case 2: MEDT_LAUNCH_BWD(2); break;
+        default: MEDT_LAUNCH_BWD(1); break;
+    }
+#undef MEDT_LAUNCH_BWD
     return launch_status("conv2d_bwd_data");
 }
 

@@ -150,12 +150,12 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
                           st.qkv, s))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
     if (tr && (rc = axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.part_sim, s))) return rc;
-    if ((rc = bn_finalize(w.part_sim, g.tpg, g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,
+    if ((rc = bn_finalize(w.part_sim, g.fparts, g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,
                           st.sim, s))) return rc;
     // logits + softmax + gated sv|sve, bn_output batch statistics                                 :157-178
     if ((rc = axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
                              tr ? w.part_out : nullptr, s))) return rc;
-    if ((rc = bn_finalize(w.part_out, g.tpg, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
+    if ((rc = bn_finalize(w.part_out, g.fparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
                           st.out, s))) return rc;
     // bn_output + pair-sum + AvgPool                                                              :179-187
     return axial_out_fwd(*d, sv->stacked, st.out, y, s);

@@ -80,6 +80,9 @@ struct AxialGeom {
     int S_T;                // sequences per workgroup tile
     int tpg;                // tiles per group
     int HW;
+    int fast3;              // 1: compile-time-L persistent forward kernels (axial_fast.hip)
+    int fparts;             // partial-statistics slots per group written by the forward L x L kernels
+    int nt;                 // sub-tiles (of S_T sequences) per super-tile in the persistent kernels
     double sim_count;       // elements per bn_similarity channel per group = spg * L * L
     double row_count;       // elements per bn_qkv / bn_output channel per group = spg * L
 };
@@ -87,6 +90,14 @@ int  axial_geom(const medt_axial_desc& d, AxialGeom* g);   // validates, returns
 size_t axial_core_lds_bytes(const AxialGeom& g, bool backward);
 
 struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; };
+
+// axial_fast.hip: 16-byte-LDS-read variants for has_pos && L % 4 == 0; return 1 when not applicable
+int axial_logit_stats_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative,
+                           GatePtrs gates, float* partials, hipStream_t s);
+int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                        GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s);
+int fast3_max_subtiles(int gp, int L);
+bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // logit statistics: partials [group][tile][SC][2]
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
