@@ -118,9 +118,9 @@ def cpu_baseline_leg(steps=3):
     import lib as droplib
     O.set_fast_bn(True)                                  # aten's fused BatchNorm, like the reference's nn.BatchNorm
     torch.manual_seed(3000)
-    # Host threads: all cores up to MEDT_CPU_THREADS (default 32).  The reference's tensors are small
+    # Host threads: MEDT_CPU_THREADS (default 8, the fastest setting measured on the 256-core MI355X host:
     # (a few MB); beyond a few tens of OpenMP threads aten's CPU kernels get slower, not faster.
-    cores = min(os.cpu_count() or 1, int(os.environ.get("MEDT_CPU_THREADS", "32")))
+    cores = min(os.cpu_count() or 1, int(os.environ.get("MEDT_CPU_THREADS", "8")))
     torch.set_num_threads(cores)
     log(f"cpu baseline: {cores} threads of {os.cpu_count()} cores")
     sd = droplib.models.axialnet.MedT(img_size=IMG, imgchan=3).state_dict()

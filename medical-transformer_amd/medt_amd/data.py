@@ -1,0 +1,180 @@
+"""Host-side input pipeline of reference utils.py / utils_gray.py without cv2 / torchvision / skimage
+(none of which exist in the MI355X image): PIL + numpy only.
+
+Semantics kept from the reference:
+  * images are read in OpenCV channel order (BGR) and scaled to [0,1] by to_tensor, no mean/std,
+    no resize (utils.py:151,90);
+  * masks: colour datasets threshold  > 127 -> 1 (utils.py:156-157); grayscale datasets >= 127 -> 1 and the
+    image is read as one channel (utils_gray.py:151,159-160);
+  * JointTransform2D: optional random crop, horizontal flip with probability p_flip drawn from
+    np.random (so train.py's np.random.seed(3000) governs it), long (class-index) masks.
+Colour jitter / random affine are accepted and rejected loudly if requested: train.py never enables them
+(color_jitter_params=None, p_random_affine default 0; train.py:85-86).
+"""
+from __future__ import annotations
+
+import os
+from collections import defaultdict
+from numbers import Number
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import Dataset
+
+
+def to_long_tensor(pic):
+    return torch.from_numpy(np.array(pic, np.uint8)).long()
+
+
+def correct_dims(*images):
+    out = [np.expand_dims(img, axis=2) if img.ndim == 2 else img for img in images]
+    return out[0] if len(out) == 1 else out
+
+
+def imread(path, gray=False):
+    """cv2.imread equivalent: uint8 HxWx3 in BGR order, or HxW when gray (cv2.IMREAD_GRAYSCALE)."""
+    with Image.open(path) as im:
+        if gray:
+            return np.array(im.convert("L"), np.uint8)
+        return np.array(im.convert("RGB"), np.uint8)[:, :, ::-1].copy()
+
+
+def imwrite(path, arr):
+    arr = np.asarray(arr)
+    if arr.ndim == 3 and arr.shape[2] == 3:
+        arr = arr[:, :, ::-1]
+    Image.fromarray(arr.astype(np.uint8)).save(path)
+
+
+def to_tensor(img_hwc_uint8):
+    return torch.from_numpy(np.ascontiguousarray(img_hwc_uint8.transpose(2, 0, 1))).float().div_(255.0)
+
+
+class JointTransform2D:
+    def __init__(self, crop=(32, 32), p_flip=0.5, color_jitter_params=(0.1, 0.1, 0.1, 0.1), p_random_affine=0,
+                 long_mask=False):
+        if color_jitter_params or p_random_affine:
+            raise NotImplementedError("colour jitter / random affine need torchvision; train.py never enables them")
+        self.crop, self.p_flip, self.long_mask = crop, p_flip, long_mask
+        self.color_jitter_params, self.p_random_affine = color_jitter_params, p_random_affine
+
+    def __call__(self, image, mask):
+        image, mask = np.asarray(image), np.asarray(mask)
+        if self.crop:
+            th, tw = self.crop
+            h, w = image.shape[:2]
+            i = 0 if h == th else int(torch.randint(0, h - th + 1, (1,)).item())
+            j = 0 if w == tw else int(torch.randint(0, w - tw + 1, (1,)).item())
+            image, mask = image[i:i + th, j:j + tw], mask[i:i + th, j:j + tw]
+        if np.random.rand() < self.p_flip:
+            image, mask = image[:, ::-1], mask[:, ::-1]
+        image = to_tensor(correct_dims(image))
+        if self.long_mask:
+            mask = to_long_tensor(mask.reshape(mask.shape[0], mask.shape[1]))
+        else:
+            mask = to_tensor(correct_dims(mask))
+        return image, mask
+
+
+class ImageToImage2D(Dataset):
+    """<root>/img/*.png + <root>/labelcol/<same stem>.png  ->  (image CHW float, mask HW long, filename)."""
+
+    def __init__(self, dataset_path, joint_transform=None, one_hot_mask=False, gray=False):
+        self.dataset_path = dataset_path
+        self.input_path = os.path.join(dataset_path, "img")
+        self.output_path = os.path.join(dataset_path, "labelcol")
+        self.images_list = os.listdir(self.input_path)
+        self.one_hot_mask = one_hot_mask
+        self.gray = gray
+        self.joint_transform = joint_transform or (lambda x, y: (to_tensor(correct_dims(x)), to_tensor(correct_dims(y))))
+
+    def __len__(self):
+        return len(self.images_list)
+
+    def __getitem__(self, idx):
+        name = self.images_list[idx]
+        image = imread(os.path.join(self.input_path, name), self.gray)
+        mask = imread(os.path.join(self.output_path, name[:-3] + "png"), gray=True).copy()
+        if self.gray:
+            mask = (mask >= 127).astype(np.uint8)
+        else:
+            mask = (mask > 127).astype(np.uint8)
+        image, mask = correct_dims(image, mask)
+        image, mask = self.joint_transform(image, mask)
+        if self.one_hot_mask:
+            assert self.one_hot_mask > 0, "one_hot_mask must be nonnegative"
+            mask = torch.zeros((self.one_hot_mask, mask.shape[1], mask.shape[2])).scatter_(0, mask.long(), 1)
+        return image, mask, name
+
+
+class Image2D(Dataset):
+    def __init__(self, dataset_path, transform=None, gray=False):
+        self.dataset_path = dataset_path
+        self.input_path = os.path.join(dataset_path, "img")
+        self.images_list = os.listdir(self.input_path)
+        self.gray = gray
+        self.transform = transform or (lambda x: to_tensor(correct_dims(x)))
+
+    def __len__(self):
+        return len(self.images_list)
+
+    def __getitem__(self, idx):
+        name = self.images_list[idx]
+        return self.transform(correct_dims(imread(os.path.join(self.input_path, name), self.gray))), name
+
+
+def chk_mkdir(*paths):
+    for p in paths:
+        if not os.path.exists(p):
+            os.makedirs(p)
+
+
+class Logger:
+    def __init__(self, verbose=False):
+        self.logs, self.verbose = defaultdict(list), verbose
+
+    def log(self, logs):
+        for k, v in logs.items():
+            self.logs[k].append(v)
+        if self.verbose:
+            print(logs)
+
+    def get_logs(self):
+        return self.logs
+
+    def to_csv(self, path):
+        import pandas as pd
+        pd.DataFrame(self.logs).to_csv(path, index=None)
+
+
+class MetricList:
+    def __init__(self, metrics):
+        assert isinstance(metrics, dict), "'metrics' must be a dictionary of callables"
+        self.metrics = metrics
+        self.results = {k: 0.0 for k in metrics}
+
+    def __call__(self, y_out, y_batch):
+        for k, fn in self.metrics.items():
+            self.results[k] += fn(y_out, y_batch)
+
+    def reset(self):
+        self.results = {k: 0.0 for k in self.metrics}
+
+    def get_results(self, normalize=False):
+        assert isinstance(normalize, bool) or isinstance(normalize, Number), "'normalize' must be boolean or a number"
+        if not normalize:
+            return self.results
+        return {k: v / normalize for k, v in self.results.items()}
+
+
+def make_synthetic_dataset(root, n=16, size=128, seed=3000, gray=False):
+    """BASELINE.json config 1 plumbing data: n PNG pairs img/NNNN.png (uniform uint8) + labelcol/NNNN.png (0/255)."""
+    rng = np.random.RandomState(seed)
+    chk_mkdir(os.path.join(root, "img"), os.path.join(root, "labelcol"))
+    for k in range(n):
+        img = rng.randint(0, 256, (size, size) if gray else (size, size, 3)).astype(np.uint8)
+        lab = (rng.rand(size, size) < 0.5).astype(np.uint8) * 255
+        Image.fromarray(img).save(os.path.join(root, "img", f"{k:04d}.png"))
+        Image.fromarray(lab).save(os.path.join(root, "labelcol", f"{k:04d}.png"))
+    return root

@@ -27,9 +27,7 @@ class TrainStep:
         self.criterion = criterion if criterion is not None else cross_entropy
         self.use_graph = use_graph
         self.warmup = warmup
-        self.graph = None
-        self._sig = None
-        self.static_x = self.static_y = self.static_loss = None
+        self._graphs = {}          # signature -> (graph, static_x, static_y, static_loss, single)
 
     # ---- eager ------------------------------------------------------------
     def _eager(self, x, y):
@@ -48,37 +46,40 @@ class TrainStep:
                 tuple(p.requires_grad for p in self.opt.params))
 
     def _capture(self, x, y):
-        self.static_x, self.static_y = x.clone(), y.clone()
+        """Note: the warm-up steps are real optimisation steps on (x, y) (the same batch is then replayed)."""
+        static_x, static_y = x.clone(), y.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                  # warm-up: allocator pools, FlatAdam groups, lazy inits
             for _ in range(self.warmup):
-                self._eager(self.static_x, self.static_y)
+                self._eager(static_x, static_y)
         torch.cuda.current_stream().wait_stream(side)
         self.opt.zero_grad()
-        self.graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         single = _world() == 1
-        with torch.cuda.graph(self.graph):
-            out = self.model(self.static_x)
-            loss = self.criterion(out, self.static_y)
+        with torch.cuda.graph(graph):
+            out = self.model(static_x)
+            loss = self.criterion(out, static_y)
             loss.backward()
             self.opt.pack_gradients()
             if single:
                 self.opt.apply(1)
-        self.static_loss = loss.detach()
-        self._single = single
+        return graph, static_x, static_y, loss.detach(), single
 
     def __call__(self, x, y):
         if not self.use_graph:
             return self._eager(x, y)
         sig = self._signature(x, y)
-        if self.graph is None or sig != self._sig:     # first call, or the gates were switched on (train.py:169-171)
-            self._capture(x, y)
-            self._sig = sig
-        self.static_x.copy_(x)
-        self.static_y.copy_(y)
-        self.graph.replay()
-        if not self._single:
+        entry = self._graphs.get(sig)
+        if entry is None:                              # first call with this shape, or the gates were switched on
+            if any(k[3] != sig[3] for k in self._graphs):          # requires_grad changed (train.py:169-171):
+                self._graphs.clear()                                # graphs captured before are stale
+            entry = self._graphs[sig] = self._capture(x, y)
+        graph, static_x, static_y, static_loss, single = entry
+        static_x.copy_(x)
+        static_y.copy_(y)
+        graph.replay()
+        if not single:
             self.opt.allreduce()
             self.opt.apply(_world())
-        return self.static_loss
+        return static_loss

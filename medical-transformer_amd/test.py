@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's test.py (reference test.py:28-146): same flags; loads a checkpoint written by
+train.py (with or without DataParallel's "module." prefix), runs the network in eval mode and writes the
+thresholded channel-1 prediction of every validation image as <direc>/<filename>.  The reference reads an
+undefined args.aug (test.py:62) and dies; here the flag exists and is ignored."""
+import argparse
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+import lib
+from medt_amd.data import imwrite
+
+parser = argparse.ArgumentParser(description='MedT')
+parser.add_argument('-j', '--workers', default=16, type=int, metavar='N', help='number of data loading workers (default: 8)')
+parser.add_argument('--epochs', default=100, type=int, metavar='N', help='number of total epochs to run(default: 1)')
+parser.add_argument('--start-epoch', default=0, type=int, metavar='N', help='manual epoch number (useful on restarts)')
+parser.add_argument('-b', '--batch_size', default=1, type=int, metavar='N', help='batch size (default: 8)')
+parser.add_argument('--learning_rate', default=1e-3, type=float, metavar='LR', help='initial learning rate (default: 0.01)')
+parser.add_argument('--momentum', default=0.9, type=float, metavar='M', help='momentum')
+parser.add_argument('--weight-decay', '--wd', default=1e-5, type=float, metavar='W', help='weight decay (default: 1e-4)')
+parser.add_argument('--train_dataset', type=str)
+parser.add_argument('--val_dataset', type=str)
+parser.add_argument('--save_freq', type=int, default=5)
+parser.add_argument('--modelname', default='off', type=str, help='name of the model to load')
+parser.add_argument('--cuda', default="on", type=str, help='switch on/off cuda option (default: off)')
+parser.add_argument('--aug', default='off', type=str)
+parser.add_argument('--direc', default='./results', type=str, help='directory to save')
+parser.add_argument('--crop', type=int, default=None)
+parser.add_argument('--device', default='cuda', type=str)
+parser.add_argument('--loaddirec', default='load', type=str)
+parser.add_argument('--imgsize', type=int, default=None)
+parser.add_argument('--gray', default='no', type=str)
+
+
+def main():
+    args = parser.parse_args()
+    if args.gray == "yes":
+        from utils_gray import JointTransform2D, ImageToImage2D
+        imgchant = 1
+    else:
+        from utils import JointTransform2D, ImageToImage2D
+        imgchant = 3
+    crop = (args.crop, args.crop) if args.crop is not None else None
+    tf_val = JointTransform2D(crop=crop, p_flip=0, color_jitter_params=None, long_mask=True)
+    valloader = DataLoader(ImageToImage2D(args.val_dataset, tf_val), 1, shuffle=True)
+    device = torch.device(args.device)
+    if device.type == "cuda":
+        device = torch.device("cuda", device.index or 0)
+        torch.cuda.set_device(device)
+    factories = {"axialunet": lib.models.axialunet, "MedT": lib.models.axialnet.MedT,
+                 "gatedaxialunet": lib.models.axialnet.gated, "logo": lib.models.axialnet.logo}
+    model = factories[args.modelname](img_size=args.imgsize, imgchan=imgchant).to(device)
+    state = torch.load(args.loaddirec, map_location=device)
+    state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+    model.load_state_dict(state)
+    model.eval()
+    fulldir = args.direc + "/"
+    os.makedirs(fulldir, exist_ok=True)
+    for batch_idx, (X_batch, y_batch, *rest) in enumerate(valloader):
+        image_filename = rest[0][0] if isinstance(rest[0][0], str) else '%s.png' % str(batch_idx + 1).zfill(3)
+        with torch.no_grad():
+            y_out = model(X_batch.to(device))
+        yHaT = (y_out.detach().cpu().numpy() >= 0.5).astype(np.uint8) * 255
+        imwrite(fulldir + image_filename, yHaT[0, 1, :, :])
+
+
+if __name__ == "__main__":
+    main()
