@@ -194,55 +194,69 @@ int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, 
 }
 
 // --------------------------------------------------------------------------- //
-// backward-weight:  dw[o,c,kh,kw] = sum_{n,ho,wo} dy[n,o,ho,wo] * x[n,c,ho*s-p+kh,wo*s-p+kw]
-// One workgroup = one tap (kh,kw) x one 64(o) x 64(c) tile x one chunk of output pixels;
-// 64-pixel LDS steps, 4x4 register tile per lane; chunk partials reduced by reduce_rows.
+// backward-weight as an implicit GEMM:  dW[o, k] = sum_q dY[o, q] * Xcol[k, q]
+//   k = (c, kh, kw) flattened (the weight tensor's own layout), q = (n, ho, wo) flattened.
+// One workgroup = one 64(o) x 64(k) tile x one chunk of QS positions; 64-position LDS steps, 4x4 register
+// tile per lane.  Flattening the taps into k keeps the tile full for the 3- and 8-channel stems (k = 147, 72)
+// and QS shrinks until there are enough workgroups to fill the chip; chunk partials go through a deterministic
+// reduction (reduce_rows), no float atomics.  The optional (raw, coef) pair applies a BatchNorm-backward affine
+// to dY on load (qkv_transform's gradient, whose dY is still in normalised space).
 // --------------------------------------------------------------------------- //
-#define CW_PIX_PER_SPLIT 256
-__global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_weight_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H,
-    int W, int Cout, int Ho, int Wo, int K, int stride, int pad) {
+template <int K>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+    int stride, int pad, int QS, int npg) {
+    constexpr int KK = K * K;
     __shared__ float A[64][65];
-    __shared__ float X[64][65];
-    const int KK = K * K;
-    const int o0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tap = blockIdx.z % KK, split = blockIdx.z / KK;
-    const int kh = tap / K, kw = tap - kh * K;
-    const int HoWo = Ho * Wo;
+    __shared__ float B[64][65];
+    const int Ktot = Cin * KK, HoWo = Ho * Wo;
+    const int o0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
     const long NP = (long)N * HoWo;
-    const long q_begin = (long)split * CW_PIX_PER_SPLIT;
-    const long q_end = q_begin + CW_PIX_PER_SPLIT < NP ? q_begin + CW_PIX_PER_SPLIT : NP;
+    const long q_begin = (long)blockIdx.z * QS;
+    const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
     const int to = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    const int j = threadIdx.x & 63, r0 = threadIdx.x >> 6;          // staging: fixed position j, rows r0, r0+4, ...
     float acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
     for (long q0 = q_begin; q0 < q_end; q0 += 64) {
-        for (int e = threadIdx.x; e < 64 * 64; e += MEDT_THREADS) {
-            const int r = e >> 6, j = e & 63;
-            const long q = q0 + j;
+        const long q = q0 + j;
+        const bool qok = q < q_end;
+        const int n = qok ? (int)(q / HoWo) : 0, p = qok ? (int)(q - (long)n * HoWo) : 0;
+        const int ho = p / Wo, wo = p - ho * Wo;
+        const int hb = ho * stride - pad, wb = wo * stride - pad;
+        const float* dyp = dy + (size_t)n * Cout * HoWo + p;
+        const float* rawp = raw ? raw + (size_t)n * Cout * HoWo + p : nullptr;
+        const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
+        const float* xp = x + (size_t)n * Cin * H * W;
+#pragma unroll 4
+        for (int r = r0; r < 64; r += 4) {
             float a = 0.f, b = 0.f;
-            if (q < q_end) {
-                const int n = (int)(q / HoWo), p = (int)(q - (long)n * HoWo);
-                if (o0 + r < Cout) a = dy[((size_t)n * Cout + o0 + r) * HoWo + p];
-                if (c0 + r < Cin) {
-                    const int ho = p / Wo, wo = p - ho * Wo;
-                    const int h = ho * stride - pad + kh, ww = wo * stride - pad + kw;
-                    if (h >= 0 && h < H && ww >= 0 && ww < W) b = x[(((size_t)n * Cin + c0 + r) * H + h) * W + ww];
-                }
+            const int o = o0 + r, k = k0 + r;
+            if (qok && o < Cout) {
+                a = dyp[(size_t)o * HoWo];
+                if (cf) a = fmaf(cf[o * 3], a, fmaf(cf[o * 3 + 1], rawp[(size_t)o * HoWo], cf[o * 3 + 2]));
+            }
+            if (qok && k < Ktot) {
+                const int c = k / KK, t = k - c * KK;
+                const int kh = t / K, kw = t - kh * K;
+                const int h = hb + kh, w = wb + kw;
+                if (h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + h) * W + w];
             }
             A[r][j] = a;
-            X[r][j] = b;
+            B[r][j] = b;
         }
         __syncthreads();
 #pragma unroll 4
-        for (int j = 0; j < 64; ++j) {
+        for (int jj = 0; jj < 64; ++jj) {
             float av[4], bv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = A[to + 16 * a][j];
+            for (int a = 0; a < 4; ++a) av[a] = A[to + 16 * a][jj];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = X[tc + 16 * b][j];
+            for (int b = 0; b < 4; ++b) bv[b] = B[tc + 16 * b][jj];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -250,27 +264,52 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_weight_kernel(
         }
         __syncthreads();
     }
-    float* out = scratch + (size_t)split * Cout * Cin * KK;
+    float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int o = o0 + to + 16 * a, c = c0 + tc + 16 * b;
-            if (o < Cout && c < Cin) out[((size_t)o * Cin + c) * KK + tap] = acc[a][b];
+            const int o = o0 + to + 16 * a, k = k0 + tc + 16 * b;
+            if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[a][b];
         }
 }
 
-int conv2d_bwd_weight_splits(int N, int Ho, int Wo) { return cdiv(N * Ho * Wo, CW_PIX_PER_SPLIT); }
+// positions per chunk: as small as 64 while the grid is below ~512 workgroups, at most 512
+static int wgrad_chunk(int Cout, int Ktot, long NP) {
+    const long tiles = (long)cdiv(Cout, 64) * cdiv(Ktot, 64);
+    int QS = 512;
+    while (QS > 64 && tiles * ((NP + QS - 1) / QS) < 512) QS >>= 1;
+    return QS;
+}
 
-int conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int N, int Cin, int H, int W, int Cout,
-                      int K, int stride, int pad, hipStream_t s) {
+int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo) {
+    const long NP = (long)N * Ho * Wo;
+    const int QS = wgrad_chunk(Cout, Cin * K * K, NP);
+    return (int)((NP + QS - 1) / QS);
+}
+
+int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
+                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    const int splits = conv2d_bwd_weight_splits(N, Ho, Wo);
-    hipLaunchKernelGGL(conv2d_bwd_weight_kernel, dim3(cdiv(Cout, 64), cdiv(Cin, 64), K * K * splits), dim3(MEDT_THREADS),
-                       0, s, dy, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad);
-    int rc = launch_status("conv2d_bwd_weight");
+    const long NP = (long)N * Ho * Wo;
+    const int Ktot = Cin * K * K, QS = wgrad_chunk(Cout, Ktot, NP);
+    const int splits = (int)((NP + QS - 1) / QS);
+    const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
+    switch (K) {
+        case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
+        case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
+        case 7: hipLaunchKernelGGL(conv_wgrad_kernel<7>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
+        default: set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K); return MEDT_EUNSUPPORTED;
+    }
+    int rc = launch_status("conv_wgrad");
     if (rc) return rc;
-    return reduce_rows(scratch, splits, Cout * Cin * K * K, dw, s);
+    if (splits == 1) {
+        if (hipMemcpyAsync(dw, scratch, (size_t)Cout * Ktot * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            set_error("conv_wgrad: copy failed"); return MEDT_ELAUNCH;
+        }
+        return MEDT_OK;
+    }
+    return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
 }
 
 // per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients)

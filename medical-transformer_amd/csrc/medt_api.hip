@@ -59,7 +59,7 @@ struct BwdWs {
         coef_qkv = c.take<float>((size_t)g.groups * 2 * g.C * 3);
         rel_part = c.take<float>(g.pos ? nblocks * 2 * g.gp * TL : 0);
         gate_part = c.take<float>(g.pos ? nblocks * 4 : 0);
-        dw_scratch = c.take<float>((size_t)conv1x1_bwd_weight_splits(g.N, g.HW) * 2 * g.C * g.C);
+        dw_scratch = c.take<float>((size_t)conv2d_bwd_weight_splits(g.N, g.C, 2 * g.C, 1, g.H, g.W) * 2 * g.C * g.C);
         dy_masked = c.take<float>(out_relu ? (size_t)g.N * g.C * (g.H / stride) * (g.W / stride) : 0);
     }
 };
@@ -203,8 +203,8 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
     if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;
-    if ((rc = conv1x1_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, 2 * g.C, g.HW,
-                                 g.groups, s))) return rc;
+    if ((rc = conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
+                                1, 0, g.groups, s))) return rc;
     if (g.pos) {
         if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
         if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, s))) return rc;
@@ -233,7 +233,7 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     if (g->Ho <= 0 || g->Wo <= 0) { set_error("conv: empty output"); return MEDT_EINVAL; }
     g->HoWo = g->Ho * g->Wo;
     g->ppg = conv2d_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo);
-    g->splits = conv2d_bwd_weight_splits(d->N, g->Ho, g->Wo);
+    g->splits = conv2d_bwd_weight_splits(d->N, d->Cin, d->Cout, d->K, g->Ho, g->Wo);
     g->out_elems = (size_t)d->N * d->Cout * g->HoWo;
     return MEDT_OK;
 }
@@ -319,7 +319,8 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     }
     if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, s))) return rc;
     if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
-    return conv2d_bwd_weight(grad_out, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s);
+    return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
+                             d->pad, 1, s);
 }
 
 int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream) {

@@ -45,9 +45,11 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
                int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int K,
                     int stride, int pad, hipStream_t s);
-int conv2d_bwd_weight_splits(int N, int Ho, int Wo);
-int conv2d_bwd_weight(const float* dy, const float* x, float* dw, float* scratch, int N, int Cin, int H, int W, int Cout,
-                      int K, int stride, int pad, hipStream_t s);
+// dw[o,c,kh,kw] = sum_{n,ho,wo} val * x[...], val = coef ? c0*dy + c1*raw + c2 : dy (coef [group][Cout][3]);
+// scratch: conv2d_bwd_weight_splits() * Cout*Cin*K*K floats
+int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo);
+int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
+                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s);
 int channel_sum(const float* x, float* out, int N, int C, int HW, hipStream_t s);
 
 // ---- elementwise.hip -----------------------------------------------------------

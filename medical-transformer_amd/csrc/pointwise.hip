@@ -79,6 +79,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_kernel(
     float acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+#pragma unroll 4
     for (int o = 0; o < Cout; ++o) {
         float v = ok ? dy[base + (size_t)o * HW] : 0.f;
         if (cf) {
@@ -99,15 +100,20 @@ int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const
                      int Cout, int HW, int groups, hipStream_t s) {
     const int npg = N / groups;
     const unsigned gx = (unsigned)(((long)N * HW + MEDT_THREADS - 1) / MEDT_THREADS);
-    if (Cin % 16 == 0)
-        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<16>, dim3(gx, Cin / 16), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w,
-                           dx, N, Cin, Cout, HW, npg);
-    else if (Cin % 8 == 0)
-        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<8>, dim3(gx, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx,
-                           N, Cin, Cout, HW, npg);
-    else
-        hipLaunchKernelGGL(conv1x1_bwd_data_kernel<1>, dim3(gx, Cin), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx, N,
-                           Cin, Cout, HW, npg);
+    int CT = 16;                                   // fewer channels per lane when the grid would not fill the chip
+    while (CT > 1 && (Cin % CT != 0 || (long)gx * (Cin / CT) < 512)) CT >>= 1;
+    while (Cin % CT != 0) CT >>= 1;
+#define MEDT_LAUNCH_1X1(T)                                                                                       \
+    hipLaunchKernelGGL(conv1x1_bwd_data_kernel<T>, dim3(gx, Cin / T), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w, dx, N, \
+                       Cin, Cout, HW, npg)
+    switch (CT) {
+        case 16: MEDT_LAUNCH_1X1(16); break;
+        case 8: MEDT_LAUNCH_1X1(8); break;
+        case 4: MEDT_LAUNCH_1X1(4); break;
+        case 2: MEDT_LAUNCH_1X1(2); break;
+        default: MEDT_LAUNCH_1X1(1); break;
+    }
+#undef MEDT_LAUNCH_1X1
     return launch_status("conv1x1_bwd_data");
 }
 
