@@ -18,8 +18,19 @@ import torch
 from ._lib import MedtError
 from . import ops
 
+import os
+
 PATCH = 32          # hard-coded in the reference (:664)
 GRID = 4
+TWO_STREAMS = os.environ.get("MEDT_TWO_STREAMS", "1") != "0"
+_side = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
 
 
 def _require_device(x):
@@ -84,15 +95,29 @@ def medt_forward(net, x):
     xin = x.contiguous()
     if xin.shape[2] < PATCH * GRID or xin.shape[3] < PATCH * GRID or xin.shape[2] != xin.shape[3]:
         raise RuntimeError(f"medt_net needs square images of at least {PATCH * GRID} px (4x4 grid of 32-px patches)")
+    # The global and the local (patch) branch only meet at the merge: run them on two HIP streams so the
+    # latency-bound small kernels of one overlap the other's (both forks are captured into the step's hipGraph;
+    # autograd replays the backward of each branch on the stream its forward ran on).
+    main = torch.cuda.current_stream()
+    side = _side_stream(xin.device) if TWO_STREAMS else None
+    if side is not None:
+        side.wait_stream(main)
     g = _stem(net, xin)
     x1 = _layer(net.layer1, g)
     x2 = _layer(net.layer2, x1)
     y = ops.up2x_relu_add(ops.conv_block(x2, net.decoder4), x1)
     y = ops.up2x_relu_add(ops.conv_block(y, net.decoder5), None)
     # local branch: all 16 patches at once, patch-major on the batch dim, 16 BatchNorm groups when training
-    xp = ops.patch_gather(xin, PATCH, GRID)
     groups = GRID * GRID if net.training else 1
-    yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
+    if side is not None:
+        with torch.cuda.stream(side):
+            xp = ops.patch_gather(xin, PATCH, GRID)
+            yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
+        main.wait_stream(side)
+        yp.record_stream(main)
+    else:
+        xp = ops.patch_gather(xin, PATCH, GRID)
+        yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
     y = ops.logo_merge(y, yp, PATCH, GRID)
     y = ops.conv_block(y, net.decoderf, relu=True)
     return ops.conv_block(y, net.adjust)
