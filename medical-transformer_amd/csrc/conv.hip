@@ -35,7 +35,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
 #pragma unroll
     for (int o = 0; o < OT; ++o) acc[o] = bias ? bias[o0 + o] : 0.f;
     const float* xn = x + (size_t)n * Cin * H * W;
-#pragma unroll(K == 1 ? 4 : 1)
+#pragma unroll K == 1 ? 4 : 1
     for (int c = 0; c < Cin; ++c) {
         float xv[KK];
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
     const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
-#pragma unroll(K == 1 ? 4 : 1)
+#pragma unroll K == 1 ? 4 : 1
     for (int o = 0; o < Cout; ++o) {
         float dv[KK];
 #pragma unroll

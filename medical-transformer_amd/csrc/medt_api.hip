@@ -64,6 +64,18 @@ struct BwdWs {
     }
 };
 
+// Make `to` wait for everything enqueued on `from` so far (event fork; capturable into a hipGraph).
+static int fork_stream(hipStream_t from, hipStream_t to) {
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, from) != hipSuccess ||
+        hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+        set_error("fork_stream: %s", hipGetErrorString(hipGetLastError()));
+        return MEDT_ELAUNCH;
+    }
+    (void)hipEventDestroy(ev);
+    return MEDT_OK;
+}
+
 static int check_common(const medt_axial_desc* d, const medt_axial_params* p, const medt_axial_saved* sv, AxialGeom* g) {
     if (!d || !p || !sv) { set_error("null descriptor / params / saved"); return MEDT_EINVAL; }
     int rc = axial_geom(*d, g);
@@ -163,7 +175,7 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
 
 int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, const float* y,
                          const float* dy, const medt_axial_saved* sv, float* dx, const medt_axial_grads* gr, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         size_t ws_bytes, void* stream, void* aux_stream) {
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
@@ -201,13 +213,18 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // bn_qkv backward, qkv_transform backward
     if ((rc = bn_bwd_finalize(w.part_qb, g.tpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
+    hipStream_t sa = s;                       // parameter-gradient tail: off the critical path when aux_stream is given
+    if (aux_stream && (hipStream_t)aux_stream != s) {
+        sa = (hipStream_t)aux_stream;
+        if ((rc = fork_stream(s, sa))) return rc;
+    }
     if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;
     if ((rc = conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
-                                1, 0, g.groups, s))) return rc;
+                                1, 0, g.groups, sa))) return rc;
     if (g.pos) {
-        if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
-        if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, s))) return rc;
+        if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, sa))) return rc;
+        if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, sa))) return rc;
     }
     return MEDT_OK;
 }
@@ -291,7 +308,8 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
 
 int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w, const medt_bn_ptrs* bn, const float* z,
                         const float* y, const float* stats, const float* dy, float* dx, float* dw, float* dbias,
-                        float* dbn_weight, float* dbn_bias, float* dres, void* ws, size_t ws_bytes, void* stream) {
+                        float* dbn_weight, float* dbn_bias, float* dres, void* ws, size_t ws_bytes, void* stream,
+                        void* aux_stream) {
     ConvGeom g;
     int rc = conv_geom(d, &g);
     if (rc) return rc;
@@ -317,10 +335,15 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     } else {
         grad_out = dy;
     }
-    if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, s))) return rc;
+    hipStream_t sa = s;
+    if (aux_stream && (hipStream_t)aux_stream != s && dx) {       // nothing to overlap with when dx is not needed
+        sa = (hipStream_t)aux_stream;
+        if ((rc = fork_stream(s, sa))) return rc;
+    }
     if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
+    if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, sa))) return rc;
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
-                             d->pad, 1, s);
+                             d->pad, 1, sa);
 }
 
 int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream) {
