@@ -100,9 +100,16 @@ static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float
     return launch_status("conv2d_fwd");
 }
 
+int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride) {
+    return conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo) ? conv_mfma_parts_per_group(N, groups, HoWo)
+                                               : conv2d_parts_per_group(N, groups, HoWo);
+}
+
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
                int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    if (conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo))
+        return conv_mfma_fwd(x, w, bias, y, partials, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
     switch (K) {
         case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
         case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
@@ -181,9 +188,12 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
     return launch_status("conv2d_bwd_data");
 }
 
-int conv2d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int K,
-                    int stride, int pad, hipStream_t s) {
+int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int Cin, int H, int W, int Cout,
+                    int K, int stride, int pad, hipStream_t s) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K
+    if (wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W))
+        return conv_mfma_bwd_data_s1(dy, w, wt_scratch, dx, N, Cin, H, W, Cout, K, pad, s);
     switch (K) {
         case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
         case 3: return conv2d_bwd_data_k<3>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
@@ -295,6 +305,18 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     const int Ktot = Cin * K * K, QS = wgrad_chunk(Cout, Ktot, NP);
     const int splits = (int)((NP + QS - 1) / QS);
     const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
+    if (conv_use_mfma(Cin, Cout, K, stride, NP) && Cout >= 64) {
+        int rc = conv_wgrad_mfma(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits,
+                                 N / groups, s);
+        if (rc) return rc;
+        if (splits == 1) {
+            if (hipMemcpyAsync(dw, scratch, (size_t)Cout * Ktot * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                set_error("conv_wgrad: copy failed"); return MEDT_ELAUNCH;
+            }
+            return MEDT_OK;
+        }
+        return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
+    }
     switch (K) {
         case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
         case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;

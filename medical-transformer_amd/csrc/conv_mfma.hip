@@ -1,0 +1,235 @@
+// conv_mfma.hip -- fp32 matrix-core (MFMA) implicit-GEMM convolutions for the channel-heavy layers:
+// MedT's local stem (64 <-> 128 channels, 3x3: 53 % of the model's FLOPs), the 3x3 decoders and the
+// wide 1x1 convolutions.  gfx950 has no TF32: v_mfma_f32_16x16x4_f32 is an exact-fp32 FMA chain at the vector
+// peak rate, so parity with the VALU path is rounding-order only.
+//
+//   forward        Y[o, q]  = sum_k W[o, k] * Xcol[k, q]        k = (c,kh,kw),  q = (n,ho,wo)
+//   backward-data  (stride 1) = forward of dY with the weights transposed and tap-flipped (flip_weights_kernel)
+//   weight grad    dW[o, k] = sum_q dY[o, q] * Xcol[k, q]       (same tiles, reduction over q)
+//
+// Workgroup = 4 waves = one 64(o) x 64(q) tile; wave w owns rows 16w..16w+15 and four 16x16 accumulators.
+// Operands go through LDS in 16-deep K slices: A[64][16] straight from the (contiguous) weight rows,
+// B[16][64] gathered from NCHW with the column's (n,ho,wo) decoded once per lane.
+// MFMA fragment maps (cdna_hip_programming.md section 3): A: lane l = A[l&15][l>>4]; B: lane l = B[l>>4][l&15];
+// D: reg r of lane l = D[(l>>4)*4 + r][l&15].
+#include "medt_kernels.h"
+
+namespace medt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Measured on MI355X (profiles/, round 1): the MFMA tile kernel beats the VALU direct kernel only for the 3x3
+// layers with a deep contraction AND enough 64x64 tiles to occupy the chip -- conv2_p 64->128 (55 vs 76 us),
+// conv3_p 128->64 (108 vs 137 us) and their backward twins; on the 2x2/4x4 maps of the deep LoGo layers
+// (<= 16 tiles) it is 2-4x slower, and for 1x1 convolutions it ties.  Hence:
+bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions) {
+    static const bool off = [] { const char* e = getenv("MEDT_DISABLE_MFMA"); return e && e[0] == '1'; }();
+    const long tiles = ((positions + 63) / 64) * ((Cout + 63) / 64);
+    return !off && K == 3 && Cout >= 32 && Cin * K * K >= 256 && (stride == 1 || stride == 2) && tiles >= 128;
+}
+
+int conv_mfma_parts_per_group(int N, int groups, int HoWo) { return cdiv((N / groups) * HoWo, 64); }
+
+template <int K>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
+    int npg) {
+    constexpr int KK = K * K;
+    __shared__ float As[64][17];
+    __shared__ float Bs[16][65];
+    const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + 63) / 64, Ktot = Cin * KK;
+    const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // B staging: this lane always fills column j = lane; decode its output position once
+    const int qj = part * 64 + lane;
+    const bool jok = qj < per_group;
+    const int nj = grp * npg + (jok ? qj / HoWo : 0), pj = jok ? qj % HoWo : 0;
+    const int hbj = (pj / Wo) * stride - pad, wbj = (pj % Wo) * stride - pad;
+    const float* xj = x + (size_t)nj * Cin * H * W;
+    // A staging: element (row ar + 16*pass, column ak)
+    const int ak = threadIdx.x & 15, ar = threadIdx.x >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
+    for (int k0 = 0; k0 < Ktot; k0 += 16) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ar + 16 * ps, o = o0 + r, k = k0 + ak;
+            As[r][ak] = (o < Cout && k < Ktot) ? w[(size_t)o * Ktot + k] : 0.f;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int kk = wv + 4 * ps, k = k0 + kk;
+            float v = 0.f;
+            if (jok && k < Ktot) {
+                const int c = k / KK, t = k - c * KK;
+                const int h = hbj + t / K, ww = wbj + t % K;
+                if (h >= 0 && h < H && ww >= 0 && ww < W) v = xj[((size_t)c * H + h) * W + ww];
+            }
+            Bs[kk][lane] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float a = As[16 * wv + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b = Bs[ks * 4 + (lane >> 4)][t * 16 + (lane & 15)];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: D[(lane>>4)*4 + r][lane&15] of tile t  ->  o = o0 + 16*wv + (lane>>4)*4 + r,  q = part*64 + t*16 + (lane&15)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = part * 64 + t * 16 + (lane & 15);
+        const bool ok = q < per_group;
+        const int n = grp * npg + (ok ? q / HoWo : 0), p = ok ? q % HoWo : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+            if (ok && o < Cout) {
+                float v = acc[t][r] + (bias ? bias[o] : 0.f);
+                s1[r] += v;
+                s2[r] = fmaf(v, v, s2[r]);
+                y[((size_t)n * Cout + o) * HoWo + p] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+    if (partials) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
+            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+            if ((lane & 15) == 0 && o < Cout) {
+                float* dst = partials + ((size_t)blockIdx.x * Cout + o) * 2;
+                dst[0] = a;
+                dst[1] = b;
+            }
+        }
+    }
+}
+
+int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
+                  int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    const dim3 grid(groups * conv_mfma_parts_per_group(N, groups, Ho * Wo), cdiv(Cout, 64)), block(MEDT_THREADS);
+    if (K == 1)
+        hipLaunchKernelGGL(conv_mfma_fwd_kernel<1>, grid, block, 0, s, x, w, bias, y, partials, Cin, H, W, Cout, Ho, Wo,
+                           stride, pad, relu, N / groups);
+    else
+        hipLaunchKernelGGL(conv_mfma_fwd_kernel<3>, grid, block, 0, s, x, w, bias, y, partials, Cin, H, W, Cout, Ho, Wo,
+                           stride, pad, relu, N / groups);
+    return launch_status("conv_mfma_fwd");
+}
+
+// wt[c][o][K*K-1-t] = w[o][c][t]: backward-data of a stride-1 convolution is the forward convolution of dY with wt
+// and padding K-1-pad.
+__global__ __launch_bounds__(MEDT_THREADS) void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                    int Cout, int Cin, int KK) {
+    const int idx = blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= Cout * Cin * KK) return;
+    const int t = idx % KK, c = (idx / KK) % Cin, o = idx / (KK * Cin);
+    wt[((size_t)c * Cout + o) * KK + (KK - 1 - t)] = w[idx];
+}
+
+int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* dx, int N, int Cin, int H, int W,
+                          int Cout, int K, int pad, hipStream_t s) {
+    const int total = Cout * Cin * K * K;
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(cdiv(total, MEDT_THREADS)), dim3(MEDT_THREADS), 0, s, w, wt_scratch,
+                       Cout, Cin, K * K);
+    int rc = launch_status("flip_weights");
+    if (rc) return rc;
+    // dy (N,Cout,Ho,Wo) with Ho = H + 2*pad - K + 1  ->  dx (N,Cin,H,W): forward conv, pad' = K-1-pad
+    const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
+    return conv_mfma_fwd(dy, wt_scratch, nullptr, dx, nullptr, N, Cout, Ho, Wo, Cin, K, 1, K - 1 - pad, 0, 1, s);
+}
+
+// --------------------------------------------------------------------------- //
+// weight gradient on the matrix cores (same tiling as conv_wgrad_kernel in conv.hip)
+// --------------------------------------------------------------------------- //
+template <int K>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+    int stride, int pad, int QS, int npg) {
+    constexpr int KK = K * K;
+    __shared__ float A[64][65];
+    __shared__ float B[64][65];
+    const int Ktot = Cin * KK, HoWo = Ho * Wo;
+    const int o0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const long NP = (long)N * HoWo;
+    const long q_begin = (long)blockIdx.z * QS;
+    const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane, r0 = wv;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
+    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+        const long q = q0 + j;
+        const bool qok = q < q_end;
+        const int n = qok ? (int)(q / HoWo) : 0, p = qok ? (int)(q - (long)n * HoWo) : 0;
+        const int ho = p / Wo, wo = p - ho * Wo;
+        const int hb = ho * stride - pad, wb = wo * stride - pad;
+        const float* dyp = dy + (size_t)n * Cout * HoWo + p;
+        const float* rawp = raw ? raw + (size_t)n * Cout * HoWo + p : nullptr;
+        const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
+        const float* xp = x + (size_t)n * Cin * H * W;
+#pragma unroll 4
+        for (int r = r0; r < 64; r += 4) {
+            float a = 0.f, b = 0.f;
+            const int o = o0 + r, k = k0 + r;
+            if (qok && o < Cout) {
+                a = dyp[(size_t)o * HoWo];
+                if (cf) a = fmaf(cf[o * 3], a, fmaf(cf[o * 3 + 1], rawp[(size_t)o * HoWo], cf[o * 3 + 2]));
+            }
+            if (qok && k < Ktot) {
+                const int c = k / KK, t = k - c * KK;
+                const int h = hb + t / K, w = wb + t % K;
+                if (h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + h) * W + w];
+            }
+            A[r][j] = a;
+            B[r][j] = b;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const float a = A[16 * wv + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b = B[t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r, k = k0 + t * 16 + (lane & 15);
+            if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[t][r];
+        }
+}
+
+int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const float* x, float* scratch, int N, int Cin,
+                    int H, int W, int Cout, int Ho, int Wo, int K, int stride, int pad, int QS, int splits, int npg,
+                    hipStream_t s) {
+    const dim3 grid(cdiv(Cout, 64), cdiv(Cin * K * K, 64), splits), block(MEDT_THREADS);
+    if (K == 1)
+        hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho,
+                           Wo, stride, pad, QS, npg);
+    else
+        hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho,
+                           Wo, stride, pad, QS, npg);
+    return launch_status("conv_wgrad_mfma");
+}
+
+}  // namespace medt

@@ -37,7 +37,7 @@ struct LayerStats {
 struct FwdWs {
     float *part_qkv, *part_sim, *part_out;
     FwdWs(Carver& c, const AxialGeom& g) {
-        part_qkv = c.take<float>((size_t)g.groups * conv2d_parts_per_group(g.N, g.groups, g.HW) * 2 * g.C * 2);
+        part_qkv = c.take<float>((size_t)g.groups * conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1) * 2 * g.C * 2);
         part_sim = c.take<float>((size_t)g.groups * g.tpg * g.SC * 2);
         part_out = c.take<float>((size_t)g.groups * g.tpg * g.OC * 2);
     }
@@ -154,7 +154,7 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
-    const int tr = d->training ? 1 : 0, ppg = conv2d_parts_per_group(g.N, g.groups, g.HW);
+    const int tr = d->training ? 1 : 0, ppg = conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1);
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
     if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, sv->qkv_raw, tr ? w.part_qkv : nullptr, g.N, g.C, g.H, g.W, 2 * g.C, 1, 1, 0,
                          0, g.groups, s))) return rc;
@@ -236,7 +236,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
 }  // extern "C"  (helpers below are C++)
 
 namespace medt {
-struct ConvGeom { int Ho, Wo, HoWo, ppg, splits; size_t out_elems; };
+struct ConvGeom { int Ho, Wo, HoWo, ppg, ppg_bwd, splits; size_t out_elems; };   // ppg: forward kernel's partial slots per BN group
 static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->stride < 1 || d->pad < 0) {
         set_error("conv: bad descriptor"); return MEDT_EINVAL;
@@ -249,15 +249,17 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     g->Wo = (d->W + 2 * d->pad - d->K) / d->stride + 1;
     if (g->Ho <= 0 || g->Wo <= 0) { set_error("conv: empty output"); return MEDT_EINVAL; }
     g->HoWo = g->Ho * g->Wo;
-    g->ppg = conv2d_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo);
+    g->ppg = conv_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo, d->Cin, d->Cout, d->K, d->stride);
+    g->ppg_bwd = conv2d_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo);       // bn_act_bwd_stats: 256 positions / part
     g->splits = conv2d_bwd_weight_splits(d->N, d->Cin, d->Cout, d->K, g->Ho, g->Wo);
     g->out_elems = (size_t)d->N * d->Cout * g->HoWo;
     return MEDT_OK;
 }
 struct ConvWs {
-    float *partials, *coef, *gbuf, *dz, *dw_scratch;
+    float *partials, *coef, *gbuf, *dz, *dw_scratch, *wt;
     ConvWs(Carver& c, const medt_conv_desc* d, const ConvGeom& g) {
-        partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * g.ppg * d->Cout * 2 : 0);
+        wt = c.take<float>((size_t)d->Cout * d->Cin * d->K * d->K);
+        partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * (g.ppg > g.ppg_bwd ? g.ppg : g.ppg_bwd) * d->Cout * 2 : 0);
         coef = c.take<float>(d->has_bn ? (size_t)d->bn_groups * d->Cout * 3 : 0);
         gbuf = c.take<float>(g.out_elems);
         dz = c.take<float>(d->has_bn ? g.out_elems : 0);
@@ -324,7 +326,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
         float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
         if ((rc = bn_act_bwd_stats(dy, y, z, st, gb, cw.partials, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s))) return rc;
-        if ((rc = bn_bwd_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout,
+        if ((rc = bn_bwd_finalize(cw.partials, g.ppg_bwd, d->bn_groups, d->Cout,
                                   (double)(d->N / d->bn_groups) * g.HoWo, 1.f, st, bn->weight, d->training ? 1 : 0, cw.coef,
                                   dbn_weight, dbn_bias, s))) return rc;
         if ((rc = bn_bwd_apply(gb, z, cw.coef, cw.dz, d->N, d->Cout, g.HoWo, d->bn_groups, s))) return rc;
@@ -340,7 +342,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         sa = (hipStream_t)aux_stream;
         if ((rc = fork_stream(s, sa))) return rc;
     }
-    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
+    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
     if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, sa))) return rc;
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
                              d->pad, 1, sa);

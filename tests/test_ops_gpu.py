@@ -48,6 +48,11 @@ CONV_CASES = [
     (16, 2, 1, 1, 0, True, False, False, False, 2, 16, 1),      # adjust
     (256, 256, 3, 2, 1, True, False, False, False, 8, 2, 1),    # decoder1_p on 2x2 maps
     (20, 24, 3, 1, 1, False, True, False, True, 3, 9, 1),       # odd sizes
+    # shapes that take the fp32-MFMA implicit-GEMM path (3x3, Cin*9 >= 256, >= 128 output tiles)
+    (64, 128, 3, 1, 1, False, True, False, True, 32, 16, 4),    # conv2_p with grouped BN
+    (128, 64, 3, 1, 1, True, False, False, True, 32, 16, 1),    # conv3_p-shaped, bias + relu, no BN
+    (32, 64, 3, 2, 1, True, False, False, False, 16, 64, 1),    # stride 2 (forward + weight gradient on MFMA)
+    (40, 72, 3, 1, 1, False, True, True, True, 36, 15, 2),      # ragged tiles: Cout % 64 != 0, positions % 64 != 0
 ]
 
 
