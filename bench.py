@@ -180,7 +180,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("MEDT_FORCE_DIST") == "1" and "RANK" in os.environ    # exercise the RCCL path on 1 GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
@@ -257,7 +258,7 @@ def main():
             result["vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -21,7 +21,7 @@ def is_distributed() -> bool:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """Make every replica start from rank `src`'s parameters and buffers (one flat broadcast per dtype)."""
-    if not is_distributed():
+    if not (dist.is_available() and dist.is_initialized()):
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     by_dtype = {}

@@ -21,6 +21,12 @@ def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def _distributed():
+    """True when the step must leave the all-reduce (and Adam) outside the captured graph."""
+    from .optim import FORCE_COLLECTIVES
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 class TrainStep:
     def __init__(self, model, optimizer: FlatAdam, criterion=None, use_graph: bool = True, warmup: int = 3):
         self.model, self.opt = model, optimizer
@@ -56,7 +62,7 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self.opt.zero_grad()
         graph = torch.cuda.CUDAGraph()
-        single = _world() == 1
+        single = not _distributed()
         with torch.cuda.graph(graph):
             out = self.model(static_x)
             loss = self.criterion(out, static_y)

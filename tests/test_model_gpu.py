@@ -142,3 +142,29 @@ def test_graphed_train_step_equals_eager(device):
     for a, b in zip(l0[1:], l1[:3]):
         assert abs(a - b) < 5e-3 * abs(a), (l0, l1)
     assert int(s1["bn1.num_batches_tracked"].item()) == int(s0["bn1.num_batches_tracked"].item()) + 1
+
+
+def test_medt_256_train_vs_oracle(device):
+    """BASELINE.json config 5 geometry (MedT, 256 px: L = 128 attention, patches only cover the top-left 128x128,
+    SURVEY.md Q1), training mode, against the live oracle.  Logits at the reference's own fp32 noise level."""
+    name, S, N = "MedT", 256, 2
+    model = build(name, S, device)
+    st = H.seeded_state(name, S, 41)
+    model.load_state_dict(st)
+    model.train()
+    x, y = H.seeded_input(42, N, 3, S)
+    out = model(x.to(device))
+    loss = torch.nn.functional.cross_entropy(out, y.to(device))
+    loss.backward()
+    torch.cuda.synchronize()
+    ost = O.clone_state(st, torch.float64)
+    oout = O.forward(name, x.double(), ost, True)
+    assert H.rel_err(out, oout) < 3e-3
+    assert abs(loss.item() - O.log_nll_loss(oout, y).item()) < 1e-3
+    sd = model.state_dict()
+    for k in ("bn1.running_mean", "layer1.0.hight_block.bn_similarity.running_var", "layer4_p.0.bn2.running_mean",
+              "layer2_p.1.width_block.bn_output.running_var"):
+        assert H.rel_err(sd[k], ost[k]) < 5e-3, k
+    assert int(sd["layer1_p.0.bn1.num_batches_tracked"].item()) == 16
+    for p in model.parameters():
+        assert p.grad is None or torch.isfinite(p.grad).all()
