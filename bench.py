@@ -113,7 +113,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
 # --------------------------------------------------------------------------- #
 # CPU baseline leg: the oracle (a port of the reference's algorithm) on the host cores
 # --------------------------------------------------------------------------- #
-def cpu_baseline_leg(steps=3):
+def cpu_baseline_leg(steps=8):
     from oracle import medt_oracle as O
     import lib as droplib
     O.set_fast_bn(True)                                  # aten's fused BatchNorm, like the reference's nn.BatchNorm
