@@ -101,15 +101,28 @@ static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float
 }
 
 int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride) {
-    return conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo) ? conv_mfma_parts_per_group(N, groups, HoWo)
-                                               : conv2d_parts_per_group(N, groups, HoWo);
+    if (!conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo)) return conv2d_parts_per_group(N, groups, HoWo);
+    if (conv_mfma_scratch_floats(N, groups, HoWo, Cin, Cout, K) > 0) return conv2d_parts_per_group(N, groups, HoWo);
+    return conv_mfma_parts_per_group(N, groups, HoWo);
 }
 
-int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
-               int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
+size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    if (conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo))
-        return conv_mfma_fwd(x, w, bias, y, partials, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
+    if (!conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo)) return 0;
+    return conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K);
+}
+
+size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    if (stride != 1 || K - 1 - pad < 0 || !conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W)) return 0;
+    return conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K);
+}
+
+int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
+               int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    if (conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
+        (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
+        return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
     switch (K) {
         case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
         case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
@@ -188,12 +201,13 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
     return launch_status("conv2d_bwd_data");
 }
 
-int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int Cin, int H, int W, int Cout,
-                    int K, int stride, int pad, hipStream_t s) {
+int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
+                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K
-    if (wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W))
-        return conv_mfma_bwd_data_s1(dy, w, wt_scratch, dx, N, Cin, H, W, Cout, K, pad, s);
+    if (wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) &&
+        (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K) == 0))
+        return conv_mfma_bwd_data_s1(dy, w, wt_scratch, ksplit_scratch, dx, N, Cin, H, W, Cout, K, pad, s);
     switch (K) {
         case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
         case 3: return conv2d_bwd_data_k<3>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);

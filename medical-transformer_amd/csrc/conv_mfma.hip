@@ -25,7 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions) {
     static const bool off = [] { const char* e = getenv("MEDT_DISABLE_MFMA"); return e && e[0] == '1'; }();
     const long tiles = ((positions + 63) / 64) * ((Cout + 63) / 64);
-    return !off && K == 3 && Cout >= 32 && Cin * K * K >= 256 && (stride == 1 || stride == 2) && tiles >= 128;
+    if (off || Cout < 32 || Cin * K * K < 256 || (stride != 1 && stride != 2)) return false;
+    if (K == 3 && tiles >= 128) return true;
+    // few tiles (2x2 / 4x4 maps of the deep LoGo layers, <= 1024 positions): split-K over workgroups + epilogue
+    return (K == 3 || K == 1) && tiles < 128 && positions <= 2048 && Cin * K * K >= 512;
 }
 
 int conv_mfma_parts_per_group(int N, int groups, int HoWo) { return cdiv((N / groups) * HoWo, 64); }
@@ -34,7 +37,7 @@ template <int K>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
-    int npg) {
+    int npg, int kchunk, float* __restrict__ ksplit_out) {
     constexpr int KK = K * K;
     __shared__ float As[64][17];
     __shared__ float Bs[16][65];
@@ -52,17 +55,20 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
-    for (int k0 = 0; k0 < Ktot; k0 += 16) {
+    // split-K: slice blockIdx.z owns k in [kbeg, kend) and writes its raw partial tile to ksplit_out (the few-tile
+    // layers on 2x2 / 4x4 maps would otherwise run on a handful of CUs); conv_splitk_epilogue sums the slices.
+    const int kbeg = blockIdx.z * kchunk, kend = min(Ktot, kbeg + kchunk);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int r = ar + 16 * ps, o = o0 + r, k = k0 + ak;
-            As[r][ak] = (o < Cout && k < Ktot) ? w[(size_t)o * Ktot + k] : 0.f;
+            As[r][ak] = (o < Cout && k < kend) ? w[(size_t)o * Ktot + k] : 0.f;
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int kk = wv + 4 * ps, k = k0 + kk;
             float v = 0.f;
-            if (jok && k < Ktot) {
+            if (jok && k < kend) {
                 const int c = k / KK, t = k - c * KK;
                 const int h = hbj + t / K, ww = wbj + t % K;
                 if (h >= 0 && h < H && ww >= 0 && ww < W) v = xj[((size_t)c * H + h) * W + ww];
@@ -82,6 +88,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
         __syncthreads();
     }
     // epilogue: D[(lane>>4)*4 + r][lane&15] of tile t  ->  o = o0 + 16*wv + (lane>>4)*4 + r,  q = part*64 + t*16 + (lane&15)
+    if (ksplit_out) {
+        float* dst = ksplit_out + (size_t)blockIdx.z * gridDim.x * 64 * Cout;       // [slice][global position][Cout]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t qg = (size_t)blockIdx.x * 64 + t * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+                if (o < Cout) dst[qg * Cout + o] = acc[t][r];
+            }
+        }
+        return;
+    }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -115,17 +134,68 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     }
 }
 
-int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
-                  int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
+// y[n,o,p] = bias[o] + sum over K slices; optional ReLU and BatchNorm partials ([group][256-position part][Cout][2]).
+// grid (groups*ppg256, Cout): lanes over the positions of one group, one channel per blockIdx.y.
+__global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
+    const float* __restrict__ slices, int nslices, size_t slice_stride, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ partials, int Cout, int HoWo, int npg, int ppg64, int relu) {
+    __shared__ float red[MEDT_WAVES * 2];
+    const int per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
+    const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o = blockIdx.y;
+    const int q = part * MEDT_THREADS + threadIdx.x;
+    float v[2] = {0.f, 0.f};
+    if (q < per_group) {
+        const size_t qg = (size_t)grp * ppg64 * 64 + q;          // position index used by the tile kernel
+        float a = bias ? bias[o] : 0.f;
+        for (int s = 0; s < nslices; ++s) a += slices[s * slice_stride + qg * Cout + o];
+        const int n = grp * npg + q / HoWo, p = q % HoWo;
+        y[((size_t)n * Cout + o) * HoWo + p] = relu ? fmaxf(a, 0.f) : a;
+        v[0] = a;
+        v[1] = a * a;
+    }
+    if (partials) block_sum<2>(v, red, partials + ((size_t)blockIdx.x * Cout + o) * 2);
+}
+
+// number of K slices for a problem with `tiles` output tiles (1 = no split)
+int conv_mfma_ksplit(int Ktot, long tiles) {
+    if (tiles >= 128) return 1;
+    int ks = (int)(256 / tiles);
+    const int maxks = Ktot / 64 > 0 ? Ktot / 64 : 1;          // at least 64 k (4 LDS steps) per slice
+    if (ks > maxks) ks = maxks;
+    return ks < 1 ? 1 : ks;
+}
+
+size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, int K) {
+    const long qt = (long)groups * conv_mfma_parts_per_group(N, groups, HoWo);
+    const int ks = conv_mfma_ksplit(Cin * K * K, qt * cdiv(Cout, 64));
+    return ks > 1 ? (size_t)ks * qt * 64 * Cout : 0;
+}
+
+int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
+                  int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    const dim3 grid(groups * conv_mfma_parts_per_group(N, groups, Ho * Wo), cdiv(Cout, 64)), block(MEDT_THREADS);
+    const int ppg64 = conv_mfma_parts_per_group(N, groups, Ho * Wo), Ktot = Cin * K * K;
+    const long qt = (long)groups * ppg64;
+    int ks = scratch ? conv_mfma_ksplit(Ktot, qt * cdiv(Cout, 64)) : 1;
+    int kchunk = Ktot;
+    if (ks > 1) {
+        kchunk = cdiv(cdiv(Ktot, ks), 16) * 16;
+        ks = cdiv(Ktot, kchunk);
+    }
+    const dim3 grid((unsigned)qt, cdiv(Cout, 64), ks), block(MEDT_THREADS);
+    float* kout = ks > 1 ? scratch : nullptr;
     if (K == 1)
         hipLaunchKernelGGL(conv_mfma_fwd_kernel<1>, grid, block, 0, s, x, w, bias, y, partials, Cin, H, W, Cout, Ho, Wo,
-                           stride, pad, relu, N / groups);
+                           stride, pad, relu, N / groups, kchunk, kout);
     else
         hipLaunchKernelGGL(conv_mfma_fwd_kernel<3>, grid, block, 0, s, x, w, bias, y, partials, Cin, H, W, Cout, Ho, Wo,
-                           stride, pad, relu, N / groups);
-    return launch_status("conv_mfma_fwd");
+                           stride, pad, relu, N / groups, kchunk, kout);
+    int rc = launch_status("conv_mfma_fwd");
+    if (rc || ks == 1) return rc;
+    const int npg = N / groups, ppg = cdiv(npg * Ho * Wo, MEDT_THREADS);
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(groups * ppg, Cout), block, 0, s, scratch, ks,
+                       (size_t)qt * 64 * Cout, bias, y, partials, Cout, Ho * Wo, npg, ppg64, relu);
+    return launch_status("conv_splitk_epilogue");
 }
 
 // wt[c][o][K*K-1-t] = w[o][c][t]: backward-data of a stride-1 convolution is the forward convolution of dY with wt
@@ -138,8 +208,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void flip_weights_kernel(const float*
     wt[((size_t)c * Cout + o) * KK + (KK - 1 - t)] = w[idx];
 }
 
-int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* dx, int N, int Cin, int H, int W,
-                          int Cout, int K, int pad, hipStream_t s) {
+int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,
+                          int Cin, int H, int W, int Cout, int K, int pad, hipStream_t s) {
     const int total = Cout * Cin * K * K;
     hipLaunchKernelGGL(flip_weights_kernel, dim3(cdiv(total, MEDT_THREADS)), dim3(MEDT_THREADS), 0, s, w, wt_scratch,
                        Cout, Cin, K * K);
@@ -147,7 +217,8 @@ int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, fl
     if (rc) return rc;
     // dy (N,Cout,Ho,Wo) with Ho = H + 2*pad - K + 1  ->  dx (N,Cin,H,W): forward conv, pad' = K-1-pad
     const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
-    return conv_mfma_fwd(dy, wt_scratch, nullptr, dx, nullptr, N, Cout, Ho, Wo, Cin, K, 1, K - 1 - pad, 0, 1, s);
+    return conv_mfma_fwd(dy, wt_scratch, nullptr, dx, nullptr, ksplit_scratch, N, Cout, Ho, Wo, Cin, K, 1, K - 1 - pad, 0,
+                         1, s);
 }
 
 // --------------------------------------------------------------------------- //

@@ -35,8 +35,11 @@ struct LayerStats {
 };
 
 struct FwdWs {
-    float *part_qkv, *part_sim, *part_out;
+    float *part_qkv, *part_sim, *part_out, *qkv_ksplit;
     FwdWs(Carver& c, const AxialGeom& g) {
+        const size_t kq = conv2d_fwd_scratch_floats(g.N, g.groups, g.C, g.H, g.W, 2 * g.C, 1, 1, 0);
+        qkv_ksplit = c.take<float>(kq);
+        if (!kq) qkv_ksplit = nullptr;
         part_qkv = c.take<float>((size_t)g.groups * conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1) * 2 * g.C * 2);
         part_sim = c.take<float>((size_t)g.groups * g.tpg * g.SC * 2);
         part_out = c.take<float>((size_t)g.groups * g.tpg * g.OC * 2);
@@ -156,8 +159,8 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
     const int tr = d->training ? 1 : 0, ppg = conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1);
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
-    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, sv->qkv_raw, tr ? w.part_qkv : nullptr, g.N, g.C, g.H, g.W, 2 * g.C, 1, 1, 0,
-                         0, g.groups, s))) return rc;
+    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, sv->qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
+                         2 * g.C, 1, 1, 0, 0, g.groups, s))) return rc;
     if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
                           st.qkv, s))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
@@ -256,9 +259,16 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     return MEDT_OK;
 }
 struct ConvWs {
-    float *partials, *coef, *gbuf, *dz, *dw_scratch, *wt;
+    float *partials, *coef, *gbuf, *dz, *dw_scratch, *wt, *ksplit, *ksplit_fwd, *ksplit_bwd;
     ConvWs(Carver& c, const medt_conv_desc* d, const ConvGeom& g) {
         wt = c.take<float>((size_t)d->Cout * d->Cin * d->K * d->K);
+        const size_t kf = conv2d_fwd_scratch_floats(d->N, d->has_bn ? d->bn_groups : 1, d->Cin, d->H, d->W, d->Cout, d->K,
+                                                    d->stride, d->pad);
+        const size_t kb = conv2d_bwd_data_scratch_floats(d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad);
+        ksplit = c.take<float>(kf > kb ? kf : kb);
+        if (!(kf > 0 || kb > 0)) ksplit = nullptr;
+        ksplit_fwd = kf > 0 ? ksplit : nullptr;
+        ksplit_bwd = kb > 0 ? ksplit : nullptr;
         partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * (g.ppg > g.ppg_bwd ? g.ppg : g.ppg_bwd) * d->Cout * 2 : 0);
         coef = c.take<float>(d->has_bn ? (size_t)d->bn_groups * d->Cout * 3 : 0);
         gbuf = c.take<float>(g.out_elems);
@@ -292,17 +302,17 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
         set_error("conv fwd: null pointer"); return MEDT_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (!d->has_bn)
-        return conv2d_fwd(x, w, d->has_bias ? bias : nullptr, y, nullptr, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
-                          d->stride, d->pad, d->relu, 1, s);
     Carver c(ws, ws_bytes);
     ConvWs cw(c, d, g);
     if (!ws || !c.ok()) { set_error("conv workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    if (!d->has_bn)
+        return conv2d_fwd(x, w, d->has_bias ? bias : nullptr, y, nullptr, cw.ksplit_fwd, d->N, d->Cin, d->H, d->W, d->Cout,
+                          d->K, d->stride, d->pad, d->relu, 1, s);
     const int tr = d->training ? 1 : 0;
     if (!tr && (!bn->running_mean || !bn->running_var)) { set_error("conv fwd: eval mode needs running statistics"); return MEDT_EINVAL; }
     BnStats st(stats, d->bn_groups * d->Cout);
-    if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
-                         d->pad, 0, d->bn_groups, s))) return rc;
+    if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, cw.ksplit_fwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
+                         d->stride, d->pad, 0, d->bn_groups, s))) return rc;
     if ((rc = bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout,
                           (double)(d->N / d->bn_groups) * g.HoWo, *bn, d->momentum, d->eps, tr, st, s))) return rc;
     return bn_apply_act(z, st, d->has_res ? res : nullptr, y, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s);
@@ -342,7 +352,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         sa = (hipStream_t)aux_stream;
         if ((rc = fork_stream(s, sa))) return rc;
     }
-    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
+    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
     if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, sa))) return rc;
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
                              d->pad, 1, sa);

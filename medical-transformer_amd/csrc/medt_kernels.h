@@ -42,11 +42,13 @@ int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
 // partials (optional): [group][part][Cout][2], part = 256-position chunk of the group's npg*Ho*Wo positions
 int conv2d_parts_per_group(int N, int groups, int HoWo);       // VALU kernel (256 positions per part)
 int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride);   // whichever kernel runs
-int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
-               int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
+int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
+               int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
+size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // wt_scratch: Cout*Cin*K*K floats (used by the MFMA path for the flipped weights; may be NULL -> VALU path)
-int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, int N, int Cin, int H, int W, int Cout,
-                    int K, int stride, int pad, hipStream_t s);
+int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
+                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s);
+size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // dw[o,c,kh,kw] = sum_{n,ho,wo} val * x[...], val = coef ? c0*dy + c1*raw + c2 : dy (coef [group][Cout][3]);
 // scratch: conv2d_bwd_weight_splits() * Cout*Cin*K*K floats
 int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo);
@@ -57,10 +59,12 @@ int channel_sum(const float* x, float* out, int N, int C, int HW, hipStream_t s)
 // ---- conv_mfma.hip (fp32 matrix-core implicit GEMM; chosen by conv_use_mfma) -----------
 bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions);
 int conv_mfma_parts_per_group(int N, int groups, int HoWo);
-int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
-                  int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
-int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* dx, int N, int Cin, int H, int W,
-                          int Cout, int K, int pad, hipStream_t s);
+// scratch: conv_mfma_scratch_floats() floats when the split-K variant may run (NULL forbids it)
+size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, int K);
+int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
+                  int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
+int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,
+                          int Cin, int H, int W, int Cout, int K, int pad, hipStream_t s);
 int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const float* x, float* scratch, int N, int Cin,
                     int H, int W, int Cout, int Ho, int Wo, int K, int stride, int pad, int QS, int splits, int npg,
                     hipStream_t s);
