@@ -303,6 +303,7 @@ static int wgrad_chunk(int Cout, int Ktot, long NP) {
     const long tiles = (long)cdiv(Cout, 64) * cdiv(Ktot, 64);
     int QS = 512;
     while (QS > 64 && tiles * ((NP + QS - 1) / QS) < 512) QS >>= 1;
+    while ((NP + QS - 1) / QS > 64) QS <<= 1;            // at most 64 partial slabs for the deterministic reduction
     return QS;
 }
 
@@ -348,23 +349,27 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
 }
 
-// per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients)
-__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+// per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients); two stages, deterministic
+#define CS_SPLITS 16
+__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                                    int N, int C, int HW) {
     __shared__ float red[MEDT_WAVES];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sp = blockIdx.y;
     float v[1] = {0.f};
     const long total = (long)N * HW;
-    for (long q = threadIdx.x; q < total; q += MEDT_THREADS) {
+    const long per = (total + CS_SPLITS - 1) / CS_SPLITS, beg = sp * per, end = beg + per < total ? beg + per : total;
+    for (long q = beg + threadIdx.x; q < end; q += MEDT_THREADS) {
         const int n = (int)(q / HW), p = (int)(q - (long)n * HW);
         v[0] += x[((size_t)n * C + c) * HW + p];
     }
-    block_sum<1>(v, red, out + c);
+    block_sum<1>(v, red, part + (size_t)sp * C + c);
 }
 
-int channel_sum(const float* x, float* out, int N, int C, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(MEDT_THREADS), 0, s, x, out, N, C, HW);
-    return launch_status("channel_sum");
+int channel_sum(const float* x, float* out, float* scratch, int N, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, CS_SPLITS), dim3(MEDT_THREADS), 0, s, x, scratch, N, C, HW);
+    int rc = launch_status("channel_sum");
+    if (rc) return rc;
+    return reduce_rows(scratch, CS_SPLITS, C, out, s);
 }
 
 }  // namespace medt

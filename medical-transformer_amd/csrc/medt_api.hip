@@ -259,7 +259,7 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     return MEDT_OK;
 }
 struct ConvWs {
-    float *partials, *coef, *gbuf, *dz, *dw_scratch, *wt, *ksplit, *ksplit_fwd, *ksplit_bwd;
+    float *partials, *coef, *bias_scratch, *gbuf, *dz, *dw_scratch, *wt, *ksplit, *ksplit_fwd, *ksplit_bwd;
     ConvWs(Carver& c, const medt_conv_desc* d, const ConvGeom& g) {
         wt = c.take<float>((size_t)d->Cout * d->Cin * d->K * d->K);
         const size_t kf = conv2d_fwd_scratch_floats(d->N, d->has_bn ? d->bn_groups : 1, d->Cin, d->H, d->W, d->Cout, d->K,
@@ -271,6 +271,7 @@ struct ConvWs {
         ksplit_bwd = kb > 0 ? ksplit : nullptr;
         partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * (g.ppg > g.ppg_bwd ? g.ppg : g.ppg_bwd) * d->Cout * 2 : 0);
         coef = c.take<float>(d->has_bn ? (size_t)d->bn_groups * d->Cout * 3 : 0);
+        bias_scratch = c.take<float>((size_t)16 * d->Cout);
         gbuf = c.take<float>(g.out_elems);
         dz = c.take<float>(d->has_bn ? g.out_elems : 0);
         dw_scratch = c.take<float>((size_t)g.splits * d->Cout * d->Cin * d->K * d->K);
@@ -353,7 +354,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         if ((rc = fork_stream(s, sa))) return rc;
     }
     if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
-    if (d->has_bias && (rc = channel_sum(grad_out, dbias, d->N, d->Cout, g.HoWo, sa))) return rc;
+    if (d->has_bias && (rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, sa))) return rc;
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
                              d->pad, 1, sa);
 }

@@ -54,7 +54,7 @@ size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, in
 int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo);
 int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
                       int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s);
-int channel_sum(const float* x, float* out, int N, int C, int HW, hipStream_t s);
+int channel_sum(const float* x, float* out, float* scratch /* 16*C floats */, int N, int C, int HW, hipStream_t s);
 
 // ---- conv_mfma.hip (fp32 matrix-core implicit GEMM; chosen by conv_use_mfma) -----------
 bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions);

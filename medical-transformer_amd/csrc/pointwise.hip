@@ -96,10 +96,61 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_kernel(
     }
 }
 
+// Small-problem variant (deep LoGo layers: <= ~4k positions, 128-256 output channels): the o-contraction is
+// split over the workgroup's four waves (64 positions per workgroup) and combined through LDS, so the serial,
+// latency-bound chain per lane is 4x shorter.
+template <int CT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int Cout, int HW, int npg) {
+    __shared__ float red[3][CT][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long q = (long)blockIdx.x * 64 + lane;
+    const int  c0 = blockIdx.y * CT;
+    const bool ok = q < (long)N * HW;
+    const int  n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
+    const size_t base = (size_t)n * Cout * HW + p;
+    const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
+    const int ob = (Cout * wv) / 4, oe = (Cout * (wv + 1)) / 4;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+#pragma unroll 4
+    for (int o = ob; o < oe; ++o) {
+        float v = ok ? dy[base + (size_t)o * HW] : 0.f;
+        if (cf) {
+            const float r = ok ? raw[base + (size_t)o * HW] : 0.f;
+            v = fmaf(cf[o * 3 + 0], v, fmaf(cf[o * 3 + 1], r, cf[o * 3 + 2]));
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = fmaf(w[o * Cin + c0 + c], v, acc[c]);
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) red[wv - 1][c][lane] = acc[c];
+    }
+    __syncthreads();
+    if (wv == 0 && ok) {
+        float* dp = dx + ((size_t)n * Cin + c0) * HW + p;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) dp[(size_t)c * HW] = acc[c] + (red[0][c][lane] + red[1][c][lane]) + red[2][c][lane];
+    }
+}
+
 int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const float* w, float* dx, int N, int Cin,
                      int Cout, int HW, int groups, hipStream_t s) {
     const int npg = N / groups;
     const unsigned gx = (unsigned)(((long)N * HW + MEDT_THREADS - 1) / MEDT_THREADS);
+    if ((long)N * HW <= 4096 && Cout >= 64 && Cin % 8 == 0) {         // small, deep: wave-split contraction
+        const unsigned g64 = (unsigned)(((long)N * HW + 63) / 64);
+        if (Cin % 16 == 0 && g64 * (Cin / 16) >= 64)
+            hipLaunchKernelGGL(conv1x1_bwd_data_ws_kernel<16>, dim3(g64, Cin / 16), dim3(MEDT_THREADS), 0, s, dy, raw, coef,
+                               w, dx, N, Cin, Cout, HW, npg);
+        else
+            hipLaunchKernelGGL(conv1x1_bwd_data_ws_kernel<8>, dim3(g64, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w,
+                               dx, N, Cin, Cout, HW, npg);
+        return launch_status("conv1x1_bwd_data_ws");
+    }
     int CT = 16;                                   // fewer channels per lane when the grid would not fill the chip
     while (CT > 1 && (Cin % CT != 0 || (long)gx * (Cin / CT) < 512)) CT >>= 1;
     while (Cin % CT != 0) CT >>= 1;
@@ -196,8 +247,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_kernel(const float* 
     const int k = blockIdx.x * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
     float s = 0.f;
-    if (k < K)
-        for (int p = slice; p < P; p += 4) s += in[(size_t)p * K + k];
+    if (k < K) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // 4 independent chains: loads overlap
+        int p = slice;
+        for (; p + 12 < P; p += 16) {
+            s0 += in[(size_t)p * K + k];
+            s1 += in[(size_t)(p + 4) * K + k];
+            s2 += in[(size_t)(p + 8) * K + k];
+            s3 += in[(size_t)(p + 12) * K + k];
+        }
+        for (; p < P; p += 4) s0 += in[(size_t)p * K + k];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[slice][threadIdx.x & 63] = s;
     __syncthreads();
     if (slice == 0 && k < K) out[k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
