@@ -226,26 +226,26 @@ int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratc
 // reduction (reduce_rows), no float atomics.  The optional (raw, coef) pair applies a BatchNorm-backward affine
 // to dY on load (qkv_transform's gradient, whose dY is still in normalised space).
 // --------------------------------------------------------------------------- //
-template <int K>
+template <int K, int TO, int TC>          // TO x TC output tile (16 | 32 | 64 each): small layers do not pay for 64 x 64
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
     int stride, int pad, int QS, int npg) {
-    constexpr int KK = K * K;
-    __shared__ float A[64][65];
-    __shared__ float B[64][65];
+    constexpr int KK = K * K, RO = TO / 16, RC = TC / 16;
+    __shared__ float A[TO][65];
+    __shared__ float B[TC][65];
     const int Ktot = Cin * KK, HoWo = Ho * Wo;
-    const int o0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int o0 = blockIdx.x * TO, k0 = blockIdx.y * TC;
     const long NP = (long)N * HoWo;
     const long q_begin = (long)blockIdx.z * QS;
     const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
     const int to = threadIdx.x >> 4, tc = threadIdx.x & 15;
     const int j = threadIdx.x & 63, r0 = threadIdx.x >> 6;          // staging: fixed position j, rows r0, r0+4, ...
-    float acc[4][4];
+    float acc[RO][RC];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RO; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+        for (int b = 0; b < RC; ++b) acc[a][b] = 0.f;
     for (long q0 = q_begin; q0 < q_end; q0 += 64) {
         const long q = q0 + j;
         const bool qok = q < q_end;
@@ -257,50 +257,57 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
         const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
         const float* xp = x + (size_t)n * Cin * H * W;
 #pragma unroll 4
-        for (int r = r0; r < 64; r += 4) {
-            float a = 0.f, b = 0.f;
-            const int o = o0 + r, k = k0 + r;
+        for (int r = r0; r < TO; r += 4) {
+            float a = 0.f;
+            const int o = o0 + r;
             if (qok && o < Cout) {
                 a = dyp[(size_t)o * HoWo];
                 if (cf) a = fmaf(cf[o * 3], a, fmaf(cf[o * 3 + 1], rawp[(size_t)o * HoWo], cf[o * 3 + 2]));
             }
+            A[r][j] = a;
+        }
+#pragma unroll 4
+        for (int r = r0; r < TC; r += 4) {
+            float b = 0.f;
+            const int k = k0 + r;
             if (qok && k < Ktot) {
                 const int c = k / KK, t = k - c * KK;
                 const int kh = t / K, kw = t - kh * K;
                 const int h = hb + kh, w = wb + kw;
                 if (h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + h) * W + w];
             }
-            A[r][j] = a;
             B[r][j] = b;
         }
         __syncthreads();
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
-            float av[4], bv[4];
+            float av[RO], bv[RC];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = A[to + 16 * a][jj];
+            for (int a = 0; a < RO; ++a) av[a] = A[to + 16 * a][jj];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = B[tc + 16 * b][jj];
+            for (int b = 0; b < RC; ++b) bv[b] = B[tc + 16 * b][jj];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RO; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < RC; ++b) acc[a][b] = fmaf(av[a], bv[b], acc[a][b]);
         }
         __syncthreads();
     }
     float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RO; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < RC; ++b) {
             const int o = o0 + to + 16 * a, k = k0 + tc + 16 * b;
             if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[a][b];
         }
 }
 
+static inline int wgrad_tile(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+
 // positions per chunk: as small as 64 while the grid is below ~512 workgroups, at most 512
 static int wgrad_chunk(int Cout, int Ktot, long NP) {
-    const long tiles = (long)cdiv(Cout, 64) * cdiv(Ktot, 64);
+    const long tiles = (long)cdiv(Cout, wgrad_tile(Cout)) * cdiv(Ktot, wgrad_tile(Ktot));
     int QS = 512;
     while (QS > 64 && tiles * ((NP + QS - 1) / QS) < 512) QS >>= 1;
     while ((NP + QS - 1) / QS > 64) QS <<= 1;            // at most 64 partial slabs for the deterministic reduction
@@ -332,11 +339,25 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
         }
         return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
     }
-    switch (K) {
-        case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
-        case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
-        case 7: hipLaunchKernelGGL(conv_wgrad_kernel<7>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups); break;
-        default: set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K); return MEDT_EUNSUPPORTED;
+    {
+        const int TO = wgrad_tile(Cout), TC = wgrad_tile(Ktot);
+        const dim3 g2(cdiv(Cout, TO), cdiv(Ktot, TC), splits);
+#define MEDT_WG(KV, TOV, TCV)                                                                                        \
+    hipLaunchKernelGGL((conv_wgrad_kernel<KV, TOV, TCV>), g2, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, \
+                       Wo, stride, pad, QS, N / groups)
+#define MEDT_WG_TC(KV, TOV)                                                                                          \
+    do { if (TC == 16) MEDT_WG(KV, TOV, 16); else if (TC == 32) MEDT_WG(KV, TOV, 32); else MEDT_WG(KV, TOV, 64); } while (0)
+#define MEDT_WG_TO(KV)                                                                                               \
+    do { if (TO == 16) MEDT_WG_TC(KV, 16); else if (TO == 32) MEDT_WG_TC(KV, 32); else MEDT_WG_TC(KV, 64); } while (0)
+        switch (K) {
+            case 1: MEDT_WG_TO(1); break;
+            case 3: MEDT_WG_TO(3); break;
+            case 7: MEDT_WG_TO(7); break;
+            default: set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K); return MEDT_EUNSUPPORTED;
+        }
+#undef MEDT_WG_TO
+#undef MEDT_WG_TC
+#undef MEDT_WG
     }
     int rc = launch_status("conv_wgrad");
     if (rc) return rc;
