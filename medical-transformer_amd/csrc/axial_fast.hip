@@ -371,16 +371,14 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                 f2 l2 = (f2)(0.f), accv[GP], acce[GP];         // two partial sums each (even / odd columns)
 #pragma unroll
                 for (int c = 0; c < GP; ++c) { accv[c] = (f2)(0.f); acce[c] = (f2)(0.f); }
-#pragma unroll
-                for (int j0 = 0; j0 < L; j0 += 4) {
+                // One 4-column chunk: logits -> running max / rescale -> probabilities -> P.V accumulation.
+                auto chunk = [&](const f4 (&k4)[HQ], const f4 (&q4)[HQ], const f4 (&t4)[HQ], const f4 (&v4)[GP],
+                                 const f4 (&e4)[GP]) {
                     f2 zlo = (f2)(0.f), zhi = (f2)(0.f);
 #pragma unroll
                     for (int c = 0; c < HQ; ++c) {
-                        const f4 k4 = *reinterpret_cast<const f4*>(kp + c * L + j0);
-                        const f4 q4 = *reinterpret_cast<const f4*>(tabr + (c * 4) * CS + j0);
-                        const f4 t4 = *reinterpret_cast<const f4*>(tabr + ((HQ + c) * 4) * CS + j0);
-                        zlo = qa[c] * k4.lo + (qb[c] * q4.lo + (k4.lo * t4.lo + zlo));
-                        zhi = qa[c] * k4.hi + (qb[c] * q4.hi + (k4.hi * t4.hi + zhi));
+                        zlo = qa[c] * k4[c].lo + (qb[c] * q4[c].lo + (k4[c].lo * t4[c].lo + zlo));
+                        zhi = qa[c] * k4[c].hi + (qb[c] * q4[c].hi + (k4[c].hi * t4[c].hi + zhi));
                     }
                     const float mn = fmaxf(m, fmaxf(fmaxf(zlo.x, zlo.y), fmaxf(zhi.x, zhi.y)));
                     const f2 alpha = (f2)(__builtin_amdgcn_exp2f(m - mn));
@@ -393,10 +391,43 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                     l2 = l2 * alpha + (plo + phi);
 #pragma unroll
                     for (int c = 0; c < GP; ++c) {
-                        const f4 v4 = *reinterpret_cast<const f4*>(vp + c * L + j0);
-                        const f4 e4 = *reinterpret_cast<const f4*>(tabr + ((GP + c) * 4) * CS + j0);
-                        accv[c] = plo * v4.lo + (phi * v4.hi + accv[c] * alpha);
-                        acce[c] = plo * e4.lo + (phi * e4.hi + acce[c] * alpha);
+                        accv[c] = plo * v4[c].lo + (phi * v4[c].hi + accv[c] * alpha);
+                        acce[c] = plo * e4[c].lo + (phi * e4[c].hi + acce[c] * alpha);
+                    }
+                };
+                auto fetch = [&](int j0, f4 (&k4)[HQ], f4 (&q4)[HQ], f4 (&t4)[HQ], f4 (&v4)[GP], f4 (&e4)[GP]) {
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) {
+                        k4[c] = *reinterpret_cast<const f4*>(kp + c * L + j0);
+                        q4[c] = *reinterpret_cast<const f4*>(tabr + (c * 4) * CS + j0);
+                        t4[c] = *reinterpret_cast<const f4*>(tabr + ((HQ + c) * 4) * CS + j0);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GP; ++c) {
+                        v4[c] = *reinterpret_cast<const f4*>(vp + c * L + j0);
+                        e4[c] = *reinterpret_cast<const f4*>(tabr + ((GP + c) * 4) * CS + j0);
+                    }
+                };
+                if constexpr (GP == 2) {
+                    // software pipeline: the 7 ds_read_b128 of chunk t+1 are issued before the arithmetic of chunk t
+                    // (sched_barrier pins the order), so LDS latency hides under ~30 VALU issues instead of stalling
+                    f4 ka[HQ], qa4[HQ], ta[HQ], va[GP], ea[GP], kb[HQ], qb4[HQ], tb[HQ], vb[GP], eb[GP];
+                    fetch(0, ka, qa4, ta, va, ea);
+#pragma unroll
+                    for (int j0 = 0; j0 < L; j0 += 8) {
+                        fetch(j0 + 4, kb, qb4, tb, vb, eb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        chunk(ka, qa4, ta, va, ea);
+                        if (j0 + 8 < L) fetch(j0 + 8, ka, qa4, ta, va, ea);
+                        __builtin_amdgcn_sched_barrier(0);
+                        chunk(kb, qb4, tb, vb, eb);
+                    }
+                } else {
+#pragma unroll
+                    for (int j0 = 0; j0 < L; j0 += 4) {
+                        f4 k4[HQ], q4[HQ], t4[HQ], v4[GP], e4[GP];
+                        fetch(j0, k4, q4, t4, v4, e4);
+                        chunk(k4, q4, t4, v4, e4);
                     }
                 }
                 const float l = l2.x + l2.y;
