@@ -53,12 +53,13 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     from medt_amd.axial import AxialConfig, _desc, _params
     import lib as droplib
     lib = ML.lib()
-    layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=True).to(device)
+    width = os.environ.get("MEDT_ROOF_AXIS", "w") != "h"      # tuning aid: the height-axis variant of the same shape
+    layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=width).to(device)
     layer.train()
     N, H, W = images, L, L
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn((N, C, H, W), generator=g).to(device)
-    cfg = AxialConfig(8, 1, True, 1, layer.bn_qkv, layer.bn_similarity, layer.bn_output)
+    cfg = AxialConfig(8, 1 if width else 0, True, 1, layer.bn_qkv, layer.bn_similarity, layer.bn_output)
     desc = _desc(x, cfg, True)
     gates = (layer.f_qr, layer.f_kr, layer.f_sve, layer.f_sv)
     params = _params(cfg, layer.qkv_transform.weight, layer.relative, gates, True)
@@ -94,7 +95,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     bytes_main = 4 * C * 4 * M
     bytes_stats = C * 4 * M
     flops_main = 7.0 * M * L * C
-    roof = {"bound": "hbm", "kernel": "attn_fwd3_kernel<GP=2,AXIS=1,L=64>",
+    roof = {"bound": "hbm", "kernel": "attn_fwd3_kernel<GP=2,AXIS=%d,L=64>" % (1 if width else 0),
             "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main},
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,

@@ -63,18 +63,30 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
     g->fast3 = 0;
     g->fparts = g->tpg;
     g->nt = 1;
+    g->bound_path = 0;
+    {
+        static const float shift = [] { const char* e = getenv("MEDT_DEBUG_BOUND_SHIFT"); return e ? (float)atof(e) : 0.f; }();
+        g->bound_shift = shift;
+    }
     if (g->pos && fast_path_enabled()) {
-        int nt = fast3_max_subtiles(gp, g->L);
+        int nt = fast3_max_subtiles(gp, g->L, g->axis);
         if (nt > 0) {
             // Persistent workgroups over super-tiles of nt*S_T sequences.  Small problems (the model's own
             // shapes) keep nt = 1 so there are enough workgroups; big ones amortise the table staging over
             // up to NT sub-tiles and cap the grid at ~8 workgroups per CU.
             while (nt > 1 && (long)g->groups * d.G * cdiv(g->spg, g->S_T * nt) < 2048) nt >>= 1;
+            static const int env_nt = [] { const char* e = getenv("MEDT_NT"); return e ? atoi(e) : 0; }();
+            static const int env_cap = [] { const char* e = getenv("MEDT_CAP"); return e ? atoi(e) : 2048; }();
+            if (env_nt > 0 && env_nt < nt) nt = env_nt;
             const int nsup = cdiv(g->spg, g->S_T * nt);
-            int cap = 2048 / (g->groups * d.G);
+            int cap = env_cap / (g->groups * d.G);
             if (cap < 1) cap = 1;
             g->fast3 = 1;
             g->nt = nt;
+            // the bound-referenced kernel saves ~25 % of the issue slots but costs a memset + a repair launch:
+            // worth it from ~64M (i,j) pairs per launch (big batches / 256-px inputs), not at bs=4 x 128 px
+            static const int force = [] { const char* e = getenv("MEDT_BOUND_PATH"); return e ? atoi(e) : -1; }();
+            g->bound_path = force >= 0 ? force : ((double)g->groups * g->spg * d.G * g->L * g->L >= 64e6);
             g->fparts = nsup < cap ? nsup : cap;
         }
     }
@@ -864,9 +876,9 @@ int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, con
 }
 
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                   GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s) {
+                   GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
     if (fast_path_enabled()) {
-        const int rc = axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, s);
+        const int rc = axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s);
         if (rc <= 0) return rc;
     }
     const size_t lds = axial_core_lds_bytes(g, false);

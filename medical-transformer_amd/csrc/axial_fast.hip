@@ -273,82 +273,213 @@ struct Fast3 {
     static constexpr int SS = S_T * NT;
     static constexpr int CS = 2 * L + (((16 - 2 * L) % 64) + 64) % 64;
     static constexpr size_t lds_floats = (size_t)SS * RS + 256 + (size_t)NCH * 4 * CS;
+    // sub-tiles a kernel variant may be asked to run: the width axis is coalesced at any tile size and keeps its
+    // prefetch registers small; the height axis wants many adjacent sequences per tile (contiguous runs of SS*4 B)
+    static constexpr int nta(int axis) { return axis == 1 ? (NT < 2 ? NT : 2) : NT; }
 };
 
-int fast3_max_subtiles(int gp, int L) {     // host mirror of Fast3<GP,L>::NT (0 = no compile-time variant)
+int fast3_max_subtiles(int gp, int L, int axis) {     // host mirror of Fast3<GP,L>::nta(axis) (0 = no compile-time variant)
     if (L != 16 && L != 32 && L != 64 && L != 128) return 0;
     const int S_T = MEDT_THREADS / L, RS = (2 * gp + 1) * L + 4;
-    const int NT = 8192 / (S_T * RS);
-    return NT < 1 ? 1 : (NT > 8 ? 8 : NT);
+    int NT = 8192 / (S_T * RS);
+    NT = NT < 1 ? 1 : (NT > 8 ? 8 : NT);
+    return axis == 1 && NT > 2 ? 2 : NT;
 }
 
-// Stage `nch` channels of a super-tile, normalised by bn_qkv, lanes along the contiguous NCHW direction.
+// Global accesses of the fast kernels go through a wave-uniform 64-bit base plus a 32-bit per-lane byte offset:
+// the compiler then uses the saddr form of global_load/global_store and the phases around the sweep spend no VALU
+// issue slots on 64-bit address arithmetic (they used to cost ~40 % of the kernel's VALU instructions).
+__device__ __forceinline__ float ldg_u(const float* __restrict__ ubase, unsigned byteoff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + byteoff);
+}
+__device__ __forceinline__ void stg_u(float* __restrict__ ubase, unsigned byteoff, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
+}
+
+// Where the elements of one super-tile live.  (n0, s0, nseq) are wave-uniform (first image, first sequence inside
+// it, sequences in the tile); element t of a thread is e = threadIdx.x + 256 t, laid out with lanes along the
+// contiguous NCHW direction (width axis: along the sequence; height axis: across the sequences of the tile).
+// Small-integer divisions use (x + 0.5) * (1/d): exact while x < 2^20 (x is at most a few thousand here).
 template <int GP, int L, int AXIS>
-__device__ __forceinline__ void stage_super(float* reg, const float* __restrict__ qkv_raw, const AxialGeom& g, int hg,
-                                            int seq0, int nseq, int nch, const float* __restrict__ sc,
-                                            const float* __restrict__ sh) {
+struct SuperMap {
     using F = Fast3<GP, L>;
-    for (int e = threadIdx.x; e < nseq * L; e += MEDT_THREADS) {
+    int n0, s0, nseq;
+    float inv_bo, inv_nseq;
+
+    __device__ __forceinline__ void set(const AxialGeom& g, int n0_, int s0_, int nseq_) {
+        n0 = n0_; s0 = s0_; nseq = nseq_;
+        inv_bo = 1.f / (float)g.Bo;
+        inv_nseq = 1.f / (float)nseq_;
+    }
+    // sequence `ls` of the tile -> image offset from n0 and index inside that image
+    __device__ __forceinline__ void image_of(const AxialGeom& g, int ls, int& dn, int& sq) const {
+        const int s = s0 + ls;
+        dn = (int)(((float)s + 0.5f) * inv_bo);
+        sq = s - dn * g.Bo;
+    }
+    __device__ __forceinline__ bool locate(const AxialGeom& g, int t, int& lo, int& dn, int& pix) const {
+        const int e = threadIdx.x + t * MEDT_THREADS;
+        if (e >= nseq * L) return false;
         int ls, i;
         if (AXIS == 1) { ls = e / L; i = e % L; }
-        else if (nseq == F::SS) { i = e / F::SS; ls = e % F::SS; }
-        else { i = e / nseq; ls = e - i * nseq; }
-        const int b = seq0 + ls, n = b / g.Bo, s = b - n * g.Bo;
-        const float* src = qkv_raw + ((size_t)n * 2 * g.C + hg * F::NCH) * g.HW + (AXIS == 1 ? s * g.W + i : i * g.W + s);
-        float* dst = reg + ls * F::RS + i;
-        for (int ch = 0; ch < nch; ++ch) dst[ch * L] = fmaf(src[(size_t)ch * g.HW], sc[ch], sh[ch]);
+        else if (nseq == F::S_T) { i = e / F::S_T; ls = e % F::S_T; }
+        else { i = (int)(((float)e + 0.5f) * inv_nseq); ls = e - i * nseq; }
+        int sq;
+        image_of(g, ls, dn, sq);
+        pix = AXIS == 1 ? sq * g.W + i : i * g.W + sq;
+        lo = ls * F::RS + i;
+        return true;
     }
-}
+};
 
+// Register prefetch of a super-tile: the raw global loads of tile u+1 are issued before the arithmetic of tile u and
+// only land in LDS (normalised by bn_qkv) after it, so the HBM latency of one tile hides under the sweep of the
+// previous one.  NCHL = channels fetched (q,k,v for the main pass; q,k for the statistics pass).
+template <int GP, int L, int AXIS, int NCHL>
+struct SuperPrefetch {
+    using F = Fast3<GP, L>;
+    using Map = SuperMap<GP, L, AXIS>;
+    static constexpr int NTA = F::nta(AXIS);
+    static_assert(NTA * NCHL <= 32, "prefetch registers");
+    float v[NTA * NCHL];
+
+    __device__ __forceinline__ void issue(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
+        const float* base = qkv_raw + ((size_t)m.n0 * 2 * g.C + hg * F::NCH) * g.HW;      // uniform
+        const int img = 2 * g.C * g.HW;
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+            int lo, dn, pix;
+            if (m.locate(g, t, lo, dn, pix)) {
+                const unsigned off = (unsigned)(dn * img + pix) * 4u;
+#pragma unroll
+                for (int ch = 0; ch < NCHL; ++ch) v[t * NCHL + ch] = ldg_u(base, off + (unsigned)(ch * g.HW) * 4u);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(float* reg, const AxialGeom& g, const Map& m, const float* __restrict__ sc,
+                                           const float* __restrict__ sh) const {
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+            int lo, dn, pix;
+            if (m.locate(g, t, lo, dn, pix)) {
+#pragma unroll
+                for (int ch = 0; ch < NCHL; ++ch) reg[lo + ch * L] = fmaf(v[t * NCHL + ch], sc[ch], sh[ch]);
+            }
+        }
+    }
+};
+
+// LDS -> global, `nch` channels starting at LDS channel lch0 (height axis: re-maps rows to lanes for coalescing).
 template <int GP, int L, int AXIS>
 __device__ __forceinline__ void store_super(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
-                                            const AxialGeom& g, int seq0, int nseq) {
+                                            const AxialGeom& g, const SuperMap<GP, L, AXIS>& m) {
     using F = Fast3<GP, L>;
-    for (int e = threadIdx.x; e < nseq * L; e += MEDT_THREADS) {
-        int ls, i;
-        if (AXIS == 1) { ls = e / L; i = e % L; }
-        else if (nseq == F::SS) { i = e / F::SS; ls = e % F::SS; }
-        else { i = e / nseq; ls = e - i * nseq; }
-        const int b = seq0 + ls, n = b / g.Bo, s = b - n * g.Bo;
-        float* out = dst + ((size_t)n * CH + ch0) * g.HW + (AXIS == 1 ? s * g.W + i : i * g.W + s);
-        const float* src = reg + ls * F::RS + lch0 * L + i;
-        for (int ch = 0; ch < nch; ++ch) out[(size_t)ch * g.HW] = src[ch * L];
+    float* base = dst + ((size_t)m.n0 * CH + ch0) * g.HW;                                   // uniform
+    const int img = CH * g.HW;
+#pragma unroll
+    for (int t = 0; t < F::nta(AXIS); ++t) {
+        int lo, dn, pix;
+        if (m.locate(g, t, lo, dn, pix)) {
+            const unsigned off = (unsigned)(dn * img + pix) * 4u;
+            const float* src = reg + lo + lch0 * L;
+            for (int ch = 0; ch < nch; ++ch) stg_u(base, off + (unsigned)(ch * g.HW) * 4u, src[ch * L]);
+        }
     }
 }
 
-template <int GP, int AXIS, int L>
+// EXACT = true : online softmax (running max, one rescale per 4-column chunk); if `flag` is given the kernel only
+//                runs when *flag != 0 (it is then the repair pass behind the bound-referenced variant).
+// EXACT = false: softmax referenced to a cheap per-row upper bound of the logits (no running max, no rescale:
+//                27 instead of 38 issues per 4 columns).  Softmax is shift invariant, so any reference >= max_j z is
+//                exact; the only failure mode is a bound so loose that every 2^(z-bound) underflows, which is
+//                detected (l == 0) and reported through *flag for the EXACT kernel launched right behind.
+template <int GP, int AXIS, int L, bool EXACT>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
                                                                  BnStats qs, BnStats ss,
                                                                  const float* __restrict__ relative, GatePtrs gates,
                                                                  float* __restrict__ stacked,
                                                                  float* __restrict__ lse_out,
-                                                                 float* __restrict__ out_partials) {
+                                                                 float* __restrict__ out_partials,
+                                                                 unsigned* __restrict__ flag) {
     using F = Fast3<GP, L>;
-    constexpr int HQ = F::HQ, NCH = F::NCH, OCG = F::OCG, RS = F::RS, CS = F::CS, S_T = F::S_T, SS = F::SS;
+    constexpr int HQ = F::HQ, NCH = F::NCH, OCG = F::OCG, RS = F::RS, CS = F::CS, S_T = F::S_T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* reg = smem;
-    float* red = reg + SS * RS;
+    float* red = reg + S_T * g.nt * RS;                       // LDS is sized for the runtime super-tile (occupancy)
     float* tab = red + 256;
+    if (EXACT && flag && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // nothing to repair
     const int grp = blockIdx.x / g.fparts, part = blockIdx.x - grp * g.fparts, hg = blockIdx.y;
     const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
     const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
     const float a_qr = ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E;
     const float a_kr = ss.scale[grp * g.SC + 2 * g.G + hg] * f_kr * MEDT_LOG2E;
     stage_tables_cols<GP>(tab, relative, L, a_kr);
-    const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
-    const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
+    if (threadIdx.x < NCH) {                                  // bn_qkv's affine for this head group: LDS-resident
+        red[128 + threadIdx.x] = qs.scale[grp * 2 * g.C + hg * NCH + threadIdx.x];
+        red[160 + threadIdx.x] = qs.shift[grp * 2 * g.C + hg * NCH + threadIdx.x];
+    }
+    __syncthreads();
+    // max |entry| of the Rq rows and of the (scaled) Rk rows: ingredients of the per-row logit bound below
+    float tqmax[HQ], tkmax[HQ];
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) {
+            float a = 0.f, b = 0.f;
+            for (int x = threadIdx.x; x < 2 * L - 1; x += MEDT_THREADS) {
+                a = fmaxf(a, fabsf(tab[(c * 4) * CS + x]));
+                b = fmaxf(b, fabsf(tab[((HQ + c) * 4) * CS + x]));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+            if (lane == 0) { red[wave * 2 * HQ + 2 * c] = a; red[wave * 2 * HQ + 2 * c + 1] = b; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) {
+            tqmax[c] = fmaxf(fmaxf(red[2 * c], red[2 * HQ + 2 * c]), fmaxf(red[4 * HQ + 2 * c], red[6 * HQ + 2 * c]));
+            tkmax[c] = fmaxf(fmaxf(red[2 * c + 1], red[2 * HQ + 2 * c + 1]),
+                             fmaxf(red[4 * HQ + 2 * c + 1], red[6 * HQ + 2 * c + 1]));
+        }
+    }
+    const float* sc = red + 128;
+    const float* sh = red + 160;
     const int lsub = threadIdx.x / L, i = threadIdx.x % L;
     const int r = (3 - i) & 3;
     const float* tabr = tab + r * CS + (L - 1 - i - r);       // + j0 per chunk (immediate offset)
     float st_sum[OCG], st_sq[OCG];
 #pragma unroll
     for (int k = 0; k < OCG; ++k) { st_sum[k] = 0.f; st_sq[k] = 0.f; }
+    int bad = 0;                                              // any row whose bound-referenced sum underflowed
     const int SSr = S_T * g.nt;                               // runtime super-tile (g.nt <= NT sub-tiles)
     const int nsup = (g.spg + SSr - 1) / SSr;
+    using Map = SuperMap<GP, L, AXIS>;
+    using PF = SuperPrefetch<GP, L, AXIS, NCH>;
+    // tiles of this workgroup: u = part, part + fparts, ...; (image, sequence-in-image) advance by a fixed step
+    const unsigned step = (unsigned)g.fparts * SSr;
+    const int dn_step = step / (unsigned)g.Bo, ds_step = step - dn_step * g.Bo;
+    Map cur, nxt;
+    {
+        const unsigned q0 = (unsigned)part * SSr;
+        const int dn = q0 / (unsigned)g.Bo;
+        nxt.set(g, grp * g.npg + dn, q0 - dn * g.Bo, min(SSr, g.spg - (int)q0));
+    }
+    PF pf;
+    if (part < nsup) pf.issue(qkv_raw, g, hg, nxt);
     for (int u = part; u < nsup; u += g.fparts) {
-        const int seq0 = grp * g.spg + u * SSr, nseq = min(SSr, g.spg - u * SSr);
-        __syncthreads();                                       // previous super-tile fully stored / tables staged
-        stage_super<GP, L, AXIS>(reg, qkv_raw, g, hg, seq0, nseq, NCH, sc, sh);
+        cur = nxt;
+        const int nseq = cur.nseq;
+        __syncthreads();                                       // previous super-tile fully consumed / tables staged
+        pf.commit(reg, g, cur, sc, sh);
+        {
+            const int un = u + g.fparts;
+            int s0 = cur.s0 + ds_step, n0 = cur.n0 + dn_step;
+            if (s0 >= g.Bo) { s0 -= g.Bo; ++n0; }
+            if (un < nsup) {
+                nxt.set(g, n0, s0, min(SSr, g.spg - un * SSr));
+                pf.issue(qkv_raw, g, hg, nxt);                 // in flight during the sweep below
+            }
+        }
         __syncthreads();
 #pragma unroll 1
         for (int sub = 0; sub < g.nt; ++sub) {
@@ -357,23 +488,67 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
             float outv[OCG], lse = 0.f;
 #pragma unroll
             for (int k = 0; k < OCG; ++k) outv[k] = 0.f;
+            // max_j |k[c][j]| of this lane's sequence (lanes of one sequence exchange through shuffles; L = 128 spans
+            // two waves and goes through LDS)
+            float kmax[HQ];
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                float a = active ? fabsf(reg[ls * RS + (HQ + c) * L + i]) : 0.f;
+#pragma unroll
+                for (int o = (L < 64 ? L : 64) / 2; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+                kmax[c] = a;
+            }
+            if (L > 64) {
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0)
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) red[64 + (threadIdx.x >> 6) * HQ + c] = kmax[c];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < HQ; ++c)
+                    kmax[c] = fmaxf(red[64 + ((threadIdx.x >> 6) & ~1) * HQ + c], red[64 + ((threadIdx.x >> 6) | 1) * HQ + c]);
+            }
             if (active) {
                 f2 qa[HQ], qb[HQ];
+                float mb = g.bound_shift;            // upper bound of this row's logits (log2 domain); 0 + test hook
 #pragma unroll
                 for (int c = 0; c < HQ; ++c) {
                     const float q = reg[ls * RS + c * L + i];
                     qa[c] = (f2)(q * a_qk);
                     qb[c] = (f2)(q * a_qr);
+                    mb += fabsf(q * a_qk) * kmax[c] + fabsf(q * a_qr) * tqmax[c] + kmax[c] * tkmax[c];
                 }
                 const float* kp = reg + ls * RS + HQ * L;
                 const float* vp = reg + ls * RS + GP * L;
-                float m = -INFINITY;
+                float m = mb;
                 f2 l2 = (f2)(0.f), accv[GP], acce[GP];         // two partial sums each (even / odd columns)
 #pragma unroll
                 for (int c = 0; c < GP; ++c) { accv[c] = (f2)(0.f); acce[c] = (f2)(0.f); }
-                // One 4-column chunk: logits -> running max / rescale -> probabilities -> P.V accumulation.
+                // Fast path: softmax is shift invariant, so any m >= max_j z works as the reference point.  The bound
+                // mb costs nothing per pair (no running max, no rescale: 27 instead of 38 issues per 4 columns); all
+                // it can do wrong is sit so far above the true maximum that every 2^(z-mb) underflows -- detected
+                // below (l == 0), in which case the wave redoes its rows with the exact online softmax.
                 auto chunk = [&](const f4 (&k4)[HQ], const f4 (&q4)[HQ], const f4 (&t4)[HQ], const f4 (&v4)[GP],
                                  const f4 (&e4)[GP]) {
+                    f2 zlo = (f2)(-mb), zhi = (f2)(-mb);
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) {
+                        zlo = qa[c] * k4[c].lo + (qb[c] * q4[c].lo + (k4[c].lo * t4[c].lo + zlo));
+                        zhi = qa[c] * k4[c].hi + (qb[c] * q4[c].hi + (k4[c].hi * t4[c].hi + zhi));
+                    }
+                    f2 plo, phi;
+                    plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
+                    phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
+                    l2 += plo + phi;
+#pragma unroll
+                    for (int c = 0; c < GP; ++c) {
+                        accv[c] = plo * v4[c].lo + (phi * v4[c].hi + accv[c]);
+                        acce[c] = plo * e4[c].lo + (phi * e4[c].hi + acce[c]);
+                    }
+                };
+                // Exact path (rare): running max with one rescale per chunk.
+                auto chunk_exact = [&](const f4 (&k4)[HQ], const f4 (&q4)[HQ], const f4 (&t4)[HQ], const f4 (&v4)[GP],
+                                       const f4 (&e4)[GP]) {
                     f2 zlo = (f2)(0.f), zhi = (f2)(0.f);
 #pragma unroll
                     for (int c = 0; c < HQ; ++c) {
@@ -408,30 +583,27 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                         e4[c] = *reinterpret_cast<const f4*>(tabr + ((GP + c) * 4) * CS + j0);
                     }
                 };
-                if constexpr (GP == 2) {
-                    // software pipeline: the 7 ds_read_b128 of chunk t+1 are issued before the arithmetic of chunk t
-                    // (sched_barrier pins the order), so LDS latency hides under ~30 VALU issues instead of stalling
-                    f4 ka[HQ], qa4[HQ], ta[HQ], va[GP], ea[GP], kb[HQ], qb4[HQ], tb[HQ], vb[GP], eb[GP];
-                    fetch(0, ka, qa4, ta, va, ea);
-#pragma unroll
-                    for (int j0 = 0; j0 < L; j0 += 8) {
-                        fetch(j0 + 4, kb, qb4, tb, vb, eb);
-                        __builtin_amdgcn_sched_barrier(0);
-                        chunk(ka, qa4, ta, va, ea);
-                        if (j0 + 8 < L) fetch(j0 + 8, ka, qa4, ta, va, ea);
-                        __builtin_amdgcn_sched_barrier(0);
-                        chunk(kb, qb4, tb, vb, eb);
-                    }
-                } else {
+                // Unrolled over the row; sched_barrier keeps the chunks in program order (without it the scheduler
+                // hoists every ds_read of the row and the register count explodes).  Latency is hidden by occupancy
+                // (>= 4 waves per SIMD), not by software pipelining: both were measured, this needs fewer registers.
+                auto sweep = [&](auto&& body) {
 #pragma unroll
                     for (int j0 = 0; j0 < L; j0 += 4) {
                         f4 k4[HQ], q4[HQ], t4[HQ], v4[GP], e4[GP];
                         fetch(j0, k4, q4, t4, v4, e4);
-                        chunk(k4, q4, t4, v4, e4);
+                        body(k4, q4, t4, v4, e4);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                };
+                if constexpr (EXACT) {
+                    m = -INFINITY;
+                    sweep(chunk_exact);
+                } else {
+                    sweep(chunk);
                 }
                 const float l = l2.x + l2.y;
-                const float inv = 1.f / l;
+                if (!EXACT) bad |= !(l > 1e-30f);                // bound too loose for this row: request repair (below)
+                const float inv = __builtin_amdgcn_rcpf(l);
                 lse = m + __log2f(l);
 #pragma unroll
                 for (int c = 0; c < GP; ++c) {
@@ -439,23 +611,46 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                     outv[2 * c + 1] = f_sve * (acce[c].x + acce[c].y) * inv;
                 }
             }
-            // the L lanes that read sequence ls are the only readers of its region: when they share a wave the
-            // in-order LDS pipe makes the overwrite safe without a barrier; L = 128 spans two waves.
-            if (L > 64) __syncthreads();
-            if (active) {
+            if constexpr (AXIS == 1) {
+                // width axis: the compute lanes already run along the contiguous direction -> store from registers
+                if (active) {
+                    int dn, sq;
+                    cur.image_of(g, ls, dn, sq);
+                    const int pix = sq * g.W + i;
+                    float* bo = stacked + ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW;            // uniform
+                    const unsigned off = (unsigned)(dn * g.OC * g.HW + pix) * 4u;
 #pragma unroll
-                for (int k = 0; k < OCG; ++k) {
-                    reg[ls * RS + k * L + i] = outv[k];
-                    st_sum[k] += outv[k];
-                    st_sq[k] = fmaf(outv[k], outv[k], st_sq[k]);
+                    for (int k = 0; k < OCG; ++k) {
+                        stg_u(bo, off + (unsigned)(k * g.HW) * 4u, outv[k]);
+                        st_sum[k] += outv[k];
+                        st_sq[k] = fmaf(outv[k], outv[k], st_sq[k]);
+                    }
+                    if (lse_out)
+                        stg_u(lse_out + ((size_t)cur.n0 * g.G + hg) * g.HW, (unsigned)(dn * g.G * g.HW + pix) * 4u, lse);
                 }
-                reg[ls * RS + NCH * L + i] = lse;
+            } else {
+                // the L lanes that read sequence ls are the only readers of its region: when they share a wave the
+                // in-order LDS pipe makes the overwrite safe without a barrier; L = 128 spans two waves.
+                if (L > 64) __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int k = 0; k < OCG; ++k) {
+                        reg[ls * RS + k * L + i] = outv[k];
+                        st_sum[k] += outv[k];
+                        st_sq[k] = fmaf(outv[k], outv[k], st_sq[k]);
+                    }
+                    reg[ls * RS + NCH * L + i] = lse;
+                }
             }
         }
-        __syncthreads();
-        store_super<GP, L, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, seq0, nseq);
-        if (lse_out) store_super<GP, L, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, seq0, nseq);
+        if constexpr (AXIS == 0) {
+            __syncthreads();
+            store_super<GP, L, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
+            if (lse_out) store_super<GP, L, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
+        }
     }
+    // (kept out of the row loop: a branch there makes LLVM sink the whole accumulator chain behind it)
+    if (!EXACT && bad) atomicOr(flag, 1u);
     if (out_partials) {
         float v[2 * OCG];
 #pragma unroll
@@ -470,34 +665,60 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
                                                                     BnStats qs, const float* __restrict__ relative,
                                                                     GatePtrs gates, float* __restrict__ partials) {
     using F = Fast3<GP, L>;
-    constexpr int HQ = F::HQ, NCH = F::NCH, RS = F::RS, CS = F::CS, S_T = F::S_T, SS = F::SS;
+    constexpr int HQ = F::HQ, NCH = F::NCH, RS = F::RS, CS = F::CS, S_T = F::S_T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* reg = smem;
-    float* red = reg + SS * RS;
+    float* red = reg + S_T * g.nt * RS;                       // LDS is sized for the runtime super-tile (occupancy)
     float* tab = red + 256;
     const int grp = blockIdx.x / g.fparts, part = blockIdx.x - grp * g.fparts, hg = blockIdx.y;
     const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
-    stage_tables_cols<GP>(tab, relative, L, 1.f);
-    const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
-    const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
+    stage_tables_cols<GP>(tab, relative, L, f_kr);              // f_kr folded into the Rk rows, f_qr into q below
+    if (threadIdx.x < NCH) {                                  // bn_qkv's affine for this head group: LDS-resident
+        red[128 + threadIdx.x] = qs.scale[grp * 2 * g.C + hg * NCH + threadIdx.x];
+        red[160 + threadIdx.x] = qs.shift[grp * 2 * g.C + hg * NCH + threadIdx.x];
+    }
+    const float* sc = red + 128;
+    const float* sh = red + 160;
     const int lsub = threadIdx.x / L, i = threadIdx.x % L;
     const int r = (3 - i) & 3;
     const float* tabr = tab + r * CS + (L - 1 - i - r);
     f2 s_qk = (f2)(0.f), q_qk = (f2)(0.f), s_qr = (f2)(0.f), q_qr = (f2)(0.f), s_kr = (f2)(0.f), q_kr = (f2)(0.f);
     const int SSr = S_T * g.nt;                               // runtime super-tile (g.nt <= NT sub-tiles)
     const int nsup = (g.spg + SSr - 1) / SSr;
+    using Map = SuperMap<GP, L, AXIS>;
+    using PF = SuperPrefetch<GP, L, AXIS, GP>;                                          // q and k channels only
+    const unsigned step = (unsigned)g.fparts * SSr;
+    const int dn_step = step / (unsigned)g.Bo, ds_step = step - dn_step * g.Bo;
+    Map cur, nxt;
+    {
+        const unsigned q0 = (unsigned)part * SSr;
+        const int dn = q0 / (unsigned)g.Bo;
+        nxt.set(g, grp * g.npg + dn, q0 - dn * g.Bo, min(SSr, g.spg - (int)q0));
+    }
+    PF pf;
+    if (part < nsup) pf.issue(qkv_raw, g, hg, nxt);
     for (int u = part; u < nsup; u += g.fparts) {
-        const int seq0 = grp * g.spg + u * SSr, nseq = min(SSr, g.spg - u * SSr);
+        cur = nxt;
+        const int nseq = cur.nseq;
         __syncthreads();
-        stage_super<GP, L, AXIS>(reg, qkv_raw, g, hg, seq0, nseq, GP, sc, sh);          // q and k channels only
+        pf.commit(reg, g, cur, sc, sh);
+        {
+            const int un = u + g.fparts;
+            int s0 = cur.s0 + ds_step, n0 = cur.n0 + dn_step;
+            if (s0 >= g.Bo) { s0 -= g.Bo; ++n0; }
+            if (un < nsup) {
+                nxt.set(g, n0, s0, min(SSr, g.spg - un * SSr));
+                pf.issue(qkv_raw, g, hg, nxt);
+            }
+        }
         __syncthreads();
 #pragma unroll 1
         for (int sub = 0; sub < g.nt; ++sub) {
             const int ls = sub * S_T + lsub;
             if (ls < nseq) {
-                f2 q[HQ];
+                f2 q[HQ], qf[HQ];
 #pragma unroll
-                for (int c = 0; c < HQ; ++c) q[c] = (f2)(reg[ls * RS + c * L + i]);
+                for (int c = 0; c < HQ; ++c) { q[c] = (f2)(reg[ls * RS + c * L + i]); qf[c] = q[c] * (f2)(f_qr); }
                 const float* kp = reg + ls * RS + HQ * L;
 #pragma unroll
                 for (int j0 = 0; j0 < L; j0 += 4) {
@@ -508,11 +729,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
                         const f4 q4 = *reinterpret_cast<const f4*>(tabr + (c * 4) * CS + j0);
                         const f4 t4 = *reinterpret_cast<const f4*>(tabr + ((HQ + c) * 4) * CS + j0);
                         alo = q[c] * k4.lo + alo;  ahi = q[c] * k4.hi + ahi;
-                        blo = q[c] * q4.lo + blo;  bhi = q[c] * q4.hi + bhi;
+                        blo = qf[c] * q4.lo + blo; bhi = qf[c] * q4.hi + bhi;
                         clo = k4.lo * t4.lo + clo; chi = k4.hi * t4.hi + chi;
                     }
-                    blo *= (f2)(f_qr); bhi *= (f2)(f_qr);
-                    clo *= (f2)(f_kr); chi *= (f2)(f_kr);
                     s_qk += alo + ahi;  q_qk = alo * alo + (ahi * ahi + q_qk);
                     s_qr += blo + bhi;  q_qr = blo * blo + (bhi * bhi + q_qr);
                     s_kr += clo + chi;  q_kr = clo * clo + (chi * chi + q_kr);
@@ -539,10 +758,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
 
 #define MEDT_F3_CASE(KERNEL, GPv, Lv, ...)                                                                          \
     case GPv * 1024 + Lv * 2 + 0:                                                                                   \
-        hipLaunchKernelGGL((KERNEL<GPv, 0, Lv>), grid, block, (Fast3<GPv, Lv>::lds_floats * sizeof(float)), s, __VA_ARGS__); \
+        hipLaunchKernelGGL((KERNEL(GPv, 0, Lv)), grid, block, ((Fast3<GPv, Lv>::lds_floats - (size_t)(Fast3<GPv, Lv>::NT - g.nt) * Fast3<GPv, Lv>::S_T * Fast3<GPv, Lv>::RS) * sizeof(float)), s, __VA_ARGS__); \
         break;                                                                                                      \
     case GPv * 1024 + Lv * 2 + 1:                                                                                   \
-        hipLaunchKernelGGL((KERNEL<GPv, 1, Lv>), grid, block, (Fast3<GPv, Lv>::lds_floats * sizeof(float)), s, __VA_ARGS__); \
+        hipLaunchKernelGGL((KERNEL(GPv, 1, Lv)), grid, block, ((Fast3<GPv, Lv>::lds_floats - (size_t)(Fast3<GPv, Lv>::NT - g.nt) * Fast3<GPv, Lv>::S_T * Fast3<GPv, Lv>::RS) * sizeof(float)), s, __VA_ARGS__); \
         break;
 #define MEDT_F3_L(KERNEL, GPv, ...)                                                                                 \
     MEDT_F3_CASE(KERNEL, GPv, 16, __VA_ARGS__) MEDT_F3_CASE(KERNEL, GPv, 32, __VA_ARGS__)                            \
@@ -553,9 +772,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
         switch (g.gp * 1024 + g.L * 2 + g.axis) {                                                                   \
             MEDT_F3_L(KERNEL, 2, __VA_ARGS__) MEDT_F3_L(KERNEL, 4, __VA_ARGS__)                                      \
             MEDT_F3_L(KERNEL, 8, __VA_ARGS__) MEDT_F3_L(KERNEL, 16, __VA_ARGS__)                                     \
-            default: set_error(#KERNEL ": no instantiation"); return MEDT_EUNSUPPORTED;                             \
+            default: set_error("fast3: no instantiation"); return MEDT_EUNSUPPORTED;                             \
         }                                                                                                           \
-        return launch_status(#KERNEL);                                                                              \
+        return launch_status("fast3 kernel");                                                                       \
     } while (0)
 
 // --------------------------------------------------------------------------- //
@@ -583,13 +802,23 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
 
 int axial_logit_stats_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative,
                            GatePtrs gates, float* partials, hipStream_t s) {
-    if (g.fast3) MEDT_FAST3_DISPATCH(logit_stats3_kernel, g, qkv_raw, qkv, relative, gates, partials);
+#define MEDT_K_STATS(a, b, c) logit_stats3_kernel<a, b, c>
+    if (g.fast3) MEDT_FAST3_DISPATCH(MEDT_K_STATS, g, qkv_raw, qkv, relative, gates, partials);
     MEDT_FAST_DISPATCH(logit_stats4_kernel, g, qkv_raw, qkv, relative, gates, partials);
 }
 
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                        GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s) {
-    if (g.fast3) MEDT_FAST3_DISPATCH(attn_fwd3_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials);
+                        GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
+#define MEDT_K_EXACT(a, b, c) attn_fwd3_kernel<a, b, c, true>
+#define MEDT_K_BOUND(a, b, c) attn_fwd3_kernel<a, b, c, false>
+    if (g.fast3 && g.bound_path && flag) {
+        // large problems: bound-referenced softmax, then the (normally empty) repair pass
+        if (hipMemsetAsync(flag, 0, sizeof(unsigned), s) != hipSuccess) { set_error("attn_fwd: memset failed"); return MEDT_ELAUNCH; }
+        int rc = [&]() -> int { MEDT_FAST3_DISPATCH(MEDT_K_BOUND, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag); }();
+        if (rc) return rc;
+        MEDT_FAST3_DISPATCH(MEDT_K_EXACT, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag);
+    }
+    if (g.fast3) MEDT_FAST3_DISPATCH(MEDT_K_EXACT, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, (unsigned*)nullptr);
     MEDT_FAST_DISPATCH(attn_fwd4_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials);
 }
 

@@ -36,7 +36,9 @@ struct LayerStats {
 
 struct FwdWs {
     float *part_qkv, *part_sim, *part_out, *qkv_ksplit;
+    unsigned* flag;
     FwdWs(Carver& c, const AxialGeom& g) {
+        flag = c.take<unsigned>(4);
         const size_t kq = conv2d_fwd_scratch_floats(g.N, g.groups, g.C, g.H, g.W, 2 * g.C, 1, 1, 0);
         qkv_ksplit = c.take<float>(kq);
         if (!kq) qkv_ksplit = nullptr;
@@ -142,7 +144,7 @@ int medt_axial_core_fwd(const medt_axial_desc* d, const medt_axial_params* p, co
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
     return axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
-                          d->training ? w.part_out : nullptr, (hipStream_t)stream);
+                          d->training ? w.part_out : nullptr, w.flag, (hipStream_t)stream);
 }
 
 int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, float* y,
@@ -169,7 +171,7 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
                           st.sim, s))) return rc;
     // logits + softmax + gated sv|sve, bn_output batch statistics                                 :157-178
     if ((rc = axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
-                             tr ? w.part_out : nullptr, s))) return rc;
+                             tr ? w.part_out : nullptr, w.flag, s))) return rc;
     if ((rc = bn_finalize(w.part_out, g.fparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
                           st.out, s))) return rc;
     // bn_output + pair-sum + AvgPool                                                              :179-187

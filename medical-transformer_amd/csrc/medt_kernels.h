@@ -102,6 +102,8 @@ struct AxialGeom {
     int fast3;              // 1: compile-time-L persistent forward kernels (axial_fast.hip)
     int fparts;             // partial-statistics slots per group written by the forward L x L kernels
     int nt;                 // sub-tiles (of S_T sequences) per super-tile in the persistent kernels
+    int bound_path;         // 1: bound-referenced softmax + repair pass (large problems only: two extra graph nodes)
+    float bound_shift;      // test hook (MEDT_DEBUG_BOUND_SHIFT): added to the softmax reference bound to force the exact fallback
     double sim_count;       // elements per bn_similarity channel per group = spg * L * L
     double row_count;       // elements per bn_qkv / bn_output channel per group = spg * L
 };
@@ -114,8 +116,8 @@ struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; };
 int axial_logit_stats_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative,
                            GatePtrs gates, float* partials, hipStream_t s);
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                        GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s);
-int fast3_max_subtiles(int gp, int L);
+                        GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
+int fast3_max_subtiles(int gp, int L, int axis);
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // logit statistics: partials [group][tile][SC][2]
@@ -123,7 +125,7 @@ int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, con
                       float* partials, hipStream_t s);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                   GatePtrs gates, float* stacked, float* lse, float* out_partials, hipStream_t s);
+                   GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
 // backward pass A: partials [group][tile][G][4] = sum dZ*{S_qk,S_qr,S_kr,1}
 int axial_attn_bwd_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                          GatePtrs gates, const float* stacked, const float* lse, const float* dy,

@@ -101,7 +101,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MedtError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
                             "(hipcc --offload-arch=gfx950); there is no CPU / eager fallback")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(os.environ.get("MEDT_LIB_OVERRIDE", LIB_PATH))   # override: kernel experiments only
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res

@@ -174,3 +174,45 @@ def test_large_batch_property(device):
         layer.bn_similarity.bias.add_(3.0)
         y2 = layer(x)
     assert H.rel_err(y2, y) < 1e-5
+
+
+def _run_layer_subprocess(env_extra):
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path[:0] = [os.path.join(os.environ["MEDT_ROOT"], "medical-transformer_amd"), os.environ["MEDT_ROOT"], os.path.join(os.environ["MEDT_ROOT"], "tests")]
+import lib as droplib
+from oracle import medt_oracle as O
+dev = torch.device("cuda:0")
+for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, False)):
+    layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=width).to(dev)
+    st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 5)
+    layer.load_state_dict(st)
+    layer.train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((2, C, 6, L) if width else (2, C, L, 6), generator=g)
+    y = layer(x.to(dev))
+    ost = O.clone_state({("m." + k): v for k, v in st.items()}, torch.float64)
+    yo = O.axial_attention(x.double(), ost, "m", width, 1, True)
+    err = (y.double().cpu() - yo).abs().max().item() / yo.abs().max().item()
+    assert err < 1e-3, (C, L, err)
+print("layers ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEDT_ROOT=root, **env_extra)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "layers ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_softmax_bound_path(device):
+    """Large problems take the bound-referenced softmax kernel (softmax shifted by a cheap per-row upper bound of
+    the logits instead of a running maximum).  MEDT_BOUND_PATH=1 forces it on small shapes: same results."""
+    _run_layer_subprocess({"MEDT_BOUND_PATH": "1"})
+
+
+def test_softmax_bound_repair_pass(device):
+    """When the bound is so loose that a row's sum underflows the kernel raises a flag and the exact kernel queued
+    behind it redoes the launch.  MEDT_DEBUG_BOUND_SHIFT=400 pushes every bound 400 octaves up, so every launch
+    is repaired: results must not change."""
+    _run_layer_subprocess({"MEDT_BOUND_PATH": "1", "MEDT_DEBUG_BOUND_SHIFT": "400"})
