@@ -64,6 +64,9 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
     g->fparts = g->tpg;
     g->nt = 1;
     g->bound_path = 0;
+    g->rows4 = 0;
+    g->nt4 = 1;
+    g->oparts = g->tpg;
     {
         static const float shift = [] { const char* e = getenv("MEDT_DEBUG_BOUND_SHIFT"); return e ? (float)atof(e) : 0.f; }();
         g->bound_shift = shift;
@@ -88,6 +91,21 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
             static const int force = [] { const char* e = getenv("MEDT_BOUND_PATH"); return e ? atoi(e) : -1; }();
             g->bound_path = force >= 0 ? force : ((double)g->groups * g->spg * d.G * g->L * g->L >= 64e6);
             g->fparts = nsup < cap ? nsup : cap;
+            g->oparts = g->fparts;
+            // gp = 2: from ~2048 workgroups of the wider tile on, four rows per lane
+            static const int force4 = [] { const char* e = getenv("MEDT_ROWS4"); return e ? atoi(e) : -1; }();
+            if (gp == 2 && force4 != 0) {
+                const int st4 = fast4_subtile_sequences(g->L);
+                int nt4 = fast4_max_subtiles(g->axis);
+                while (nt4 > 1 && (long)g->groups * d.G * cdiv(g->spg, st4 * nt4) < 2048) nt4 >>= 1;
+                const long blocks4 = (long)g->groups * d.G * cdiv(g->spg, st4 * nt4);
+                if (force4 == 1 || blocks4 >= 2048) {
+                    const int nsup4 = cdiv(g->spg, st4 * nt4);
+                    g->rows4 = 1;
+                    g->nt4 = nt4;
+                    g->oparts = nsup4 < cap ? nsup4 : cap;
+                }
+            }
         }
     }
     g->sim_count = (double)g->spg * g->L * g->L;

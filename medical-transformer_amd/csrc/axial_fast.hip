@@ -265,8 +265,9 @@ __device__ __forceinline__ void stage_tables_cols(float* tab, const float* __res
 
 template <int GP, int L>
 struct Fast3 {
-    static constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = 2 * GP;
-    static constexpr int S_T = MEDT_THREADS / L;
+    static constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = 2 * GP, LEN = L;
+    static constexpr int S_T = MEDT_THREADS / L;              // sequences per sub-tile (one row per lane)
+    static constexpr int EPT = 1;                             // tile elements per thread and sub-tile (S_T*L/256)
     static constexpr int RS = (NCH + 1) * L + 4;
     static constexpr int NT0 = 8192 / (S_T * RS);
     static constexpr int NT = NT0 < 1 ? 1 : (NT0 > 8 ? 8 : NT0);
@@ -300,9 +301,9 @@ __device__ __forceinline__ void stg_u(float* __restrict__ ubase, unsigned byteof
 // it, sequences in the tile); element t of a thread is e = threadIdx.x + 256 t, laid out with lanes along the
 // contiguous NCHW direction (width axis: along the sequence; height axis: across the sequences of the tile).
 // Small-integer divisions use (x + 0.5) * (1/d): exact while x < 2^20 (x is at most a few thousand here).
-template <int GP, int L, int AXIS>
+template <class F, int AXIS>
 struct SuperMap {
-    using F = Fast3<GP, L>;
+    static constexpr int L = F::LEN;
     int n0, s0, nseq;
     float inv_bo, inv_nseq;
 
@@ -335,11 +336,11 @@ struct SuperMap {
 // Register prefetch of a super-tile: the raw global loads of tile u+1 are issued before the arithmetic of tile u and
 // only land in LDS (normalised by bn_qkv) after it, so the HBM latency of one tile hides under the sweep of the
 // previous one.  NCHL = channels fetched (q,k,v for the main pass; q,k for the statistics pass).
-template <int GP, int L, int AXIS, int NCHL>
+template <class F, int AXIS, int NCHL>
 struct SuperPrefetch {
-    using F = Fast3<GP, L>;
-    using Map = SuperMap<GP, L, AXIS>;
-    static constexpr int NTA = F::nta(AXIS);
+    static constexpr int L = F::LEN;
+    using Map = SuperMap<F, AXIS>;
+    static constexpr int NTA = F::nta(AXIS) * F::EPT;
     static_assert(NTA * NCHL <= 32, "prefetch registers");
     float v[NTA * NCHL];
 
@@ -370,14 +371,14 @@ struct SuperPrefetch {
 };
 
 // LDS -> global, `nch` channels starting at LDS channel lch0 (height axis: re-maps rows to lanes for coalescing).
-template <int GP, int L, int AXIS>
+template <class F, int AXIS>
 __device__ __forceinline__ void store_super(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
-                                            const AxialGeom& g, const SuperMap<GP, L, AXIS>& m) {
-    using F = Fast3<GP, L>;
+                                            const AxialGeom& g, const SuperMap<F, AXIS>& m) {
+    constexpr int L = F::LEN;
     float* base = dst + ((size_t)m.n0 * CH + ch0) * g.HW;                                   // uniform
     const int img = CH * g.HW;
 #pragma unroll
-    for (int t = 0; t < F::nta(AXIS); ++t) {
+    for (int t = 0; t < F::nta(AXIS) * F::EPT; ++t) {
         int lo, dn, pix;
         if (m.locate(g, t, lo, dn, pix)) {
             const unsigned off = (unsigned)(dn * img + pix) * 4u;
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
     int bad = 0;                                              // any row whose bound-referenced sum underflowed
     const int SSr = S_T * g.nt;                               // runtime super-tile (g.nt <= NT sub-tiles)
     const int nsup = (g.spg + SSr - 1) / SSr;
-    using Map = SuperMap<GP, L, AXIS>;
-    using PF = SuperPrefetch<GP, L, AXIS, NCH>;
+    using Map = SuperMap<F, AXIS>;
+    using PF = SuperPrefetch<F, AXIS, NCH>;
     // tiles of this workgroup: u = part, part + fparts, ...; (image, sequence-in-image) advance by a fixed step
     const unsigned step = (unsigned)g.fparts * SSr;
     const int dn_step = step / (unsigned)g.Bo, ds_step = step - dn_step * g.Bo;
@@ -645,11 +646,236 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
         }
         if constexpr (AXIS == 0) {
             __syncthreads();
-            store_super<GP, L, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
-            if (lse_out) store_super<GP, L, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
+            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
+            if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
         }
     }
     // (kept out of the row loop: a branch there makes LLVM sink the whole accumulator chain behind it)
+    if (!EXACT && bad) atomicOr(flag, 1u);
+    if (out_partials) {
+        float v[2 * OCG];
+#pragma unroll
+        for (int k = 0; k < OCG; ++k) { v[2 * k] = st_sum[k]; v[2 * k + 1] = st_sq[k]; }
+        __syncthreads();
+        block_sum<2 * OCG>(v, red, out_partials + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// Four rows per lane (gp = 2, large problems).  The one-row-per-lane kernel above is LDS-bandwidth bound: every
+// lane fetches 7 x 16 B per 4 columns (k, 2 v, 4 table windows).  Here a lane owns rows i0, i0+2, i0+4, i0+6 of a
+// sequence, so the k/v fetches are shared by four rows and the table windows of the four rows overlap
+// (y = j - i + L - 1 spans y0-6 .. y0+3): 15 x 16 B per 16 (row, column) pairs instead of 28 -- the kernel
+// becomes VALU bound.  Rows two apart keep every packed-FMA operand an even-aligned register pair: the pair
+// (column c, c+1), c even, of row r' sits at window offsets (6 + c - 2r', +1).  Lanes with odd i0 read table
+// copy 1 (U[x]), lanes with even i0 copy 0 (U[x-3]), which makes the window base a multiple of 4 floats for
+// both and -- with the copy stride a multiple of 64 floats -- puts the two copies' windows on disjoint banks.
+// --------------------------------------------------------------------------- //
+template <int L>
+struct Fast4 {
+    static constexpr int GP = 2, HQ = 1, NCH = 4, OCG = 4, LEN = L;
+    static constexpr int LPS = L / 4;                         // lanes per sequence
+    static constexpr int S_T = MEDT_THREADS / LPS;            // sequences per sub-tile
+    static constexpr int EPT = 4;                             // tile elements per thread and sub-tile
+    static constexpr int RS = (NCH + 1) * L + 4;
+    static constexpr int NT = 2;
+    static constexpr int CS = ((2 * L + 4 + 63) / 64) * 64;
+    static constexpr int nta(int axis) { return axis == 1 ? 1 : NT; }
+    static constexpr size_t lds_floats(int nt) { return (size_t)S_T * nt * RS + 256 + 8 * CS; }
+};
+
+int fast4_subtile_sequences(int L) { return MEDT_THREADS / (L / 4); }
+int fast4_max_subtiles(int axis) { return axis == 1 ? 1 : 2; }
+
+template <int AXIS, int L, bool EXACT>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
+                                                                  BnStats qs, BnStats ss,
+                                                                  const float* __restrict__ relative, GatePtrs gates,
+                                                                  float* __restrict__ stacked,
+                                                                  float* __restrict__ lse_out,
+                                                                  float* __restrict__ out_partials,
+                                                                  unsigned* __restrict__ flag) {
+    using F = Fast4<L>;
+    constexpr int NCH = F::NCH, OCG = F::OCG, RS = F::RS, CS = F::CS, S_T = F::S_T, LPS = F::LPS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* reg = smem;
+    float* red = reg + S_T * g.nt4 * RS;
+    float* tab = red + 256;
+    if (EXACT && flag && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // nothing to repair
+    const int grp = blockIdx.x / g.oparts, part = blockIdx.x - grp * g.oparts, hg = blockIdx.y;
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
+    const float a_qr = ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E;
+    const float a_kr = ss.scale[grp * g.SC + 2 * g.G + hg] * f_kr * MEDT_LOG2E;
+    {   // tables: row 0 = Rq, 1 = Rk (scaled), 2,3 = Rv; two copies each, column ordered (see stage_tables_cols)
+        constexpr int TL = 2 * L - 1;
+        for (int e = threadIdx.x; e < 8 * CS; e += MEDT_THREADS) {
+            const int rc = e / CS, x = e - rc * CS, row = rc >> 1, copy = rc & 1;
+            const int y = x - (copy ? 0 : 3);
+            float v = 0.f;
+            if (y >= 0 && y < TL) v = row == 1 ? a_kr * relative[TL + y] : relative[row * TL + (TL - 1 - y)];
+            tab[e] = v;
+        }
+    }
+    if (threadIdx.x < NCH) {                                  // bn_qkv's affine for this head group: LDS-resident
+        red[128 + threadIdx.x] = qs.scale[grp * 2 * g.C + hg * NCH + threadIdx.x];
+        red[160 + threadIdx.x] = qs.shift[grp * 2 * g.C + hg * NCH + threadIdx.x];
+    }
+    __syncthreads();
+    float tqmax, tkmax;                                       // max |entry| of Rq and of the scaled Rk (logit bound)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float a = 0.f, b = 0.f;
+        for (int x = threadIdx.x; x < 2 * L - 1; x += MEDT_THREADS) {
+            a = fmaxf(a, fabsf(tab[1 * CS + x]));
+            b = fmaxf(b, fabsf(tab[3 * CS + x]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+        if (lane == 0) { red[wave * 2] = a; red[wave * 2 + 1] = b; }
+        __syncthreads();
+        tqmax = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        tkmax = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    }
+    const float* sc = red + 128;
+    const float* sh = red + 160;
+    const int lsub = threadIdx.x / LPS, a = threadIdx.x % LPS, b = a & 1, i0 = 4 * (a & ~1) + b;
+    const float* tabl = tab + b * CS + (b ? L - 8 : L - 4) - 4 * (a & ~1);    // this lane's window at j0 = 0
+    float st_sum[OCG], st_sq[OCG];
+#pragma unroll
+    for (int k = 0; k < OCG; ++k) { st_sum[k] = 0.f; st_sq[k] = 0.f; }
+    int bad = 0;
+    const int SSr = S_T * g.nt4;
+    const int nsup = (g.spg + SSr - 1) / SSr;
+    using Map = SuperMap<F, AXIS>;
+    using PF = SuperPrefetch<F, AXIS, NCH>;
+    const unsigned step = (unsigned)g.oparts * SSr;
+    const int dn_step = step / (unsigned)g.Bo, ds_step = step - dn_step * g.Bo;
+    Map cur, nxt;
+    {
+        const unsigned q0 = (unsigned)part * SSr;
+        const int dn = q0 / (unsigned)g.Bo;
+        nxt.set(g, grp * g.npg + dn, q0 - dn * g.Bo, min(SSr, g.spg - (int)q0));
+    }
+    PF pf;
+    if (part < nsup) pf.issue(qkv_raw, g, hg, nxt);
+    for (int u = part; u < nsup; u += g.oparts) {
+        cur = nxt;
+        const int nseq = cur.nseq;
+        __syncthreads();                                       // previous super-tile fully stored / tables staged
+        pf.commit(reg, g, cur, sc, sh);
+        {
+            const int un = u + g.oparts;
+            int s0 = cur.s0 + ds_step, n0 = cur.n0 + dn_step;
+            if (s0 >= g.Bo) { s0 -= g.Bo; ++n0; }
+            if (un < nsup) {
+                nxt.set(g, n0, s0, min(SSr, g.spg - un * SSr));
+                pf.issue(qkv_raw, g, hg, nxt);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int sub = 0; sub < g.nt4; ++sub) {
+            const int ls = sub * S_T + lsub;
+            const bool active = ls < nseq;
+            float* sq = reg + ls * RS;                         // q | k | v0 | v1 rows of this sequence
+            float kmx = 0.f;
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kmx = fmaxf(kmx, fabsf(sq[L + i0 + 2 * r]));
+            }
+#pragma unroll
+            for (int o = LPS / 2; o > 0; o >>= 1) kmx = fmaxf(kmx, __shfl_xor(kmx, o, 64));
+            if (active) {
+                float qa[4], qb[4], m[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float q = sq[i0 + 2 * r];
+                    qa[r] = q * a_qk;
+                    qb[r] = q * a_qr;
+                    m[r] = EXACT ? -INFINITY
+                                 : g.bound_shift + fabsf(qa[r]) * kmx + fabsf(qb[r]) * tqmax + kmx * tkmax;
+                }
+                f2 l2[4], av0[4], av1[4], ae0[4], ae1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { l2[r] = av0[r] = av1[r] = ae0[r] = ae1[r] = (f2)(0.f); }
+                const float* kp = sq + L;
+                const float* vp = sq + 2 * L;
+#pragma unroll
+                for (int j0 = 0; j0 < L; j0 += 4) {
+                    const f4 k4 = *reinterpret_cast<const f4*>(kp + j0);
+                    const f4 v0 = *reinterpret_cast<const f4*>(vp + j0);
+                    const f4 v1 = *reinterpret_cast<const f4*>(vp + L + j0);
+                    f2 wq[6], wk[6], w0[6], w1[6];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const f4 xq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 4 * t);
+                        const f4 xk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 4 * t);
+                        const f4 x0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 4 * t);
+                        const f4 x1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 4 * t);
+                        wq[2 * t] = xq.lo; wq[2 * t + 1] = xq.hi;
+                        wk[2 * t] = xk.lo; wk[2 * t + 1] = xk.hi;
+                        w0[2 * t] = x0.lo; w0[2 * t + 1] = x0.hi;
+                        w1[2 * t] = x1.lo; w1[2 * t + 1] = x1.hi;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f2 fqa = (f2)(qa[r]), fqb = (f2)(qb[r]);
+                        if constexpr (EXACT) {
+                            f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + k4.lo * wk[3 - r]);
+                            f2 zhi = fqa * k4.hi + (fqb * wq[4 - r] + k4.hi * wk[4 - r]);
+                            const float mn = fmaxf(m[r], fmaxf(fmaxf(zlo.x, zlo.y), fmaxf(zhi.x, zhi.y)));
+                            const f2 alpha = (f2)(__builtin_amdgcn_exp2f(m[r] - mn));
+                            m[r] = mn;
+                            zlo -= (f2)(mn);
+                            zhi -= (f2)(mn);
+                            f2 plo, phi;
+                            plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
+                            phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
+                            l2[r] = l2[r] * alpha + (plo + phi);
+                            av0[r] = plo * v0.lo + (phi * v0.hi + av0[r] * alpha);
+                            av1[r] = plo * v1.lo + (phi * v1.hi + av1[r] * alpha);
+                            ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r] * alpha);
+                            ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r] * alpha);
+                        } else {
+                            const f2 zi = (f2)(-m[r]);
+                            const f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + (k4.lo * wk[3 - r] + zi));
+                            const f2 zhi = fqa * k4.hi + (fqb * wq[4 - r] + (k4.hi * wk[4 - r] + zi));
+                            f2 plo, phi;
+                            plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
+                            phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
+                            l2[r] += plo + phi;
+                            av0[r] = plo * v0.lo + (phi * v0.hi + av0[r]);
+                            av1[r] = plo * v1.lo + (phi * v1.hi + av1[r]);
+                            ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r]);
+                            ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // keep the unrolled chunks in order (register pressure)
+                }
+                // results replace this sequence's q|k|v rows in LDS: its lanes all sit in this wave and have issued
+                // every read of the sweep above (in-order LDS pipe)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float l = l2[r].x + l2[r].y;
+                    if (!EXACT) bad |= !(l > 1e-30f);
+                    const float inv = __builtin_amdgcn_rcpf(l);
+                    const float o[4] = {f_sv * (av0[r].x + av0[r].y) * inv, f_sve * (ae0[r].x + ae0[r].y) * inv,
+                                        f_sv * (av1[r].x + av1[r].y) * inv, f_sve * (ae1[r].x + ae1[r].y) * inv};
+#pragma unroll
+                    for (int k = 0; k < OCG; ++k) {
+                        sq[k * L + i0 + 2 * r] = o[k];
+                        st_sum[k] += o[k];
+                        st_sq[k] = fmaf(o[k], o[k], st_sq[k]);
+                    }
+                    sq[NCH * L + i0 + 2 * r] = m[r] + __log2f(l);
+                }
+            }
+        }
+        __syncthreads();
+        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
+        if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
+    }
     if (!EXACT && bad) atomicOr(flag, 1u);
     if (out_partials) {
         float v[2 * OCG];
@@ -685,8 +911,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
     f2 s_qk = (f2)(0.f), q_qk = (f2)(0.f), s_qr = (f2)(0.f), q_qr = (f2)(0.f), s_kr = (f2)(0.f), q_kr = (f2)(0.f);
     const int SSr = S_T * g.nt;                               // runtime super-tile (g.nt <= NT sub-tiles)
     const int nsup = (g.spg + SSr - 1) / SSr;
-    using Map = SuperMap<GP, L, AXIS>;
-    using PF = SuperPrefetch<GP, L, AXIS, GP>;                                          // q and k channels only
+    using Map = SuperMap<F, AXIS>;
+    using PF = SuperPrefetch<F, AXIS, GP>;                                          // q and k channels only
     const unsigned step = (unsigned)g.fparts * SSr;
     const int dn_step = step / (unsigned)g.Bo, ds_step = step - dn_step * g.Bo;
     Map cur, nxt;
@@ -811,6 +1037,32 @@ int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, B
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
 #define MEDT_K_EXACT(a, b, c) attn_fwd3_kernel<a, b, c, true>
 #define MEDT_K_BOUND(a, b, c) attn_fwd3_kernel<a, b, c, false>
+    if (g.rows4 && flag) {
+        // gp = 2, large problem: four rows per lane (VALU bound instead of LDS bound), same repair protocol
+#define MEDT_R4_LAUNCH(EX, AX, Lv)                                                                                   \
+    hipLaunchKernelGGL((attn_fwd4r_kernel<AX, Lv, EX>), dim3(g.groups * g.oparts, g.G), dim3(MEDT_THREADS),            \
+                       Fast4<Lv>::lds_floats(g.nt4) * sizeof(float), s, g, qkv_raw, qkv, sim, relative, gates, stacked, \
+                       lse, out_partials, flag)
+#define MEDT_R4_CASES(EX)                                                                                            \
+    switch (g.L * 2 + g.axis) {                                                                                      \
+        case 16 * 2 + 0: MEDT_R4_LAUNCH(EX, 0, 16); break;   case 16 * 2 + 1: MEDT_R4_LAUNCH(EX, 1, 16); break;        \
+        case 32 * 2 + 0: MEDT_R4_LAUNCH(EX, 0, 32); break;   case 32 * 2 + 1: MEDT_R4_LAUNCH(EX, 1, 32); break;        \
+        case 64 * 2 + 0: MEDT_R4_LAUNCH(EX, 0, 64); break;   case 64 * 2 + 1: MEDT_R4_LAUNCH(EX, 1, 64); break;        \
+        case 128 * 2 + 0: MEDT_R4_LAUNCH(EX, 0, 128); break; case 128 * 2 + 1: MEDT_R4_LAUNCH(EX, 1, 128); break;     \
+        default: set_error("rows4: no instantiation"); return MEDT_EUNSUPPORTED;                                     \
+    }
+        if (g.bound_path) {
+            if (hipMemsetAsync(flag, 0, sizeof(unsigned), s) != hipSuccess) { set_error("attn_fwd: memset failed"); return MEDT_ELAUNCH; }
+            MEDT_R4_CASES(false)
+            const int rc = launch_status("attn_fwd4r (bound)");
+            if (rc) return rc;
+            MEDT_R4_CASES(true)
+            return launch_status("attn_fwd4r (repair)");
+        }
+        flag = nullptr;
+        MEDT_R4_CASES(true)
+        return launch_status("attn_fwd4r");
+    }
     if (g.fast3 && g.bound_path && flag) {
         // large problems: bound-referenced softmax, then the (normally empty) repair pass
         if (hipMemsetAsync(flag, 0, sizeof(unsigned), s) != hipSuccess) { set_error("attn_fwd: memset failed"); return MEDT_ELAUNCH; }

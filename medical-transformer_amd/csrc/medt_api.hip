@@ -172,7 +172,7 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // logits + softmax + gated sv|sve, bn_output batch statistics                                 :157-178
     if ((rc = axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
                              tr ? w.part_out : nullptr, w.flag, s))) return rc;
-    if ((rc = bn_finalize(w.part_out, g.fparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
+    if ((rc = bn_finalize(w.part_out, g.oparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
                           st.out, s))) return rc;
     // bn_output + pair-sum + AvgPool                                                              :179-187
     return axial_out_fwd(*d, sv->stacked, st.out, y, s);

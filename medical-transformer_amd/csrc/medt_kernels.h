@@ -102,6 +102,7 @@ struct AxialGeom {
     int fast3;              // 1: compile-time-L persistent forward kernels (axial_fast.hip)
     int fparts;             // partial-statistics slots per group written by the forward L x L kernels
     int nt;                 // sub-tiles (of S_T sequences) per super-tile in the persistent kernels
+    int rows4, nt4, oparts; // 4-rows-per-lane forward kernel (gp = 2, large problems): its sub-tiles and out-partials slots
     int bound_path;         // 1: bound-referenced softmax + repair pass (large problems only: two extra graph nodes)
     float bound_shift;      // test hook (MEDT_DEBUG_BOUND_SHIFT): added to the softmax reference bound to force the exact fallback
     double sim_count;       // elements per bn_similarity channel per group = spg * L * L
@@ -118,6 +119,8 @@ int axial_logit_stats_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
 int fast3_max_subtiles(int gp, int L, int axis);
+int fast4_subtile_sequences(int L);
+int fast4_max_subtiles(int axis);
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // logit statistics: partials [group][tile][SC][2]

@@ -185,13 +185,14 @@ sys.path[:0] = [os.path.join(os.environ["MEDT_ROOT"], "medical-transformer_amd")
 import lib as droplib
 from oracle import medt_oracle as O
 dev = torch.device("cuda:0")
-for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, False)):
+for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, False), (16, 64, False), (16, 32, True),
+                    (16, 128, False), (16, 128, True), (16, 16, True), (16, 32, False)):
     layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=width).to(dev)
     st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 5)
     layer.load_state_dict(st)
     layer.train()
     g = torch.Generator().manual_seed(2)
-    x = torch.randn((2, C, 6, L) if width else (2, C, L, 6), generator=g)
+    x = torch.randn((3, C, 7, L) if width else (3, C, L, 7), generator=g)
     y = layer(x.to(dev))
     ost = O.clone_state({("m." + k): v for k, v in st.items()}, torch.float64)
     yo = O.axial_attention(x.double(), ost, "m", width, 1, True)
@@ -216,3 +217,10 @@ def test_softmax_bound_repair_pass(device):
     behind it redoes the launch.  MEDT_DEBUG_BOUND_SHIFT=400 pushes every bound 400 octaves up, so every launch
     is repaired: results must not change."""
     _run_layer_subprocess({"MEDT_BOUND_PATH": "1", "MEDT_DEBUG_BOUND_SHIFT": "400"})
+
+
+@pytest.mark.parametrize("bound,shift", [("0", "0"), ("1", "0"), ("1", "400")], ids=["exact", "bound", "repair"])
+def test_four_rows_per_lane_kernel(bound, shift, device):
+    """gp = 2 layers of large problems run the four-rows-per-lane forward kernel (MEDT_ROWS4=1 forces it on the
+    small test shapes, ragged tiles included): exact, bound-referenced and repaired variants, both axes, L = 16..128."""
+    _run_layer_subprocess({"MEDT_ROWS4": "1", "MEDT_BOUND_PATH": bound, "MEDT_DEBUG_BOUND_SHIFT": shift})
