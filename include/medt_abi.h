@@ -190,6 +190,12 @@ int medt_adam_step(float* p, const float* g, float* m, float* v, float* state, s
 /* out = a * (y > 0) elementwise (ReLU backward by output sign). */
 int medt_relu_mask(const float* a, const float* y, float* out, size_t n, void* stream);
 
+/* Scoring without MATLAB (performancemetrics_monuseg.m:19-84, performancemetrics_glas.m): per-image confusion
+ * counts of the prediction test.py writes (logits[:,1] >= threshold, test.py:131-137) against target > 0.
+ * logits (N,K,HW) float, target (N,HW) int64, counts (N,4) int32 = {tp, fp, fn, tn}; the call zeroes counts itself. */
+int medt_seg_counts(const float* logits, const int64_t* target, int32_t* counts, int N, int K, int HW, float threshold,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

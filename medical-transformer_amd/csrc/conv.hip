@@ -327,17 +327,12 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     const int Ktot = Cin * K * K, QS = wgrad_chunk(Cout, Ktot, NP);
     const int splits = (int)((NP + QS - 1) / QS);
     const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
+    if (splits == 1) scratch = dw;                         // a single slab is the result: no reduction pass
     if (conv_use_mfma(Cin, Cout, K, stride, NP) && Cout >= 64) {
         int rc = conv_wgrad_mfma(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits,
                                  N / groups, s);
         if (rc) return rc;
-        if (splits == 1) {
-            if (hipMemcpyAsync(dw, scratch, (size_t)Cout * Ktot * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-                set_error("conv_wgrad: copy failed"); return MEDT_ELAUNCH;
-            }
-            return MEDT_OK;
-        }
-        return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
+        return splits == 1 ? MEDT_OK : reduce_rows(scratch, splits, Cout * Ktot, dw, s);
     }
     {
         const int TO = wgrad_tile(Cout), TC = wgrad_tile(Ktot);
@@ -361,13 +356,7 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     }
     int rc = launch_status("conv_wgrad");
     if (rc) return rc;
-    if (splits == 1) {
-        if (hipMemcpyAsync(dw, scratch, (size_t)Cout * Ktot * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            set_error("conv_wgrad: copy failed"); return MEDT_ELAUNCH;
-        }
-        return MEDT_OK;
-    }
-    return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
+    return splits == 1 ? MEDT_OK : reduce_rows(scratch, splits, Cout * Ktot, dw, s);
 }
 
 // per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients); two stages, deterministic

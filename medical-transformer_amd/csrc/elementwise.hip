@@ -392,4 +392,50 @@ int adam_step(float* p, const float* g, float* m, float* v, float* state, size_t
     return launch_status("adam_step");
 }
 
+// --------------------------------------------------------------------------- //
+// Per-image confusion counts of a 2-class segmentation: prediction = logits[:,1] >= threshold (what test.py writes
+// as PNG, test.py:131-137), ground truth = target > 0.  counts[n] = {tp, fp, fn, tn} (integer atomics: exact and
+// order independent).  Replaces the per-pixel loops of performancemetrics_*.m.
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(MEDT_THREADS) void seg_counts_kernel(const float* __restrict__ logits,
+                                                                  const int64_t* __restrict__ target,
+                                                                  int* __restrict__ counts, int K, int HW,
+                                                                  float threshold) {
+    const int n = blockIdx.y;
+    const float* fg = logits + ((size_t)n * K + 1) * HW;
+    const int64_t* t = target + (size_t)n * HW;
+    int tp = 0, fp = 0, fn = 0, tn = 0;
+    for (int p = blockIdx.x * MEDT_THREADS + threadIdx.x; p < HW; p += gridDim.x * MEDT_THREADS) {
+        const bool pred = fg[p] >= threshold, gt = t[p] > 0;
+        tp += pred && gt;
+        fp += pred && !gt;
+        fn += !pred && gt;
+        tn += !pred && !gt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tp += __shfl_xor(tp, o, 64);
+        fp += __shfl_xor(fp, o, 64);
+        fn += __shfl_xor(fn, o, 64);
+        tn += __shfl_xor(tn, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counts + n * 4 + 0, tp);
+        atomicAdd(counts + n * 4 + 1, fp);
+        atomicAdd(counts + n * 4 + 2, fn);
+        atomicAdd(counts + n * 4 + 3, tn);
+    }
+}
+
+int seg_counts(const float* logits, const int64_t* target, int* counts, int N, int K, int HW, float threshold,
+               hipStream_t s) {
+    if (hipMemsetAsync(counts, 0, (size_t)N * 4 * sizeof(int), s) != hipSuccess) {
+        set_error("seg_counts: memset failed");
+        return MEDT_ELAUNCH;
+    }
+    const int parts = min(cdiv(HW, MEDT_THREADS), 64);
+    hipLaunchKernelGGL(seg_counts_kernel, dim3(parts, N), dim3(MEDT_THREADS), 0, s, logits, target, counts, K, HW, threshold);
+    return launch_status("seg_counts");
+}
+
 }  // namespace medt

@@ -402,5 +402,10 @@ int medt_relu_mask(const float* a, const float* y, float* out, size_t n, void* s
     if (!a || !y || !out) { set_error("relu_mask: null pointer"); return MEDT_EINVAL; }
     return relu_mask(a, y, out, n, (hipStream_t)stream);
 }
+int medt_seg_counts(const float* logits, const int64_t* target, int32_t* counts, int N, int K, int HW, float threshold,
+                    void* stream) {
+    if (!logits || !target || !counts || K < 2 || N < 1 || HW < 1) { set_error("seg_counts: bad arguments"); return MEDT_EINVAL; }
+    return seg_counts(logits, target, counts, N, K, HW, threshold, (hipStream_t)stream);
+}
 
 }  // extern "C"

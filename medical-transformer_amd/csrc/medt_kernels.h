@@ -14,11 +14,6 @@ int conv1x1_fwd(const float* x, const float* w, float* y, float* partials,
 // dx[n,c,p] = sum_o w[o,c] * val[n,o,p],  val = coef ? c0*dy + c1*raw + c2 : dy   (coef [group][Cout][3])
 int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const float* w, float* dx,
                      int N, int Cin, int Cout, int HW, int groups, hipStream_t s);
-// dw[o,c] = sum_{n,p} val[n,o,p] * x[n,c,p];  scratch holds conv1x1_bwd_weight_splits()*Cout*Cin floats.
-int conv1x1_bwd_weight_splits(int N, int HW);
-int conv1x1_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
-                       int N, int Cin, int Cout, int HW, int groups, hipStream_t s);
-
 // Batch-norm statistics: partials [group][parts_per_group][CH][2] -> mean/rstd/scale/shift per (group, ch),
 // running-stat recurrence over the groups in order.  training==0: fold the running stats instead.
 int bn_finalize(const float* partials, int parts_per_group, int groups, int CH, double count,
@@ -77,6 +72,7 @@ int bn_act_bwd_stats(const float* dy, const float* y, const float* z, BnStats st
 int bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, int N, int C, int HW, int groups,
                  hipStream_t s);
 int relu_mask(const float* a, const float* y, float* out, size_t total, hipStream_t s);
+int seg_counts(const float* logits, const int64_t* target, int* counts, int N, int K, int HW, float threshold, hipStream_t s);
 int relu_fwd(const float* x, float* y, size_t total, hipStream_t s);
 int up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, hipStream_t s);
 int up2x_relu_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, hipStream_t s);

@@ -169,76 +169,6 @@ int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const
 }
 
 // --------------------------------------------------------------------------- //
-// 1x1 convolution backward-weight:  dw[o,c] = sum_{n,p} val[n,o,p] * x[n,c,p]
-// 32x32 output tile per workgroup, split over pixel chunks, 64-pixel LDS steps.
-// --------------------------------------------------------------------------- //
-#define BW_PIX_PER_SPLIT 256
-__global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_weight_kernel(
-    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
-    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int Cout, int HW, int npg) {
-    __shared__ float A[32][65];
-    __shared__ float X[32][65];
-    const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const long NP = (long)N * HW;
-    const long q_begin = (long)blockIdx.z * BW_PIX_PER_SPLIT;
-    const long q_end = q_begin + BW_PIX_PER_SPLIT < NP ? q_begin + BW_PIX_PER_SPLIT : NP;
-    const int to = threadIdx.x >> 4, tc = threadIdx.x & 15;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
-        // stage 32 rows x 64 pixels of val and of x (lanes along pixels)
-        for (int e = threadIdx.x; e < 32 * 64; e += MEDT_THREADS) {
-            const int r = e >> 6, j = e & 63;
-            const long q = q0 + j;
-            float a = 0.f, b = 0.f;
-            if (q < q_end) {
-                const int n = (int)(q / HW), p = (int)(q - (long)n * HW);
-                if (o0 + r < Cout) {
-                    const size_t idx = ((size_t)n * Cout + o0 + r) * HW + p;
-                    a = dy[idx];
-                    if (coef) {
-                        const float* cf = coef + ((size_t)(n / npg) * Cout + o0 + r) * 3;
-                        a = fmaf(cf[0], a, fmaf(cf[1], raw[idx], cf[2]));
-                    }
-                }
-                if (c0 + r < Cin) b = x[((size_t)n * Cin + c0 + r) * HW + p];
-            }
-            A[r][j] = a;
-            X[r][j] = b;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const float a0 = A[to][j], a1 = A[to + 16][j], b0 = X[tc][j], b1 = X[tc + 16][j];
-            acc[0][0] = fmaf(a0, b0, acc[0][0]);
-            acc[0][1] = fmaf(a0, b1, acc[0][1]);
-            acc[1][0] = fmaf(a1, b0, acc[1][0]);
-            acc[1][1] = fmaf(a1, b1, acc[1][1]);
-        }
-        __syncthreads();
-    }
-    float* out = scratch + (size_t)blockIdx.z * Cout * Cin;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int o = o0 + to + 16 * a, c = c0 + tc + 16 * b;
-            if (o < Cout && c < Cin) out[o * Cin + c] = acc[a][b];
-        }
-}
-
-int conv1x1_bwd_weight_splits(int N, int HW) { return cdiv(N * HW, BW_PIX_PER_SPLIT); }
-
-int conv1x1_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
-                       int N, int Cin, int Cout, int HW, int groups, hipStream_t s) {
-    const int splits = conv1x1_bwd_weight_splits(N, HW);
-    hipLaunchKernelGGL(conv1x1_bwd_weight_kernel, dim3(cdiv(Cout, 32), cdiv(Cin, 32), splits), dim3(MEDT_THREADS), 0, s,
-                       dy, raw, coef, x, scratch, N, Cin, Cout, HW, N / groups);
-    int rc = launch_status("conv1x1_bwd_weight");
-    if (rc) return rc;
-    return reduce_rows(scratch, splits, Cout * Cin, dw, s);
-}
-
-// --------------------------------------------------------------------------- //
 // out[k] = sum_p in[p][k]      (deterministic: fixed order, no atomics)
 // --------------------------------------------------------------------------- //
 __global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_kernel(const float* __restrict__ in, int P, int K,

@@ -91,6 +91,7 @@ SIGNATURES = {
     "medt_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "medt_relu_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_seg_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }
 
 

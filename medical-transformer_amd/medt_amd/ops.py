@@ -215,3 +215,21 @@ class CrossEntropyFn(torch.autograd.Function):
 def cross_entropy(logits, target, ignore_index=-100):
     """F.cross_entropy(logits, target) with mean reduction (what LogNLLLoss.forward computes, metrics.py:17-20)."""
     return CrossEntropyFn.apply(logits, target, ignore_index)
+
+
+# --------------------------------------------------------------------------- #
+# segmentation scoring (replaces performancemetrics_*.m)
+# --------------------------------------------------------------------------- #
+def seg_counts(logits, target, threshold=0.5):
+    """(N,K,H,W) logits, (N,H,W) int64 labels -> (N,4) int32 {tp, fp, fn, tn} of `logits[:,1] >= threshold` vs
+    `target > 0`, counted on the device."""
+    _require_device(logits)
+    logits, target = logits.contiguous(), target.contiguous()
+    if target.dtype != torch.int64:
+        raise L.MedtError("seg_counts: int64 label maps expected")
+    N, K = logits.shape[0], logits.shape[1]
+    HW = logits[0, 0].numel()
+    counts = torch.empty((N, 4), device=logits.device, dtype=torch.int32)
+    L.check(L.lib().medt_seg_counts(logits.data_ptr(), target.data_ptr(), counts.data_ptr(), N, K, HW, float(threshold),
+                                    _stream()), "medt_seg_counts")
+    return counts

@@ -51,3 +51,20 @@ def make_weighted_metric(classwise_metric):
 
 jaccard_index = make_weighted_metric(classwise_iou)
 f1_score = make_weighted_metric(classwise_f1)
+
+
+# --------------------------------------------------------------------------- #
+# Dataset scores without MATLAB
+# --------------------------------------------------------------------------- #
+def segmentation_scores(counts):
+    """Per-image F1 / IoU / pixel accuracy from (N,4) {tp, fp, fn, tn} counts, with the conventions of the reference's
+    scoring scripts (performancemetrics_monuseg.m:68-78): F = 2tp/(2tp+fp+fn), IoU = tp/(tp+fp+fn),
+    PA = tp/(tp+fn) (their `tp/ttp`), and an image without a single true positive scores 1 on all three."""
+    c = counts.detach().to("cpu").double()
+    tp, fp, fn = c[:, 0], c[:, 1], c[:, 2]
+    one = tp == 0
+    f1 = 2 * tp / (2 * tp + fp + fn).clamp_min(1)
+    iou = tp / (tp + fp + fn).clamp_min(1)
+    pa = tp / (tp + fn).clamp_min(1)
+    f1[one], iou[one], pa[one] = 1.0, 1.0, 1.0
+    return f1, iou, pa

@@ -11,6 +11,8 @@ import torch
 from torch.utils.data import DataLoader
 
 import lib
+import medt_amd
+import metrics
 from medt_amd.data import imwrite
 
 parser = argparse.ArgumentParser(description='MedT')
@@ -59,12 +61,19 @@ def main():
     model.eval()
     fulldir = args.direc + "/"
     os.makedirs(fulldir, exist_ok=True)
+    scores = []
     for batch_idx, (X_batch, y_batch, *rest) in enumerate(valloader):
         image_filename = rest[0][0] if isinstance(rest[0][0], str) else '%s.png' % str(batch_idx + 1).zfill(3)
         with torch.no_grad():
             y_out = model(X_batch.to(device))
+            # what performancemetrics_*.m computes offline from the PNGs, counted on the device
+            scores.append(medt_amd.seg_counts(y_out, y_batch.to(device).long().reshape(y_out.shape[0], *y_out.shape[2:])))
         yHaT = (y_out.detach().cpu().numpy() >= 0.5).astype(np.uint8) * 255
         imwrite(fulldir + image_filename, yHaT[0, 1, :, :])
+    if scores:
+        f1, iou, pa = metrics.segmentation_scores(torch.cat(scores))
+        print("images {}  F1 {:.4f}  mIoU {:.4f}  PA {:.4f}".format(len(f1), f1.mean().item(), iou.mean().item(),
+                                                                   pa.mean().item()))
 
 
 if __name__ == "__main__":

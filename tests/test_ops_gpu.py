@@ -202,3 +202,39 @@ def test_flat_adam_matches_torch_adam(device):
         o_mine.step()
     for a, b in zip(ref + [unused_ref, late_ref], mine + [unused_mine, late_mine]):
         _cmp(b, a, 1e-5)
+
+
+def test_seg_counts_and_scores(device):
+    """Device-side confusion counts + the scoring conventions of performancemetrics_monuseg.m (per-pixel loops)."""
+    import medt_amd
+    import metrics
+    torch.manual_seed(4)
+    logits = torch.randn(5, 2, 37, 41)
+    logits[1, 1] = -3.0                                   # an image without any predicted foreground (tp = 0 -> scores 1)
+    logits[2, 1, 0, 0] = 0.5                              # threshold is inclusive (>= 0.5, test.py)
+    target = torch.randint(0, 2, (5, 37, 41))
+    target[3] = 0
+    counts = medt_amd.seg_counts(logits.to(device), target.to(device)).cpu()
+    pred, gt = logits[:, 1] >= 0.5, target > 0
+    want = torch.stack([(pred & gt).flatten(1).sum(1), (pred & ~gt).flatten(1).sum(1), (~pred & gt).flatten(1).sum(1),
+                        (~pred & ~gt).flatten(1).sum(1)], 1).int()
+    assert torch.equal(counts, want)
+    f1, iou, pa = metrics.segmentation_scores(counts)
+    for n in range(5):                                    # the MATLAB loop, literally
+        tp = fp = fn = uni = ttp = 0
+        for p_, g_ in zip(pred[n].flatten().tolist(), gt[n].flatten().tolist()):
+            if not p_:
+                if g_:
+                    fp += 1; uni += 1; ttp += 1           # (their "fp" is a missed foreground pixel)
+            else:
+                if g_:
+                    tp += 1; ttp += 1
+                else:
+                    fn += 1
+                uni += 1
+        if tp:
+            assert abs(f1[n].item() - 2 * tp / (2 * tp + fp + fn)) < 1e-12
+            assert abs(iou[n].item() - tp / uni) < 1e-12
+            assert abs(pa[n].item() - tp / ttp) < 1e-12
+        else:
+            assert f1[n].item() == iou[n].item() == pa[n].item() == 1.0
