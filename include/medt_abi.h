@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 3
+#define MEDT_ABI_VERSION 4
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -116,12 +116,8 @@ int medt_axial_layer_fwd(const medt_axial_desc*, const medt_axial_params*, const
  * desc.training == 0 the BatchNorms are the affine maps of their running stats. */
 int medt_axial_layer_bwd(const medt_axial_desc*, const medt_axial_params*, const float* x, const float* y,
                          const float* dy, const medt_axial_saved*, float* dx, const medt_axial_grads*,
-                         void* workspace, size_t workspace_bytes, void* stream, void* aux_stream);
-/* y: forward output, needed iff out_relu.
- * aux_stream (may be NULL): the parameter-gradient tail (weight gradient GEMM, relative-table / gate reductions) is
- * not on the critical path of backpropagation; when given, it is forked onto aux_stream behind an event recorded on
- * `stream` (capturable).  The caller joins aux_stream before it reads the parameter gradients and keeps the
- * workspace / inputs alive until then. */
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* y: forward output, needed iff out_relu. */
 
 /* The two L x L stages on their own, for benchmarks / profiling (bench.py's roofline leg).
  * qkv_raw -> [logit statistics partials] and qkv_raw -> stacked, lse, given the BN
@@ -159,7 +155,7 @@ int medt_conv_block_fwd(const medt_conv_desc*, const float* x, const float* w, c
 int medt_conv_block_bwd(const medt_conv_desc*, const float* x, const float* w, const medt_bn_ptrs* bn,
                         const float* z, const float* y, const float* stats, const float* dy,
                         float* dx, float* dw, float* dbias, float* dbn_weight, float* dbn_bias, float* dres,
-                        void* workspace, size_t workspace_bytes, void* stream, void* aux_stream /* as above; dw, dbias */);
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* y = relu(bilinear_x2(x)) + skip       F.interpolate(scale_factor=(2,2), mode='bilinear') + relu + torch.add
  * (lib/models/axialnet.py:493-501, 650-652, 690-698).  x (NC,H,W) -> y (NC,2H,2W); skip may be NULL.

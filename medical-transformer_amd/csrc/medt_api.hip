@@ -69,18 +69,6 @@ struct BwdWs {
     }
 };
 
-// Make `to` wait for everything enqueued on `from` so far (event fork; capturable into a hipGraph).
-static int fork_stream(hipStream_t from, hipStream_t to) {
-    hipEvent_t ev;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, from) != hipSuccess ||
-        hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
-        set_error("fork_stream: %s", hipGetErrorString(hipGetLastError()));
-        return MEDT_ELAUNCH;
-    }
-    (void)hipEventDestroy(ev);
-    return MEDT_OK;
-}
-
 static int check_common(const medt_axial_desc* d, const medt_axial_params* p, const medt_axial_saved* sv, AxialGeom* g) {
     if (!d || !p || !sv) { set_error("null descriptor / params / saved"); return MEDT_EINVAL; }
     int rc = axial_geom(*d, g);
@@ -160,6 +148,15 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
     const int tr = d->training ? 1 : 0, ppg = conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1);
+    if (wopos_small_ok(g, *d)) {
+        // tiny position-free layers (MedT's local branch): the whole layer in one workgroup per (BN group, head),
+        // then one finalisation launch for the saved statistics and the ordered running-stat updates
+        if ((rc = wopos_small_fwd(g, *d, *p, x, y, sv->qkv_raw, sv->stacked, sv->lse, w.part_qkv, w.part_sim, w.part_out,
+                                  s))) return rc;
+        return bn_finalize3(w.part_qkv, 2 * g.C, g.row_count, p->bn_qkv, st.qkv, w.part_sim, g.SC, g.sim_count,
+                            p->bn_similarity, st.sim, w.part_out, g.OC, g.row_count, p->bn_output, st.out, 1, g.groups,
+                            d->momentum, d->eps, tr, s);
+    }
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
     if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, sv->qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
                          2 * g.C, 1, 1, 0, 0, g.groups, s))) return rc;
@@ -180,7 +177,7 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
 
 int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, const float* y,
                          const float* dy, const medt_axial_saved* sv, float* dx, const medt_axial_grads* gr, void* ws,
-                         size_t ws_bytes, void* stream, void* aux_stream) {
+                         size_t ws_bytes, void* stream) {
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
@@ -218,11 +215,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // bn_qkv backward, qkv_transform backward
     if ((rc = bn_bwd_finalize(w.part_qb, g.tpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
-    hipStream_t sa = s;                       // parameter-gradient tail: off the critical path when aux_stream is given
-    if (aux_stream && (hipStream_t)aux_stream != s) {
-        sa = (hipStream_t)aux_stream;
-        if ((rc = fork_stream(s, sa))) return rc;
-    }
+    const hipStream_t sa = s;
     if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;
     if ((rc = conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
@@ -323,8 +316,7 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
 
 int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w, const medt_bn_ptrs* bn, const float* z,
                         const float* y, const float* stats, const float* dy, float* dx, float* dw, float* dbias,
-                        float* dbn_weight, float* dbn_bias, float* dres, void* ws, size_t ws_bytes, void* stream,
-                        void* aux_stream) {
+                        float* dbn_weight, float* dbn_bias, float* dres, void* ws, size_t ws_bytes, void* stream) {
     ConvGeom g;
     int rc = conv_geom(d, &g);
     if (rc) return rc;
@@ -350,11 +342,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     } else {
         grad_out = dy;
     }
-    hipStream_t sa = s;
-    if (aux_stream && (hipStream_t)aux_stream != s && dx) {       // nothing to overlap with when dx is not needed
-        sa = (hipStream_t)aux_stream;
-        if ((rc = fork_stream(s, sa))) return rc;
-    }
+    const hipStream_t sa = s;
     if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
     if (d->has_bias && (rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, sa))) return rc;
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,

@@ -20,6 +20,10 @@ int bn_finalize(const float* partials, int parts_per_group, int groups, int CH, 
                 const medt_bn_ptrs& bn, float momentum, float eps, int training, BnStats out, hipStream_t s);
 // Backward: partials [group][parts][CH][2] = [sum d, sum d*xhat] (d still to be multiplied by dscale).
 // Writes coef[group][CH][3] with  dx = c0*d + c1*x + c2,  and dweight[CH], dbias[CH].
+int bn_finalize3(const float* p0, int CH0, double n0, const medt_bn_ptrs& bn0, BnStats o0,
+                 const float* p1, int CH1, double n1, const medt_bn_ptrs& bn1, BnStats o1,
+                 const float* p2, int CH2, double n2, const medt_bn_ptrs& bn2, BnStats o2,
+                 int ppg, int groups, float momentum, float eps, int training, hipStream_t s);
 int bn_bwd_finalize(const float* partials, int parts_per_group, int groups, int CH, double count, float dscale,
                     BnStats st, const float* weight, int training, float* coef, float* dweight, float* dbias,
                     hipStream_t s);
@@ -117,6 +121,11 @@ int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, B
 int fast3_max_subtiles(int gp, int L, int axis);
 int fast4_subtile_sequences(int L);
 int fast4_max_subtiles(int axis);
+// axial_small.hip: a whole position-free layer per (BN group, head) workgroup
+bool wopos_small_ok(const AxialGeom& g, const medt_axial_desc& d);
+int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* x, float* y,
+                    float* qkv_raw, float* stacked, float* lse, float* part_q, float* part_s, float* part_o,
+                    hipStream_t s);
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // logit statistics: partials [group][tile][SC][2]

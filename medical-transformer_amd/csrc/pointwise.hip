@@ -230,12 +230,12 @@ __device__ __forceinline__ bool group_sums(const float* __restrict__ partials, i
     return true;
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partials, int ppg, int groups, int CH,
-                                                         double count, const float* __restrict__ weight,
-                                                         const float* __restrict__ bias, float* running_mean,
-                                                         float* running_var, int64_t* nbt, float momentum, float eps,
-                                                         int training, BnStats out) {
-    const int ch = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict__ partials, int ppg, int groups, int CH,
+                                                 double count, const float* __restrict__ weight,
+                                                 const float* __restrict__ bias, float* running_mean,
+                                                 float* running_var, int64_t* nbt, float momentum, float eps,
+                                                 int training, BnStats out) {
+    const int lane = threadIdx.x;
     const float g = weight[ch], b = bias[ch];
     if (!training) {
         const float  mean = running_mean[ch];
@@ -296,6 +296,56 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
         if (running_var) running_var[ch] = (float)rv;
         if (ch == 0 && nbt) *nbt += groups;
     }
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partials, int ppg, int groups, int CH,
+                                                         double count, const float* __restrict__ weight,
+                                                         const float* __restrict__ bias, float* running_mean,
+                                                         float* running_var, int64_t* nbt, float momentum, float eps,
+                                                         int training, BnStats out) {
+    bn_finalize_body(blockIdx.x, partials, ppg, groups, CH, count, weight, bias, running_mean, running_var, nbt, momentum,
+                     eps, training, out);
+}
+
+// Three BatchNorms of one layer in one launch (the fused small-layer forward, axial_small.hip): block -> (BN, channel).
+struct BnFin {
+    const float* partials;
+    int ppg, CH;
+    double count;
+    const float *weight, *bias;
+    float *running_mean, *running_var;
+    int64_t* nbt;
+    BnStats out;
+};
+__global__ __launch_bounds__(64) void bn_finalize3_kernel(BnFin a, BnFin b, BnFin c, int groups, float momentum, float eps,
+                                                          int training) {
+    int ch = blockIdx.x;
+    const BnFin* f = &a;
+    if (ch >= a.CH) {
+        ch -= a.CH;
+        f = &b;
+        if (ch >= b.CH) { ch -= b.CH; f = &c; }
+    }
+    bn_finalize_body(ch, f->partials, f->ppg, groups, f->CH, f->count, f->weight, f->bias, f->running_mean, f->running_var,
+                     f->nbt, momentum, eps, training, f->out);
+}
+
+static BnFin make_fin(const float* partials, int ppg, int CH, double count, const medt_bn_ptrs& bn, BnStats out) {
+    BnFin f;
+    f.partials = partials; f.ppg = ppg; f.CH = CH; f.count = count;
+    f.weight = bn.weight; f.bias = bn.bias; f.running_mean = bn.running_mean; f.running_var = bn.running_var;
+    f.nbt = bn.num_batches_tracked; f.out = out;
+    return f;
+}
+
+int bn_finalize3(const float* p0, int CH0, double n0, const medt_bn_ptrs& bn0, BnStats o0,
+                 const float* p1, int CH1, double n1, const medt_bn_ptrs& bn1, BnStats o1,
+                 const float* p2, int CH2, double n2, const medt_bn_ptrs& bn2, BnStats o2,
+                 int ppg, int groups, float momentum, float eps, int training, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize3_kernel, dim3(CH0 + CH1 + CH2), dim3(64), 0, s, make_fin(p0, ppg, CH0, n0, bn0, o0),
+                       make_fin(p1, ppg, CH1, n1, bn1, o1), make_fin(p2, ppg, CH2, n2, bn2, o2), groups, momentum, eps,
+                       training);
+    return launch_status("bn_finalize3");
 }
 
 int bn_finalize(const float* partials, int ppg, int groups, int CH, double count, const medt_bn_ptrs& bn,

@@ -64,7 +64,7 @@ SIGNATURES = {
                                        C.POINTER(AxialSaved), C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_axial_layer_bwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(AxialSaved), C.c_void_p, C.POINTER(AxialGrads), C.c_void_p,
-                                       C.c_size_t, C.c_void_p, C.c_void_p]),
+                                       C.c_size_t, C.c_void_p]),
     "medt_axial_core_stats": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved),
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_axial_core_fwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved),
@@ -107,7 +107,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.medt_abi_version() != 3:
+        if l.medt_abi_version() != 4:
             raise MedtError("libmedt_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -120,44 +120,3 @@ def check(rc: int, what: str):
 
 def ptr(t):
     return None if t is None else t.data_ptr()
-
-
-# --------------------------------------------------------------------------- #
-# auxiliary stream for the parameter-gradient tail of the backward entry points
-# --------------------------------------------------------------------------- #
-# Off by default: measured neutral on MI355X (6.30 vs 6.32 ms/step -- the weight-gradient kernels are not on the
-# critical path once the two branches already overlap), and one more stream is one more thing to get wrong.
-AUX_ENABLED = os.environ.get("MEDT_WGRAD_STREAM", "0") == "1"
-_aux = {}
-_join_queued = [False]
-
-
-def aux_stream(device):
-    """Per-device side stream that receives weight-gradient work; joined once at the end of each backward pass."""
-    if not AUX_ENABLED:
-        return None
-    key = (device.type, device.index)
-    st = _aux.get(key)
-    if st is None:
-        st = _aux[key] = torch.cuda.Stream(device=device)
-    if not _join_queued[0]:
-        _join_queued[0] = True
-
-        def _join():
-            _join_queued[0] = False
-            for s2 in _aux.values():
-                torch.cuda.current_stream(s2.device).wait_stream(s2)
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_join)
-        except RuntimeError:              # not inside a backward pass (direct call in a test): join immediately after
-            _join_queued[0] = False
-            return None
-    return st
-
-
-def keep_alive(aux, *tensors):
-    """The tensors are still read on `aux` after the caller's backward() returns."""
-    if aux is not None:
-        for t in tensors:
-            if t is not None:
-                t.record_stream(aux)

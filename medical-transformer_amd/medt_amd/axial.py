@@ -114,11 +114,9 @@ class AxialAttentionFn(torch.autograd.Function):
         ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         stream = torch.cuda.current_stream().cuda_stream
-        aux = L.aux_stream(dev)
         L.check(lib.medt_axial_layer_bwd(C.byref(desc), C.byref(params), x.data_ptr(), L.ptr(y), dy.data_ptr(), C.byref(saved),
-                                         dx.data_ptr(), C.byref(grads), ws.data_ptr(), ws_bytes, stream,
-                                         aux.cuda_stream if aux is not None else None), "medt_axial_layer_bwd")
-        L.keep_alive(aux, ws, x, qkv_raw, flat)
+                                         dx.data_ptr(), C.byref(grads), ws.data_ptr(), ws_bytes, stream),
+                "medt_axial_layer_bwd")
         dw = parts[0].view_as(w_qkv)
         drel = parts[7].view_as(relative) if relative is not None else None
         if want_gates:

@@ -86,13 +86,11 @@ class ConvBlockFn(torch.autograd.Function):
         ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         bnp = _bn_ptrs(cfg.bn, False) if has_bn else None
-        aux = L.aux_stream(dev) if need_dx else None
         L.check(lib.medt_conv_block_bwd(C.byref(desc), x.data_ptr(), w.data_ptr(), C.byref(bnp) if has_bn else None,
                                         L.ptr(z), L.ptr(y), L.ptr(stats), dy.data_ptr(), L.ptr(dx), dw.data_ptr(),
                                         L.ptr(dbias), dbn[0].data_ptr() if has_bn else None,
                                         dbn[1].data_ptr() if has_bn else None, L.ptr(dres), ws.data_ptr(), ws_bytes,
-                                        _stream(), aux.cuda_stream if aux is not None else None), "medt_conv_block_bwd")
-        L.keep_alive(aux, ws, x, dy, dw, dbias)
+                                        _stream()), "medt_conv_block_bwd")
         return (dx, dw, dbias, dbn[0] if has_bn else None, dbn[1] if has_bn else None, dres, None, None)
 
 
