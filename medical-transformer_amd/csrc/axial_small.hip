@@ -292,4 +292,356 @@ int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axi
     return launch_status("wopos_small_fwd");
 }
 
+// --------------------------------------------------------------------------- //
+// Backward of the same layers, core part: from dy to the gradient at the output of qkv_transform (before the
+// bn_qkv backward affine, which the conv kernels apply on load), again one workgroup per (BN group, head).
+// Replaces relu_mask, axial_out_bwd_stats, attn_bwd_stats, attn_bwd and the in-between finalisations' critical-path
+// role: the BatchNorm backward coefficients of bn_output and bn_similarity are group-local and computed here; the
+// per-group partial sums still go out so the finalisation kernels produce the parameter gradients (sum over the
+// groups) and bn_qkv's coefficients exactly as on the layer-by-layer path.
+// --------------------------------------------------------------------------- //
+struct SmallBwdArgs {
+    const float *qkv_raw, *stacked, *lse, *dy, *y;      // y: forward output, only read when out_relu
+    BnStats sq, ss, so;                                 // saved statistics of bn_qkv, bn_similarity, bn_output
+    const float *w_out, *w_sim;                         // bn_output.weight (C), bn_similarity.weight (G)
+    float *dqkv;                                        // (N, 2C, H, W)
+    float *part_ob, *part_sb, *part_qb;                 // [groups][C][2], [groups][G][4], [groups][2C][2]
+    int N, C, H, W, G, npg, stride, training, out_relu;
+};
+
+template <int AXIS, int L, int GP>
+__global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdArgs a) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP, R = L == 16 ? 4 : 1;     // rows (positions) per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = blockIdx.x, hg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, W = a.W, HW = a.H * a.W, P = a.npg * HW, G = a.G;
+    const int n0 = grp * a.npg;
+    float* Q = smem;                    // [NCH][P] normalised q | k | v; later the gradients of the same rows
+    float* D = Q + NCH * P;             // [GP][P]  d(loss)/d(sv)
+    float* lse = D + GP * P;            // [P]
+    float* dlt = lse + P;               // [P]      Delta_i = sum_c dsv[c,i] sv[c,i]
+    float* red = dlt + P;               // [256]    reduction scratch
+    float* cf = red + 256;              // [3*GP] bn_output coefficients, then [8] bn_similarity (e, u, w)
+    const int st = a.stride, Ho = a.H / st, Wo = a.W / st;
+    const double cnt = (double)P;
+
+    // normalised q|k|v of this head and the row log-sum-exps
+    for (int item = tid; item < NCH * P; item += MEDT_THREADS) {
+        const int oc = item / P, q = item - oc * P, ni = q / HW, p = q - ni * HW, ch = hg * NCH + oc;
+        Q[item] = fmaf(a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p], a.sq.scale[grp * 2 * C + ch],
+                       a.sq.shift[grp * 2 * C + ch]);
+    }
+    for (int q = tid; q < P; q += MEDT_THREADS) {
+        const int ni = q / HW, p = q - ni * HW;
+        lse[q] = a.lse[((size_t)(n0 + ni) * G + hg) * HW + p];
+    }
+    // 1. AvgPool2d + ReLU-mask + bn_output backward                                        (axialnet.py:242-253)
+    float gy[R][GP], sv[R][GP];
+    {
+        float v[2 * GP];
+#pragma unroll
+        for (int k = 0; k < 2 * GP; ++k) v[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = tid + r * MEDT_THREADS;
+            if (q < P) {
+                const int ni = q / HW, p = q - ni * HW, h = p / W, w = p - h * W;
+                const size_t po = (size_t)(h / st) * Wo + (w / st);
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    const int ch = hg * GP + c;
+                    const size_t yo = ((size_t)(n0 + ni) * C + ch) * Ho * Wo + po;
+                    float d = a.dy[yo];
+                    if (a.out_relu && !(a.y[yo] > 0.f)) d = 0.f;
+                    const float s = a.stacked[((size_t)(n0 + ni) * C + ch) * HW + p];
+                    gy[r][c] = d;
+                    sv[r][c] = s;
+                    v[2 * c] += d;
+                    v[2 * c + 1] += d * ((s - a.so.mean[grp * C + ch]) * a.so.rstd[grp * C + ch]);
+                }
+            }
+        }
+        block_sum<2 * GP>(v, red, red + 128);
+        if (tid < GP) {
+            const int ch = hg * GP + tid;
+            const float dscale = 1.f / (float)(st * st);
+            const float r1 = red[128 + 2 * tid], r2 = red[128 + 2 * tid + 1];
+            a.part_ob[((size_t)grp * C + ch) * 2] = r1;
+            a.part_ob[((size_t)grp * C + ch) * 2 + 1] = r2;
+            // same arithmetic as bn_bwd_finalize_kernel (pointwise.hip)
+            const double s1 = (double)r1 * dscale, s2 = (double)r2 * dscale;
+            const double mean = a.so.mean[grp * C + ch], rstd = a.so.rstd[grp * C + ch], A = (double)a.w_out[ch] * rstd;
+            cf[3 * tid] = (float)(A * dscale);
+            if (a.training) {
+                const double m1 = s1 / cnt, m2 = s2 / cnt;
+                cf[3 * tid + 1] = (float)(-A * rstd * m2);
+                cf[3 * tid + 2] = (float)(A * (rstd * mean * m2 - m1));
+            } else {
+                cf[3 * tid + 1] = 0.f;
+                cf[3 * tid + 2] = 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = tid + r * MEDT_THREADS;
+            if (q < P) {
+                float dl = 0.f;
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    const float d = fmaf(cf[3 * c], gy[r][c], fmaf(cf[3 * c + 1], sv[r][c], cf[3 * c + 2]));
+                    D[c * P + q] = d;
+                    dl = fmaf(d, sv[r][c], dl);
+                }
+                dlt[q] = dl;
+            }
+        }
+    }
+    __syncthreads();
+    const int sj = AXIS == 1 ? 1 : W;
+    const float a_qk = a.ss.scale[grp * G + hg] * MEDT_LOG2E;
+    // everything one (i, j) pair contributes; qi/kj: positions of query i and key j
+    auto pair = [&](int qi, int kj, float& S, float& Pij, float& dZ) {
+        S = 0.f;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) S = fmaf(Q[c * P + qi], Q[(HQ + c) * P + kj], S);
+        Pij = __builtin_amdgcn_exp2f(fmaf(S, a_qk, -lse[qi]));
+        float dP = 0.f;
+#pragma unroll
+        for (int c = 0; c < GP; ++c) dP = fmaf(D[c * P + qi], Q[(GP + c) * P + kj], dP);
+        dZ = Pij * (dP - dlt[qi]);
+    };
+    // 2. bn_similarity backward statistics: sum dZ, sum dZ * S over the group              (:236)
+    {
+        float v[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = tid + r * MEDT_THREADS;
+            if (q < P) {
+                const int i = AXIS == 1 ? q % W : (q % HW) / W, base = q - i * sj;
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    float S, Pij, dZ;
+                    pair(q, base + j * sj, S, Pij, dZ);
+                    v[0] += dZ;
+                    v[1] = fmaf(dZ, S, v[1]);
+                }
+            }
+        }
+        block_sum<2>(v, red, red + 128);
+        if (tid == 0) {
+            const float a0f = red[128], axf = red[129];
+            float* ps = a.part_sb + ((size_t)grp * G + hg) * 4;
+            ps[0] = a0f; ps[1] = axf; ps[2] = 0.f; ps[3] = 0.f;
+            // same arithmetic as sim_bwd_finalize_kernel / sim_coef (axial_core.hip)
+            const double a0 = a0f, ax = axf, count = cnt * L;
+            const double mean = a.ss.mean[grp * G + hg], rstd = a.ss.rstd[grp * G + hg];
+            const double sxh = rstd * (ax - mean * a0), e = (double)a.w_sim[hg] * rstd;
+            cf[64] = (float)e;
+            if (a.training) {
+                const double m1 = a0 / count, m2 = sxh / count, u = -e * rstd * m2;
+                cf[65] = (float)u;
+                cf[66] = (float)(-e * m1 - u * mean);
+            } else {
+                cf[65] = 0.f;
+                cf[66] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    const float ce = cf[64], cu = cf[65], cw = cf[66];
+    // 3. dq (this thread's positions as queries) and dk, dv (as keys)                       (:232-241)
+    float gq[R][NCH];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) gq[r][k] = 0.f;
+        const int q = tid + r * MEDT_THREADS;
+        if (q < P) {
+            const int i = AXIS == 1 ? q % W : (q % HW) / W, base = q - i * sj;
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const int o = base + j * sj;
+                float S, Pij, dZ;
+                pair(q, o, S, Pij, dZ);                       // o as key of query q
+                const float dS = fmaf(ce, dZ, fmaf(cu, S, cw));
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) gq[r][c] = fmaf(dS, Q[(HQ + c) * P + o], gq[r][c]);
+                pair(o, q, S, Pij, dZ);                       // q as key of query o
+                const float dS2 = fmaf(ce, dZ, fmaf(cu, S, cw));
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) gq[r][HQ + c] = fmaf(dS2, Q[c * P + o], gq[r][HQ + c]);
+#pragma unroll
+                for (int c = 0; c < GP; ++c) gq[r][GP + c] = fmaf(Pij, D[c * P + o], gq[r][GP + c]);
+            }
+        }
+    }
+    __syncthreads();                                           // Q is free: it now receives the gradients
+    // 4. gradient at the bn_qkv output -> global, and its bn_qkv backward statistics        (:228)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = tid + r * MEDT_THREADS;
+        if (q < P) {
+            const int ni = q / HW, p = q - ni * HW;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                Q[k * P + q] = gq[r][k];
+                a.dqkv[((size_t)(n0 + ni) * 2 * C + hg * NCH + k) * HW + p] = gq[r][k];
+            }
+        }
+    }
+    __syncthreads();
+    for (int oc = wave; oc < NCH; oc += MEDT_WAVES) {
+        const int ch = hg * NCH + oc;
+        const float mean = a.sq.mean[grp * 2 * C + ch], rstd = a.sq.rstd[grp * 2 * C + ch];
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = lane; q < P; q += 64) {
+            const int ni = q / HW, p = q - ni * HW;
+            const float g = Q[oc * P + q];
+            const float xh = (a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p] - mean) * rstd;
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            a.part_qb[((size_t)grp * 2 * C + ch) * 2] = s1;
+            a.part_qb[((size_t)grp * 2 * C + ch) * 2 + 1] = s2;
+        }
+    }
+}
+
+static size_t small_bwd_lds_bytes(int gp, int P) { return ((size_t)3 * gp * P + 2 * P + 256 + 80) * sizeof(float); }
+
+bool wopos_small_bwd_ok(const AxialGeom& g, const medt_axial_desc& d) {
+    if (!wopos_small_ok(g, d)) return false;
+    const int P = g.npg * g.HW;
+    if (P > (g.L == 16 ? 1024 : 256)) return false;
+    return small_bwd_lds_bytes(g.gp, P) <= 64 * 1024;
+}
+
+int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* y,
+                    const float* dy, const float* qkv_raw, const float* stacked, const float* lse, BnStats sq, BnStats ss,
+                    BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, hipStream_t s) {
+    SmallBwdArgs a;
+    a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.y = y;
+    a.sq = sq; a.ss = ss; a.so = so;
+    a.w_out = p.bn_output.weight; a.w_sim = p.bn_similarity.weight;
+    a.dqkv = dqkv; a.part_ob = part_ob; a.part_sb = part_sb; a.part_qb = part_qb;
+    a.N = g.N; a.C = g.C; a.H = g.H; a.W = g.W; a.G = g.G; a.npg = g.npg;
+    a.stride = d.stride; a.training = d.training ? 1 : 0; a.out_relu = d.out_relu;
+    const dim3 grid(g.groups, g.G), block(MEDT_THREADS);
+    const size_t lds = small_bwd_lds_bytes(g.gp, g.npg * g.HW);
+#define MEDT_SMALL(AX, Lv, GPv) hipLaunchKernelGGL((wopos_small_bwd_kernel<AX, Lv, GPv>), grid, block, lds, s, a)
+#define MEDT_SMALL_GP(AX, Lv)                                                                       \
+    switch (g.gp) {                                                                                 \
+        case 2: MEDT_SMALL(AX, Lv, 2); break;                                                       \
+        case 4: MEDT_SMALL(AX, Lv, 4); break;                                                       \
+        case 8: MEDT_SMALL(AX, Lv, 8); break;                                                       \
+        default: MEDT_SMALL(AX, Lv, 16); break;                                                     \
+    }
+#define MEDT_SMALL_L(AX)                                                                            \
+    switch (g.L) {                                                                                  \
+        case 4: MEDT_SMALL_GP(AX, 4) break;                                                         \
+        case 8: MEDT_SMALL_GP(AX, 8) break;                                                         \
+        default: MEDT_SMALL_GP(AX, 16) break;                                                       \
+    }
+    if (g.axis == 1) { MEDT_SMALL_L(1) } else { MEDT_SMALL_L(0) }
+#undef MEDT_SMALL_L
+#undef MEDT_SMALL_GP
+#undef MEDT_SMALL
+    return launch_status("wopos_small_bwd");
+}
+
+// Parameter gradients of the three BatchNorms (sum over the BN groups of the per-group partials written by the kernel
+// above) and bn_qkv's backward coefficients for the conv kernels, in one launch: block -> (BN, channel), lane -> group.
+// Same formulas as bn_bwd_finalize_kernel (pointwise.hip) and sim_bwd_finalize_kernel (axial_core.hip).
+struct SmallFinArgs {
+    const float *part_ob, *part_sb, *part_qb;
+    BnStats so, ss, sq;
+    const float* w_qkv_bn;              // bn_qkv.weight (2C)
+    float *coef_qkv;                    // [groups][2C][3]
+    float *d_out_w, *d_out_b, *d_sim_w, *d_sim_b, *d_qkv_w, *d_qkv_b;
+    int C, G, groups, training;
+    double row_count, sim_count;
+    float dscale_out;
+};
+
+__device__ __forceinline__ double small_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void wopos_small_bwd_finalize_kernel(SmallFinArgs a) {
+    const int lane = threadIdx.x, C = a.C, G = a.G;
+    int ch = blockIdx.x;
+    double dg = 0.0, db = 0.0;
+    if (ch < C) {                                               // bn_output
+        for (int grp = lane; grp < a.groups; grp += 64) {
+            const float* q = a.part_ob + ((size_t)grp * C + ch) * 2;
+            db += (double)q[0] * a.dscale_out;
+            dg += (double)q[1] * a.dscale_out;
+        }
+        dg = small_wave_sum_d(dg);
+        db = small_wave_sum_d(db);
+        if (lane == 0) { a.d_out_w[ch] = (float)dg; a.d_out_b[ch] = (float)db; }
+        return;
+    }
+    ch -= C;
+    if (ch < G) {                                               // bn_similarity
+        for (int grp = lane; grp < a.groups; grp += 64) {
+            const float* q = a.part_sb + ((size_t)grp * G + ch) * 4;
+            const double a0 = q[0], ax = q[1];
+            const double mean = a.ss.mean[grp * G + ch], rstd = a.ss.rstd[grp * G + ch];
+            dg += rstd * (ax - mean * a0);
+            db += a0;
+        }
+        dg = small_wave_sum_d(dg);
+        db = small_wave_sum_d(db);
+        if (lane == 0) { a.d_sim_w[ch] = (float)dg; a.d_sim_b[ch] = (float)db; }
+        return;
+    }
+    ch -= G;                                                    // bn_qkv: coefficients dx = c0*d + c1*x + c2 as well
+    const int CH = 2 * C;
+    for (int grp = lane; grp < a.groups; grp += 64) {
+        const float* q = a.part_qb + ((size_t)grp * CH + ch) * 2;
+        const double s1 = q[0], s2 = q[1];
+        const double mean = a.sq.mean[grp * CH + ch], rstd = a.sq.rstd[grp * CH + ch], A = (double)a.w_qkv_bn[ch] * rstd;
+        float* cf = a.coef_qkv + ((size_t)grp * CH + ch) * 3;
+        cf[0] = (float)A;
+        if (a.training) {
+            const double m1 = s1 / a.row_count, m2 = s2 / a.row_count;
+            cf[1] = (float)(-A * rstd * m2);
+            cf[2] = (float)(A * (rstd * mean * m2 - m1));
+        } else {
+            cf[1] = 0.f;
+            cf[2] = 0.f;
+        }
+        dg += s2;
+        db += s1;
+    }
+    dg = small_wave_sum_d(dg);
+    db = small_wave_sum_d(db);
+    if (lane == 0) { a.d_qkv_w[ch] = (float)dg; a.d_qkv_b[ch] = (float)db; }
+}
+
+int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p,
+                             const float* part_ob, const float* part_sb, const float* part_qb, BnStats sq, BnStats ss,
+                             BnStats so, float* coef_qkv, const medt_axial_grads& gr, hipStream_t s) {
+    SmallFinArgs a;
+    a.part_ob = part_ob; a.part_sb = part_sb; a.part_qb = part_qb;
+    a.so = so; a.ss = ss; a.sq = sq;
+    a.w_qkv_bn = p.bn_qkv.weight;
+    a.coef_qkv = coef_qkv;
+    a.d_out_w = gr.bn_out_weight; a.d_out_b = gr.bn_out_bias;
+    a.d_sim_w = gr.bn_sim_weight; a.d_sim_b = gr.bn_sim_bias;
+    a.d_qkv_w = gr.bn_qkv_weight; a.d_qkv_b = gr.bn_qkv_bias;
+    a.C = g.C; a.G = g.G; a.groups = g.groups; a.training = d.training ? 1 : 0;
+    a.row_count = g.row_count; a.sim_count = g.sim_count;
+    a.dscale_out = 1.f / (float)(d.stride * d.stride);
+    hipLaunchKernelGGL(wopos_small_bwd_finalize_kernel, dim3(g.C + g.G + 2 * g.C), dim3(64), 0, s, a);
+    return launch_status("wopos_small_bwd_finalize");
+}
+
 }  // namespace medt

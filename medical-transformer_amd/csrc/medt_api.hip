@@ -194,6 +194,19 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
     const int tr = d->training ? 1 : 0, ppg = conv2d_parts_per_group(g.N, g.groups, g.HW), TL = 2 * g.L - 1;
+    if (wopos_small_bwd_ok(g, *d)) {
+        // tiny position-free layers: dy -> gradient at the qkv_transform output in one workgroup per (BN group, head);
+        // one finalisation launch then sums the per-group partials into the BatchNorm parameter gradients and writes
+        // bn_qkv's backward coefficients for the conv kernels
+        if ((rc = wopos_small_bwd(g, *d, *p, y, dy, sv->qkv_raw, sv->stacked, sv->lse, st.qkv, st.sim, st.out, w.dqkv,
+                                  w.part_ob, w.part_sb, w.part_qb, s))) return rc;
+        if ((rc = wopos_small_bwd_finalize(g, *d, *p, w.part_ob, w.part_sb, w.part_qb, st.qkv, st.sim, st.out, w.coef_qkv,
+                                           *gr, s))) return rc;
+        if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
+            return rc;
+        return conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C,
+                                 1, 1, 0, g.groups, s);
+    }
     if (d->out_relu) {               // fused ReLU after the layer: mask the incoming gradient by the output sign
         if ((rc = relu_mask(dy, y, w.dy_masked, (size_t)g.N * g.C * (g.H / d->stride) * (g.W / d->stride), s))) return rc;
         dy = w.dy_masked;

@@ -126,6 +126,13 @@ bool wopos_small_ok(const AxialGeom& g, const medt_axial_desc& d);
 int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* x, float* y,
                     float* qkv_raw, float* stacked, float* lse, float* part_q, float* part_s, float* part_o,
                     hipStream_t s);
+bool wopos_small_bwd_ok(const AxialGeom& g, const medt_axial_desc& d);
+int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* y,
+                    const float* dy, const float* qkv_raw, const float* stacked, const float* lse, BnStats sq, BnStats ss,
+                    BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, hipStream_t s);
+int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p,
+                             const float* part_ob, const float* part_sb, const float* part_qb, BnStats sq, BnStats ss,
+                             BnStats so, float* coef_qkv, const medt_axial_grads& gr, hipStream_t s);
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // logit statistics: partials [group][tile][SC][2]
