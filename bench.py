@@ -95,7 +95,9 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     bytes_main = 4 * C * 4 * M
     bytes_stats = C * 4 * M
     flops_main = 7.0 * M * L * C
-    roof = {"bound": "hbm", "kernel": "attn_fwd3_kernel<GP=2,AXIS=%d,L=64>" % (1 if width else 0),
+    # the launch = memset of the repair flag + the bound-referenced four-rows-per-lane kernel + the exact kernel's
+    # early exit; MEDT_ROWS4=0 / MEDT_BOUND_PATH=0 select the other variants
+    roof = {"bound": "hbm", "kernel": "attn_fwd4r_kernel<AXIS=%d,L=64,EXACT=false>" % (1 if width else 0),
             "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main},
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
