@@ -1,0 +1,220 @@
+// conv_small.hip -- 1x1 convolution + train-mode BatchNorm (+ residual, ReLU) blocks whose BatchNorm group is small
+// enough for one workgroup (the conv_down / conv_up / downsample blocks of MedT's local branch: 4-image patch groups on
+// 16x16 ... 2x2 maps, lib/models/axialnet.py:346-391, 450-454).
+//
+// Forward: one workgroup per (BN group, chunk of output channels) computes the convolution for every position of the
+// group, so the batch statistics of its channels are exact block-level sums and the normalise + residual + ReLU pass
+// runs in the same kernel: conv -> bn_finalize -> bn_apply_act becomes this kernel + bn_finalize (saved statistics and
+// the group-ordered running-stat updates).  Backward: one wave per (BN group, channel) does the ReLU mask, the two
+// BatchNorm-backward sums and dz = c0*g + c1*z + c2: bn_act_bwd_stats -> bn_bwd_finalize -> bn_bwd_apply becomes this
+// kernel + bn_bwd_finalize (parameter gradients: sums over the groups).  Same saved tensors either way.
+#include "medt_common.h"
+#include "medt_kernels.h"
+#include <type_traits>
+
+namespace medt {
+
+struct SmallConvArgs {
+    const float *x, *w, *res;
+    medt_bn_ptrs bn;
+    float *z, *y, *partials;            // partials: [groups][Cout][2]
+    int N, Cin, H, W, Cout, stride, npg, relu, training;
+    float eps;
+};
+
+// identical arithmetic to bn_finalize_kernel (pointwise.hip) given the same float sums
+__device__ __forceinline__ void conv_small_scale_shift(float s, float ss, double count, const medt_bn_ptrs& bn, int ch,
+                                                       float eps, int training, float& scale, float& shift) {
+    const float g = bn.weight[ch], b = bn.bias[ch];
+    if (training) {
+        const double mean = (double)s / count;
+        double var = (double)ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        scale = (float)(g * rstd);
+        shift = (float)(b - mean * g * rstd);
+    } else {
+        const float mean = bn.running_mean[ch];
+        const float rstd = (float)(1.0 / sqrt((double)bn.running_var[ch] + (double)eps));
+        scale = g * rstd;
+        shift = b - mean * g * rstd;
+    }
+}
+
+constexpr int SC_NOC = 16;              // output channels per workgroup
+
+__global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = blockIdx.x, oc0 = blockIdx.y * SC_NOC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = blockDim.x, NW = T >> 6;           // 256 ... 1024 threads: one position per thread when the group has 1024
+    const int Cin = a.Cin, W = a.W, HW = a.H * a.W, st = a.stride, Ho = a.H / st, Wo = a.W / st, HoWo = Ho * Wo;
+    const int P = a.npg * HoWo, n0 = grp * a.npg;
+    float* Z = smem;                    // [SC_NOC][P]
+    float* Wl = Z + SC_NOC * P;         // [Cin][SC_NOC]
+    float* sc = Wl + Cin * SC_NOC;      // [SC_NOC]
+    float* sh = sc + SC_NOC;            // [SC_NOC]
+    for (int e = tid; e < SC_NOC * Cin; e += T) {
+        const int oc = e / Cin, c = e - oc * Cin;
+        Wl[c * SC_NOC + oc] = a.w[(size_t)(oc0 + oc) * Cin + c];
+    }
+    __syncthreads();
+    {
+        // a work item = one output position x NOC_T channels; groups with few positions split the 16 channels over
+        // more threads
+        int chunks = P >= T ? 1 : T / P;
+        if (chunks > SC_NOC / 4) chunks = SC_NOC / 4;
+        const int noc = SC_NOC / chunks;                            // 16, 8 or 4
+        auto project = [&](auto cb_tag) {
+            constexpr int CB = decltype(cb_tag)::value;
+            for (int item = tid; item < P * chunks; item += T) {
+                const int chunk = item / P, q = item - chunk * P, ni = q / HoWo, po = q - ni * HoWo, c0o = chunk * noc;
+                const int ho = po / Wo, wo = po - ho * Wo;
+                const float* xp = a.x + ((size_t)(n0 + ni) * Cin) * HW + (ho * st) * W + wo * st;
+                float acc[SC_NOC];
+#pragma unroll
+                for (int o = 0; o < SC_NOC; ++o) acc[o] = 0.f;
+                for (int c0 = 0; c0 < Cin; c0 += CB) {
+                    float xv[CB];
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) xv[k] = xp[(size_t)(c0 + k) * HW];
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) {
+                        const float* wr = Wl + (c0 + k) * SC_NOC + c0o;
+#pragma unroll
+                        for (int o = 0; o < SC_NOC; o += 4)
+                            if (o < noc) {
+                                const float4 w4 = *reinterpret_cast<const float4*>(wr + o);
+                                acc[o] = fmaf(w4.x, xv[k], acc[o]);
+                                acc[o + 1] = fmaf(w4.y, xv[k], acc[o + 1]);
+                                acc[o + 2] = fmaf(w4.z, xv[k], acc[o + 2]);
+                                acc[o + 3] = fmaf(w4.w, xv[k], acc[o + 3]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < SC_NOC; ++o)
+                    if (o < noc) {
+                        Z[(c0o + o) * P + q] = acc[o];
+                        a.z[((size_t)(n0 + ni) * a.Cout + oc0 + c0o + o) * HoWo + po] = acc[o];
+                    }
+            }
+        };
+        if ((Cin & 31) == 0) project(std::integral_constant<int, 32>{});
+        else project(std::integral_constant<int, 16>{});
+    }
+    __syncthreads();
+    for (int oc = wave; oc < SC_NOC; oc += NW) {
+        float s = 0.f, ss = 0.f;
+        for (int q = lane; q < P; q += 64) {
+            const float v = Z[oc * P + q];
+            s += v;
+            ss = fmaf(v, v, ss);
+        }
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            const int ch = oc0 + oc;
+            conv_small_scale_shift(s, ss, (double)P, a.bn, ch, a.eps, a.training, sc[oc], sh[oc]);
+            if (a.training) {
+                a.partials[((size_t)grp * a.Cout + ch) * 2] = s;
+                a.partials[((size_t)grp * a.Cout + ch) * 2 + 1] = ss;
+            }
+        }
+    }
+    __syncthreads();
+    for (int item = tid; item < SC_NOC * P; item += T) {
+        const int oc = item / P, q = item - oc * P, ni = q / HoWo, po = q - ni * HoWo;
+        const size_t idx = ((size_t)(n0 + ni) * a.Cout + oc0 + oc) * HoWo + po;
+        float v = fmaf(Z[item], sc[oc], sh[oc]);
+        if (a.res) v += a.res[idx];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[idx] = v;
+    }
+}
+
+static size_t conv_small_lds(int P, int Cin) { return ((size_t)SC_NOC * P + (size_t)Cin * SC_NOC + 2 * SC_NOC) * sizeof(float); }
+
+static bool conv_small_enabled() {
+    static const bool on = [] { const char* e = getenv("MEDT_DISABLE_SMALL"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
+bool conv_small_ok(const medt_conv_desc& d) {
+    if (!conv_small_enabled() || !d.has_bn || d.K != 1 || d.pad != 0 || d.has_bias) return false;
+    if (d.stride < 1 || d.H % d.stride || d.W % d.stride) return false;
+    if ((d.Cin & 15) || (d.Cout % SC_NOC)) return false;
+    const int P = (d.N / d.bn_groups) * (d.H / d.stride) * (d.W / d.stride);
+    return P <= 1024 && conv_small_lds(P, d.Cin) <= 64 * 1024;
+}
+
+int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,
+                   float* z, float* y, float* partials, hipStream_t s) {
+    SmallConvArgs a;
+    a.x = x; a.w = w; a.res = d.has_res ? res : nullptr; a.bn = bn; a.z = z; a.y = y; a.partials = partials;
+    a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.stride = d.stride; a.npg = d.N / d.bn_groups;
+    a.relu = d.relu; a.training = d.training ? 1 : 0; a.eps = d.eps;
+    const int P = a.npg * (d.H / d.stride) * (d.W / d.stride);
+    const int threads = P <= 256 ? 256 : (P <= 512 ? 512 : 1024);
+    hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel, dim3(d.bn_groups, d.Cout / SC_NOC), dim3(threads),
+                       conv_small_lds(P, d.Cin), s, a);
+    return launch_status("conv1x1_bn_small_fwd");
+}
+
+// --------------------------------------------------------------------------- //
+// backward of BatchNorm (+ ReLU mask) for the same blocks: one wave per (group, channel)
+// --------------------------------------------------------------------------- //
+struct SmallBnBwdArgs {
+    const float *dy, *y, *z, *weight;
+    BnStats st;
+    float *g, *dz, *partials;           // g: masked incoming gradient (= d(res)); partials [groups][C][2]
+    int C, HW, npg, relu, training;
+};
+
+__global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_small_kernel(SmallBnBwdArgs a) {
+    const int grp = blockIdx.x, c = blockIdx.y * MEDT_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= a.C) return;
+    const int HW = a.HW, P = a.npg * HW, gc = grp * a.C + c;
+    const float mean = a.st.mean[gc], rstd = a.st.rstd[gc];
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = lane; q < P; q += 64) {
+        const int ni = q / HW, p = q - ni * HW;
+        const size_t idx = ((size_t)(grp * a.npg + ni) * a.C + c) * HW + p;
+        float d = a.dy[idx];
+        if (a.relu && !(a.y[idx] > 0.f)) d = 0.f;
+        if (a.g) a.g[idx] = d;
+        s1 += d;
+        s2 = fmaf(d, (a.z[idx] - mean) * rstd, s2);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        a.partials[(size_t)gc * 2] = s1;
+        a.partials[(size_t)gc * 2 + 1] = s2;
+    }
+    // same arithmetic as bn_bwd_coef (pointwise.hip), dscale = 1
+    const double A = (double)a.weight[c] * (double)rstd;
+    float c0 = (float)A, c1 = 0.f, c2 = 0.f;
+    if (a.training) {
+        const double m1 = (double)s1 / (double)P, m2 = (double)s2 / (double)P;
+        c1 = (float)(-A * (double)rstd * m2);
+        c2 = (float)(A * ((double)rstd * (double)mean * m2 - m1));
+    }
+    for (int q = lane; q < P; q += 64) {
+        const int ni = q / HW, p = q - ni * HW;
+        const size_t idx = ((size_t)(grp * a.npg + ni) * a.C + c) * HW + p;
+        float d = a.dy[idx];
+        if (a.relu && !(a.y[idx] > 0.f)) d = 0.f;
+        a.dz[idx] = fmaf(c0, d, fmaf(c1, a.z[idx], c2));
+    }
+}
+
+int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
+                     const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s) {
+    SmallBnBwdArgs a;
+    a.dy = dy; a.y = y; a.z = z; a.weight = weight; a.st = st; a.g = g; a.dz = dz; a.partials = partials;
+    a.C = d.Cout; a.HW = HoWo; a.npg = d.N / d.bn_groups; a.relu = d.relu; a.training = d.training ? 1 : 0;
+    hipLaunchKernelGGL(bn_act_bwd_small_kernel, dim3(d.bn_groups, cdiv(d.Cout, MEDT_WAVES)), dim3(MEDT_THREADS), 0, s, a);
+    return launch_status("bn_act_bwd_small");
+}
+
+}  // namespace medt

@@ -320,6 +320,13 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
     const int tr = d->training ? 1 : 0;
     if (!tr && (!bn->running_mean || !bn->running_var)) { set_error("conv fwd: eval mode needs running statistics"); return MEDT_EINVAL; }
     BnStats st(stats, d->bn_groups * d->Cout);
+    if (conv_small_ok(*d)) {
+        // small BN groups (local branch): conv + exact block-level statistics + normalise/residual/ReLU in one kernel,
+        // then the saved statistics and the ordered running-stat updates
+        if ((rc = conv_small_fwd(*d, x, w, *bn, res, z, y, cw.partials, s))) return rc;
+        return bn_finalize(cw.partials, 1, d->bn_groups, d->Cout, (double)(d->N / d->bn_groups) * g.HoWo, *bn, d->momentum,
+                           d->eps, tr, st, s);
+    }
     if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, cw.ksplit_fwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
                          d->stride, d->pad, 0, d->bn_groups, s))) return rc;
     if ((rc = bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout,
@@ -343,11 +350,20 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     if (d->has_bn) {
         BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
         float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
+        if (conv_small_ok(*d)) {
+            // one wave per (group, channel): mask, sums, coefficients and dz in one kernel; the finalisation only
+            // produces the parameter gradients (one partial slot per group)
+            if ((rc = bn_act_bwd_small(*d, dy, y, z, st, bn->weight, (d->has_res && dres) ? dres : nullptr, cw.dz,
+                                       cw.partials, g.HoWo, s))) return rc;
+            if ((rc = bn_bwd_finalize(cw.partials, 1, d->bn_groups, d->Cout, (double)(d->N / d->bn_groups) * g.HoWo, 1.f,
+                                      st, bn->weight, d->training ? 1 : 0, cw.coef, dbn_weight, dbn_bias, s))) return rc;
+        } else {
         if ((rc = bn_act_bwd_stats(dy, y, z, st, gb, cw.partials, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s))) return rc;
         if ((rc = bn_bwd_finalize(cw.partials, g.ppg_bwd, d->bn_groups, d->Cout,
                                   (double)(d->N / d->bn_groups) * g.HoWo, 1.f, st, bn->weight, d->training ? 1 : 0, cw.coef,
                                   dbn_weight, dbn_bias, s))) return rc;
         if ((rc = bn_bwd_apply(gb, z, cw.coef, cw.dz, d->N, d->Cout, g.HoWo, d->bn_groups, s))) return rc;
+        }
         grad_out = cw.dz;
     } else if (d->relu) {
         if ((rc = relu_mask(dy, y, cw.gbuf, g.out_elems, s))) return rc;

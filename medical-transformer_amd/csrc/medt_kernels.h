@@ -121,6 +121,12 @@ int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, B
 int fast3_max_subtiles(int gp, int L, int axis);
 int fast4_subtile_sequences(int L);
 int fast4_max_subtiles(int axis);
+// conv_small.hip: 1x1 conv + BatchNorm blocks whose BN group fits one workgroup
+bool conv_small_ok(const medt_conv_desc& d);
+int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,
+                   float* z, float* y, float* partials, hipStream_t s);
+int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
+                     const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s);
 // axial_small.hip: a whole position-free layer per (BN group, head) workgroup
 bool wopos_small_ok(const AxialGeom& g, const medt_axial_desc& d);
 int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* x, float* y,
