@@ -224,3 +224,17 @@ def test_four_rows_per_lane_kernel(bound, shift, device):
     """gp = 2 layers of large problems run the four-rows-per-lane forward kernel (MEDT_ROWS4=1 forces it on the
     small test shapes, ragged tiles included): exact, bound-referenced and repaired variants, both axes, L = 16..128."""
     _run_layer_subprocess({"MEDT_ROWS4": "1", "MEDT_BOUND_PATH": bound, "MEDT_DEBUG_BOUND_SHIFT": shift})
+
+
+def test_layer_by_layer_fallback_of_small_layers(device):
+    """Position-free layers / 1x1 conv blocks whose BatchNorm group fits one workgroup normally run the fused
+    small-layer kernels (axial_small.hip, conv_small.hip).  MEDT_DISABLE_SMALL=1 forces the layer-by-layer path those
+    shapes used before, which stays the path of larger groups: same parity tests, in a subprocess."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEDT_DISABLE_SMALL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_axial_layer_gpu.py"), os.path.join(root, "tests", "test_ops_gpu.py"),
+                        "-k", "wopos or test_conv_block"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
