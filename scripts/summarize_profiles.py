@@ -17,10 +17,10 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def one(pattern):
-    fs = glob.glob(os.path.join(RAW, pattern))
+    fs = sorted(glob.glob(os.path.join(RAW, pattern)), key=os.path.getmtime)    # gpurun merges runs: newest wins
     if not fs:
         raise SystemExit("missing " + pattern)
-    return fs[0]
+    return fs[-1]
 
 
 def counters(folder):
