@@ -97,7 +97,8 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     flops_main = 7.0 * M * L * C
     # the launch = memset of the repair flag + the bound-referenced four-rows-per-lane kernel + the exact kernel's
     # early exit; MEDT_ROWS4=0 / MEDT_BOUND_PATH=0 select the other variants
-    roof = {"bound": "hbm", "kernel": "attn_fwd4r_kernel<AXIS=%d,L=64,EXACT=false>" % (1 if width else 0),
+    kname = ("attn_fwd4r_kernel<AXIS=%d,L=%d,EXACT=false>" if C // 8 == 2 else "attn_fwd3_kernel<GP=%d,AXIS=%%d,L=%%d,EXACT=false>" % (C // 8))
+    roof = {"bound": "hbm", "kernel": kname % (1 if width else 0, L),
             "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main},
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
@@ -105,7 +106,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
             "stats_kernel": {"achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
                              "bytes_per_launch": bytes_stats}}
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tf):
+    if os.path.exists(tf) and (C, L) == (16, 64):
         try:
             roof["traffic"] = json.load(open(tf)).get("attn_fwd_bytes_per_launch")
         except Exception:
@@ -255,6 +256,9 @@ def main():
         log(f"eval fwd {result['fwd_ms_per_image']:.3f} ms/image")
         if not args.no_roofline:
             result["roofline"] = roofline_leg(device)
+            # SURVEY.md 8(d)'s second scaled shape (256-px inputs: C=32, gp=4, L=128), reported beside the headline one
+            other = roofline_leg(device, C=32, L=128, images=128, iters=10)
+            result["roofline"]["also"] = [{k: other[k] for k in ("kernel", "shape", "achieved", "frac", "launch_ms", "valu_tflops")}]
             log("roofline leg done")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg()

@@ -228,14 +228,13 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // bn_qkv backward, qkv_transform backward
     if ((rc = bn_bwd_finalize(w.part_qb, g.tpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
-    const hipStream_t sa = s;
     if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;
     if ((rc = conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
-                                1, 0, g.groups, sa))) return rc;
+                                1, 0, g.groups, s))) return rc;
     if (g.pos) {
-        if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, sa))) return rc;
-        if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, sa))) return rc;
+        if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
+        if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, s))) return rc;
     }
     return MEDT_OK;
 }
@@ -371,11 +370,10 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     } else {
         grad_out = dy;
     }
-    const hipStream_t sa = s;
     if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
-    if (d->has_bias && (rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, sa))) return rc;
+    if (d->has_bias && (rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, s))) return rc;
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
-                             d->pad, 1, sa);
+                             d->pad, 1, s);
 }
 
 int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream) {
