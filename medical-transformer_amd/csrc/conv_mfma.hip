@@ -58,24 +58,36 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     // split-K: slice blockIdx.z owns k in [kbeg, kend) and writes its raw partial tile to ksplit_out (the few-tile
     // layers on 2x2 / 4x4 maps would otherwise run on a handful of CUs); conv_splitk_epilogue sums the slices.
     const int kbeg = blockIdx.z * kchunk, kend = min(Ktot, kbeg + kchunk);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    // Software pipeline: the 8 global loads of K-slice s+1 are issued before the 16 MFMAs of slice s and only written
+    // to LDS after them, so their latency hides under the matrix work (one workgroup per CU has little else to hide it).
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int r = ar + 16 * ps, o = o0 + r, k = k0 + ak;
-            As[r][ak] = (o < Cout && k < kend) ? w[(size_t)o * Ktot + k] : 0.f;
+            const int o = o0 + ar + 16 * ps, k = k0 + ak;
+            ra[ps] = (o < Cout && k < kend) ? w[(size_t)o * Ktot + k] : 0.f;
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int kk = wv + 4 * ps, k = k0 + kk;
+            const int k = k0 + wv + 4 * ps;
             float v = 0.f;
             if (jok && k < kend) {
                 const int c = k / KK, t = k - c * KK;
                 const int h = hbj + t / K, ww = wbj + t % K;
                 if (h >= 0 && h < H && ww >= 0 && ww < W) v = xj[((size_t)c * H + h) * W + ww];
             }
-            Bs[kk][lane] = v;
+            rb[ps] = v;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            As[ar + 16 * ps][ak] = ra[ps];
+            Bs[wv + 4 * ps][lane] = rb[ps];
         }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float a = As[16 * wv + (lane & 15)][ks * 4 + (lane >> 4)];
@@ -242,7 +254,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
-    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+    // Software pipeline as in the forward kernel: the 32 global loads of the next 64 positions fly during the 64 MFMAs
+    float ra[16], rb[16];
+    auto fetch = [&](long q0) {
         const long q = q0 + j;
         const bool qok = q < q_end;
         const int n = qok ? (int)(q / HoWo) : 0, p = qok ? (int)(q - (long)n * HoWo) : 0;
@@ -252,8 +266,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
         const float* rawp = raw ? raw + (size_t)n * Cout * HoWo + p : nullptr;
         const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
         const float* xp = x + (size_t)n * Cin * H * W;
-#pragma unroll 4
-        for (int r = r0; r < 64; r += 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + 4 * i;
             float a = 0.f, b = 0.f;
             const int o = o0 + r, k = k0 + r;
             if (qok && o < Cout) {
@@ -265,10 +280,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
                 const int h = hb + t / K, w = wb + t % K;
                 if (h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + h) * W + w];
             }
-            A[r][j] = a;
-            B[r][j] = b;
+            ra[i] = a;
+            rb[i] = b;
+        }
+    };
+    if (q_begin < q_end) fetch(q_begin);
+    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            A[r0 + 4 * i][j] = ra[i];
+            B[r0 + 4 * i][j] = rb[i];
         }
         __syncthreads();
+        if (q0 + 64 < q_end) fetch(q0 + 64);
 #pragma unroll 4
         for (int ks = 0; ks < 16; ++ks) {
             const float a = A[16 * wv + (lane & 15)][ks * 4 + (lane >> 4)];
