@@ -246,7 +246,11 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
     for (int a = 0; a < RO; ++a)
 #pragma unroll
         for (int b = 0; b < RC; ++b) acc[a][b] = 0.f;
-    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+    // Software pipeline: the global loads of the next 64 positions are issued before the FMA block of the current ones
+    // and written to LDS after it (most layers run one workgroup per CU: nothing else hides the load latency).
+    constexpr int NA = TO / 4, NB = TC / 4;
+    float ra[NA], rb[NB];
+    auto fetch = [&](long q0) {
         const long q = q0 + j;
         const bool qok = q < q_end;
         const int n = qok ? (int)(q / HoWo) : 0, p = qok ? (int)(q - (long)n * HoWo) : 0;
@@ -256,29 +260,37 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
         const float* rawp = raw ? raw + (size_t)n * Cout * HoWo + p : nullptr;
         const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
         const float* xp = x + (size_t)n * Cin * H * W;
-#pragma unroll 4
-        for (int r = r0; r < TO; r += 4) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
             float a = 0.f;
-            const int o = o0 + r;
+            const int o = o0 + r0 + 4 * i;
             if (qok && o < Cout) {
                 a = dyp[(size_t)o * HoWo];
                 if (cf) a = fmaf(cf[o * 3], a, fmaf(cf[o * 3 + 1], rawp[(size_t)o * HoWo], cf[o * 3 + 2]));
             }
-            A[r][j] = a;
+            ra[i] = a;
         }
-#pragma unroll 4
-        for (int r = r0; r < TC; r += 4) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
             float b = 0.f;
-            const int k = k0 + r;
+            const int k = k0 + r0 + 4 * i;
             if (qok && k < Ktot) {
                 const int c = k / KK, t = k - c * KK;
                 const int kh = t / K, kw = t - kh * K;
                 const int h = hb + kh, w = wb + kw;
                 if (h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + h) * W + w];
             }
-            B[r][j] = b;
+            rb[i] = b;
         }
+    };
+    if (q_begin < q_end) fetch(q_begin);
+    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) A[r0 + 4 * i][j] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) B[r0 + 4 * i][j] = rb[i];
         __syncthreads();
+        if (q0 + 64 < q_end) fetch(q0 + 64);
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
             float av[RO], bv[RC];
