@@ -232,8 +232,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
     int stride, int pad, int QS, int npg) {
     constexpr int KK = K * K, RO = TO / 16, RC = TC / 16;
-    __shared__ float A[TO][65];
-    __shared__ float B[TC][65];
+    // row stride 68: 16-byte aligned rows for ds_read_b128 along the position index, and 68 mod 64 = 4 puts the 16
+    // B rows a wave reads at once on disjoint 4-bank groups
+    __shared__ __attribute__((aligned(16))) float A[TO][68];
+    __shared__ __attribute__((aligned(16))) float B[TC][68];
     const int Ktot = Cin * KK, HoWo = Ho * Wo;
     const int o0 = blockIdx.x * TO, k0 = blockIdx.y * TC;
     const long NP = (long)N * HoWo;
@@ -291,17 +293,24 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
         for (int i = 0; i < NB; ++i) B[r0 + 4 * i][j] = rb[i];
         __syncthreads();
         if (q0 + 64 < q_end) fetch(q0 + 64);
-#pragma unroll 4
-        for (int jj = 0; jj < 64; ++jj) {
-            float av[RO], bv[RC];
+#pragma unroll 2
+        for (int jj = 0; jj < 64; jj += 4) {                      // four positions per 16-byte LDS read
+            float4 av[RO], bv[RC];
 #pragma unroll
-            for (int a = 0; a < RO; ++a) av[a] = A[to + 16 * a][jj];
+            for (int a = 0; a < RO; ++a) av[a] = *reinterpret_cast<const float4*>(&A[to + 16 * a][jj]);
 #pragma unroll
-            for (int b = 0; b < RC; ++b) bv[b] = B[tc + 16 * b][jj];
+            for (int b = 0; b < RC; ++b) bv[b] = *reinterpret_cast<const float4*>(&B[tc + 16 * b][jj]);
 #pragma unroll
             for (int a = 0; a < RO; ++a)
 #pragma unroll
-                for (int b = 0; b < RC; ++b) acc[a][b] = fmaf(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < RC; ++b) {
+                    float t = acc[a][b];
+                    t = fmaf(av[a].x, bv[b].x, t);
+                    t = fmaf(av[a].y, bv[b].y, t);
+                    t = fmaf(av[a].z, bv[b].z, t);
+                    t = fmaf(av[a].w, bv[b].w, t);
+                    acc[a][b] = t;
+                }
         }
         __syncthreads();
     }
