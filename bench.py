@@ -37,7 +37,7 @@ IMG = 128
 
 def build_model(name, img, device):
     import lib as droplib
-    f = {"MedT": droplib.models.axialnet.MedT, "gatedaxialunet": droplib.models.axialnet.gated,
+    f = {"MedT": droplib.models.axialnet.MedT, "gatedaxialunet": droplib.models.axialnet.gated, "gated": droplib.models.axialnet.gated,
          "axialunet": droplib.models.axialunet, "logo": droplib.models.axialnet.logo}[name]
     return f(img_size=img, imgchan=3).to(device)
 
