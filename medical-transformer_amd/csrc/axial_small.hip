@@ -45,13 +45,31 @@ __device__ __forceinline__ void small_scale_shift(float s, float ss, double coun
     }
 }
 
+// block_sum for workgroups of NW waves (256 or 512 threads)
+template <int K>
+__device__ __forceinline__ void small_block_sum(float (&v)[K], float* red, float* dst, int NW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) red[wave * K + k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (int w = 0; w < NW; ++w) s += red[w * K + k];
+        dst[k] = s;
+    }
+    __syncthreads();
+}
+
 template <int AXIS, int L, int GP>
-__global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdArgs a) {
-    constexpr int HQ = GP / 2, NCH = 2 * GP, RMAX = 4;          // up to 4 rows (positions) per thread: P <= 1024
+__global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP, RMAX = 2;          // up to 2 rows (positions) per thread: P <= 2 * blockDim.x
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = blockIdx.x, hg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = a.C, W = a.W, HW = a.H * a.W, P = a.npg * HW;
-    const int n0 = grp * a.npg;
+    const int n0 = grp * a.npg, T = blockDim.x, NW = T >> 6;
     float* Q = smem;                    // [NCH][P]  q | k | v rows of this head, raw then normalised
     float* S = Q + NCH * P;             // [GP][P]   sv
     float* sc = S + GP * P;             // [32] scale
@@ -63,20 +81,20 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
     //    A work item is a position and a chunk of NOC <= 16 output channels: x is loaded once per item (16 loads in
     //    flight: one workgroup per CU has nothing else to hide the L2 latency) and the 256 threads stay busy when
     //    the group has fewer than 256 positions.
-    for (int e = tid; e < NCH * C; e += MEDT_THREADS) {
+    for (int e = tid; e < NCH * C; e += T) {
         const int oc = e / C, c = e - oc * C;
         Wl[c * NCH + oc] = a.w[(size_t)(hg * NCH + oc) * C + c];
     }
     __syncthreads();
     {
         constexpr int NOC_MAX = NCH < 16 ? NCH : 16;
-        int chunks = P >= MEDT_THREADS ? 1 : MEDT_THREADS / P;
+        int chunks = P >= T ? 1 : T / P;
         if (chunks > NCH / 4) chunks = NCH / 4;
         if (chunks < NCH / NOC_MAX) chunks = NCH / NOC_MAX;
         const int noc = NCH / chunks;                           // 4, 8 or 16
         auto project = [&](auto cb_tag) {
             constexpr int CB = decltype(cb_tag)::value;         // x values in flight per thread
-            for (int item = tid; item < P * chunks; item += MEDT_THREADS) {
+            for (int item = tid; item < P * chunks; item += T) {
                 const int chunk = item / P, q = item - chunk * P, ni = q / HW, p = q - ni * HW, oc0 = chunk * noc;
                 const float* xp = a.x + ((size_t)(n0 + ni) * C) * HW + p;
                 float acc[NOC_MAX];
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
     }
     __syncthreads();
     // 2. bn_qkv: batch statistics over the group's positions (one wave per channel)      (:228)
-    for (int oc = wave; oc < NCH; oc += MEDT_WAVES) {
+    for (int oc = wave; oc < NCH; oc += NW) {
         float s = 0.f, ss = 0.f;
         for (int q = lane; q < P; q += 64) {
             const float v = Q[oc * P + q];
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
         }
     }
     __syncthreads();
-    for (int item = tid; item < NCH * P; item += MEDT_THREADS) {
+    for (int item = tid; item < NCH * P; item += T) {
         const int oc = item / P;
         Q[item] = fmaf(Q[item], sc[oc], sh[oc]);
     }
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
     float v[2] = {0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-        const int q = tid + r * MEDT_THREADS;
+        const int q = tid + r * T;
         if (q < P) {
             const int i = AXIS == 1 ? q % W : (q % HW) / W;
             rbase[r] = q - i * sj;
@@ -164,7 +182,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
             }
         }
     }
-    block_sum<2>(v, red, red + 32);
+    small_block_sum<2>(v, red, red + 32, NW);
     if (tid == 0) {
         float scale, shift;
         small_scale_shift(red[32], red[33], (double)P * L, a.bs, hg, a.eps, a.training, scale, shift);
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
     // 4. softmax + P.V per row; sv stays in LDS for the output statistics                 (:237-241)
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-        const int q = tid + r * MEDT_THREADS;
+        const int q = tid + r * T;
         if (q < P) {
             const int ni = q / HW, p = q - ni * HW;
             float m = -INFINITY;
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
     }
     __syncthreads();
     // 5. bn_output statistics                                                             (:242)
-    for (int c = wave; c < GP; c += MEDT_WAVES) {
+    for (int c = wave; c < GP; c += NW) {
         float s = 0.f, ss = 0.f;
         for (int q = lane; q < P; q += 64) {
             const float x = S[c * P + q];
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_fwd_kernel(SmallFwdA
     // 6. bn_output apply + AvgPool2d(stride) [+ the block's ReLU]                          (:242-253, :381-383)
     const int st = a.stride, Ho = a.H / st, Wo = a.W / st, HoWo = Ho * Wo;
     const float pool = 1.f / (float)(st * st);
-    for (int item = tid; item < GP * a.npg * HoWo; item += MEDT_THREADS) {
+    for (int item = tid; item < GP * a.npg * HoWo; item += T) {
         const int c = item / (a.npg * HoWo), r = item - c * a.npg * HoWo, ni = r / HoWo, po = r - ni * HoWo;
         const int ho = po / Wo, wo = po - ho * Wo;
         const float* src = S + c * P + ni * HW;
@@ -269,7 +287,7 @@ int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axi
     a.part_q = part_q; a.part_s = part_s; a.part_o = part_o;
     a.N = g.N; a.C = g.C; a.H = g.H; a.W = g.W; a.G = g.G; a.gp = g.gp; a.L = g.L; a.npg = g.npg;
     a.stride = d.stride; a.training = d.training ? 1 : 0; a.out_relu = d.out_relu; a.eps = d.eps;
-    const dim3 grid(g.groups, g.G), block(MEDT_THREADS);
+    const dim3 grid(g.groups, g.G), block(g.npg * g.HW > 512 ? 512 : 256);
     const size_t lds = small_lds_bytes(g.gp, g.npg * g.HW, g.C);
 #define MEDT_SMALL(AX, Lv, GPv) hipLaunchKernelGGL((wopos_small_fwd_kernel<AX, Lv, GPv>), grid, block, lds, s, a)
 #define MEDT_SMALL_GP(AX, Lv)                                                                       \
@@ -310,28 +328,28 @@ struct SmallBwdArgs {
 };
 
 template <int AXIS, int L, int GP>
-__global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdArgs a) {
-    constexpr int HQ = GP / 2, NCH = 2 * GP, R = L == 16 ? 4 : 1;     // rows (positions) per thread
+__global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
+    constexpr int HQ = GP / 2, NCH = 2 * GP, R = L == 16 ? 2 : 1;     // rows (positions) per thread (512 threads when L = 16)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = blockIdx.x, hg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = a.C, W = a.W, HW = a.H * a.W, P = a.npg * HW, G = a.G;
-    const int n0 = grp * a.npg;
+    const int n0 = grp * a.npg, T = blockDim.x, NW = T >> 6;
     float* Q = smem;                    // [NCH][P] normalised q | k | v; later the gradients of the same rows
     float* D = Q + NCH * P;             // [GP][P]  d(loss)/d(sv)
     float* lse = D + GP * P;            // [P]
     float* dlt = lse + P;               // [P]      Delta_i = sum_c dsv[c,i] sv[c,i]
-    float* red = dlt + P;               // [256]    reduction scratch
-    float* cf = red + 256;              // [3*GP] bn_output coefficients, then [8] bn_similarity (e, u, w)
+    float* red = dlt + P;               // [576]    reduction scratch (8 waves x 32 values + 64 results)
+    float* cf = red + 576;              // [3*GP] bn_output coefficients, then [8] bn_similarity (e, u, w)
     const int st = a.stride, Ho = a.H / st, Wo = a.W / st;
     const double cnt = (double)P;
 
     // normalised q|k|v of this head and the row log-sum-exps
-    for (int item = tid; item < NCH * P; item += MEDT_THREADS) {
+    for (int item = tid; item < NCH * P; item += T) {
         const int oc = item / P, q = item - oc * P, ni = q / HW, p = q - ni * HW, ch = hg * NCH + oc;
         Q[item] = fmaf(a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p], a.sq.scale[grp * 2 * C + ch],
                        a.sq.shift[grp * 2 * C + ch]);
     }
-    for (int q = tid; q < P; q += MEDT_THREADS) {
+    for (int q = tid; q < P; q += T) {
         const int ni = q / HW, p = q - ni * HW;
         lse[q] = a.lse[((size_t)(n0 + ni) * G + hg) * HW + p];
     }
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
         for (int k = 0; k < 2 * GP; ++k) v[k] = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int q = tid + r * MEDT_THREADS;
+            const int q = tid + r * T;
             if (q < P) {
                 const int ni = q / HW, p = q - ni * HW, h = p / W, w = p - h * W;
                 const size_t po = (size_t)(h / st) * Wo + (w / st);
@@ -361,11 +379,11 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
                 }
             }
         }
-        block_sum<2 * GP>(v, red, red + 128);
+        small_block_sum<2 * GP>(v, red, red + 512, NW);
         if (tid < GP) {
             const int ch = hg * GP + tid;
             const float dscale = 1.f / (float)(st * st);
-            const float r1 = red[128 + 2 * tid], r2 = red[128 + 2 * tid + 1];
+            const float r1 = red[512 + 2 * tid], r2 = red[512 + 2 * tid + 1];
             a.part_ob[((size_t)grp * C + ch) * 2] = r1;
             a.part_ob[((size_t)grp * C + ch) * 2 + 1] = r2;
             // same arithmetic as bn_bwd_finalize_kernel (pointwise.hip)
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int q = tid + r * MEDT_THREADS;
+            const int q = tid + r * T;
             if (q < P) {
                 float dl = 0.f;
 #pragma unroll
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
         float v[2] = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int q = tid + r * MEDT_THREADS;
+            const int q = tid + r * T;
             if (q < P) {
                 const int i = AXIS == 1 ? q % W : (q % HW) / W, base = q - i * sj;
 #pragma unroll
@@ -428,9 +446,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
                 }
             }
         }
-        block_sum<2>(v, red, red + 128);
+        small_block_sum<2>(v, red, red + 512, NW);
         if (tid == 0) {
-            const float a0f = red[128], axf = red[129];
+            const float a0f = red[512], axf = red[513];
             float* ps = a.part_sb + ((size_t)grp * G + hg) * 4;
             ps[0] = a0f; ps[1] = axf; ps[2] = 0.f; ps[3] = 0.f;
             // same arithmetic as sim_bwd_finalize_kernel / sim_coef (axial_core.hip)
@@ -456,7 +474,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
     for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int k = 0; k < NCH; ++k) gq[r][k] = 0.f;
-        const int q = tid + r * MEDT_THREADS;
+        const int q = tid + r * T;
         if (q < P) {
             const int i = AXIS == 1 ? q % W : (q % HW) / W, base = q - i * sj;
 #pragma unroll
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
     // 4. gradient at the bn_qkv output -> global, and its bn_qkv backward statistics        (:228)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int q = tid + r * MEDT_THREADS;
+        const int q = tid + r * T;
         if (q < P) {
             const int ni = q / HW, p = q - ni * HW;
 #pragma unroll
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
         }
     }
     __syncthreads();
-    for (int oc = wave; oc < NCH; oc += MEDT_WAVES) {
+    for (int oc = wave; oc < NCH; oc += NW) {
         const int ch = hg * NCH + oc;
         const float mean = a.sq.mean[grp * 2 * C + ch], rstd = a.sq.rstd[grp * 2 * C + ch];
         float s1 = 0.f, s2 = 0.f;
@@ -511,12 +529,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void wopos_small_bwd_kernel(SmallBwdA
     }
 }
 
-static size_t small_bwd_lds_bytes(int gp, int P) { return ((size_t)3 * gp * P + 2 * P + 256 + 80) * sizeof(float); }
+static size_t small_bwd_lds_bytes(int gp, int P) { return ((size_t)3 * gp * P + 2 * P + 576 + 80) * sizeof(float); }
 
 bool wopos_small_bwd_ok(const AxialGeom& g, const medt_axial_desc& d) {
     if (!wopos_small_ok(g, d)) return false;
     const int P = g.npg * g.HW;
-    if (P > (g.L == 16 ? 1024 : 256)) return false;
+    if (P > (g.L == 16 ? 1024 : 256)) return false;          // R rows per thread x 512 / 256 threads
     return small_bwd_lds_bytes(g.gp, P) <= 64 * 1024;
 }
 
@@ -530,7 +548,7 @@ int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axi
     a.dqkv = dqkv; a.part_ob = part_ob; a.part_sb = part_sb; a.part_qb = part_qb;
     a.N = g.N; a.C = g.C; a.H = g.H; a.W = g.W; a.G = g.G; a.npg = g.npg;
     a.stride = d.stride; a.training = d.training ? 1 : 0; a.out_relu = d.out_relu;
-    const dim3 grid(g.groups, g.G), block(MEDT_THREADS);
+    const dim3 grid(g.groups, g.G), block(g.L == 16 ? 512 : 256);
     const size_t lds = small_bwd_lds_bytes(g.gp, g.npg * g.HW);
 #define MEDT_SMALL(AX, Lv, GPv) hipLaunchKernelGGL((wopos_small_bwd_kernel<AX, Lv, GPv>), grid, block, lds, s, a)
 #define MEDT_SMALL_GP(AX, Lv)                                                                       \
