@@ -128,95 +128,6 @@ size_t axial_core_lds_bytes(const AxialGeom& g, bool backward) {
 }
 
 // --------------------------------------------------------------------------- //
-// forward statistics pass: sum / sum-of-squares of qk, f_qr*qr, f_kr*kr per head
-// --------------------------------------------------------------------------- //
-template <int GP, bool POS, int AXIS>
-__global__ __launch_bounds__(MEDT_THREADS) void logit_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
-                                                                   BnStats qs, const float* __restrict__ relative,
-                                                                   GatePtrs gates, float* __restrict__ partials) {
-    constexpr int HQ = GP / 2, NCH = 2 * GP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = g.L, TL = 2 * L - 1, RS = (NCH + 1) * L + 1;
-    float* reg = smem;
-    float* red = reg + g.S_T * RS;
-    float* tq = red + 256;
-    float* tk = tq + HQ * TL;
-    const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
-    TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
-    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, GP, t);          // q and k channels only
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
-    if (POS) {
-        for (int e = threadIdx.x; e < HQ * TL; e += MEDT_THREADS) {
-            const int c = e / TL, d = e - c * TL;
-            tq[e] = relative[c * TL + d];
-            tk[e] = relative[(HQ + c) * TL + (TL - 1 - d)];
-        }
-    }
-    __syncthreads();
-    const int ls = threadIdx.x / L, i = threadIdx.x - ls * L;
-    const bool active = ls < t.nseq;
-    const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
-    const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
-    if (active) {
-#pragma unroll
-        for (int ch = 0; ch < GP; ++ch) {
-            const int idx = ls * RS + ch * L + i;
-            reg[idx] = fmaf(reg[idx], sc[ch], sh[ch]);
-        }
-    }
-    __syncthreads();
-    float acc[POS ? 6 : 2];
-#pragma unroll
-    for (int k = 0; k < (POS ? 6 : 2); ++k) acc[k] = 0.f;
-    if (active) {
-        float q[HQ];
-#pragma unroll
-        for (int c = 0; c < HQ; ++c) q[c] = reg[ls * RS + c * L + i];
-        const float* kp = reg + ls * RS + HQ * L;
-        for (int j = 0; j < L; ++j) {
-            const int d = i - j + L - 1;
-            float tqk = 0.f, rq = 0.f, rk = 0.f;
-#pragma unroll
-            for (int c = 0; c < HQ; ++c) {
-                const float kc = kp[c * L + j];
-                tqk = fmaf(q[c], kc, tqk);
-                if (POS) {
-                    rq = fmaf(q[c], tq[c * TL + d], rq);
-                    rk = fmaf(kc, tk[c * TL + d], rk);
-                }
-            }
-            acc[0] += tqk;
-            acc[1] = fmaf(tqk, tqk, acc[1]);
-            if (POS) {
-                const float a = f_qr * rq, b = f_kr * rk;
-                acc[2] += a;
-                acc[3] = fmaf(a, a, acc[3]);
-                acc[4] += b;
-                acc[5] = fmaf(b, b, acc[5]);
-            }
-        }
-    }
-    // partial layout [grp][tile][SC][2], channel x*G + hg
-    float* dst = partials + ((size_t)blockIdx.x * g.SC + hg) * 2;
-    float tmp[POS ? 6 : 2];
-#pragma unroll
-    for (int k = 0; k < (POS ? 6 : 2); ++k) tmp[k] = acc[k];
-    // block_sum writes dst[k*stride]; channels are G apart -> do the three pairs by hand
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < (POS ? 6 : 2); ++k) {
-        const float s = wave_sum(tmp[k]);
-        if (lane == 0) red[wave * 6 + k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < (POS ? 6 : 2)) {
-        const int k = threadIdx.x;
-        const float s = (red[k] + red[6 + k]) + (red[12 + k] + red[18 + k]);
-        dst[(size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
-    }
-}
-
-// --------------------------------------------------------------------------- //
 // forward main pass
 // --------------------------------------------------------------------------- //
 template <int GP, bool POS, int AXIS>
@@ -882,16 +793,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
         }                                                                                                     \
         return launch_status(#KERNEL);                                                                        \
     } while (0)
-
-int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      float* partials, hipStream_t s) {
-    if (fast_path_enabled()) {
-        const int rc = axial_logit_stats_fast(g, qkv_raw, qkv, relative, gates, partials, s);
-        if (rc <= 0) return rc;
-    }
-    const size_t lds = axial_core_lds_bytes(g, false);
-    MEDT_DISPATCH(logit_stats_kernel, g, qkv_raw, qkv, relative, gates, partials);
-}
 
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                    GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {

@@ -153,85 +153,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
 }
 
 // --------------------------------------------------------------------------- //
-// forward statistics pass: sum / sum of squares of qk, f_qr*qr, f_kr*kr per head
-// --------------------------------------------------------------------------- //
-template <int GP, int AXIS>
-__global__ __launch_bounds__(MEDT_THREADS) void logit_stats4_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
-                                                                    BnStats qs, const float* __restrict__ relative,
-                                                                    GatePtrs gates, float* __restrict__ partials) {
-    constexpr int HQ = GP / 2, NCH = 2 * GP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = g.L, RS = region4(NCH, L), CS = copy_stride(L);
-    float* reg = smem;
-    float* red = reg + g.S_T * RS;
-    float* tab = red + 256;
-    const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
-    TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
-    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, GP, t);           // q and k channels only
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
-    stage_tables4<GP>(tab, relative, L, 1.f);
-    __syncthreads();
-    const int ls = threadIdx.x / L, i = threadIdx.x - ls * L;
-    const bool active = ls < t.nseq;
-    const float* sc = qs.scale + grp * 2 * g.C + hg * NCH;
-    const float* sh = qs.shift + grp * 2 * g.C + hg * NCH;
-    if (active) {
-#pragma unroll
-        for (int ch = 0; ch < GP; ++ch) {
-            const int idx = ls * RS + ch * L + i;
-            reg[idx] = fmaf(reg[idx], sc[ch], sh[ch]);
-        }
-    }
-    __syncthreads();
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        float q[HQ];
-#pragma unroll
-        for (int c = 0; c < HQ; ++c) q[c] = reg[ls * RS + c * L + i];
-        const float* kp = reg + ls * RS + HQ * L;
-        const int r = i & 3;
-        const float* tabr = tab + r * CS;
-        for (int j0 = 0; j0 < L; j0 += 4) {
-            const int xoff = i - j0 + L - 4 - r;
-            float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, cc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < HQ; ++c) {
-                const float4 k4 = *reinterpret_cast<const float4*>(kp + c * L + j0);
-                const float4 q4 = *reinterpret_cast<const float4*>(tabr + (c * 4) * CS + xoff);
-                const float4 t4 = *reinterpret_cast<const float4*>(tabr + ((HQ + c) * 4) * CS + xoff);
-                a[0] = fmaf(q[c], k4.x, a[0]); b[0] = fmaf(q[c], q4.w, b[0]); cc[0] = fmaf(k4.x, t4.w, cc[0]);
-                a[1] = fmaf(q[c], k4.y, a[1]); b[1] = fmaf(q[c], q4.z, b[1]); cc[1] = fmaf(k4.y, t4.z, cc[1]);
-                a[2] = fmaf(q[c], k4.z, a[2]); b[2] = fmaf(q[c], q4.y, b[2]); cc[2] = fmaf(k4.z, t4.y, cc[2]);
-                a[3] = fmaf(q[c], k4.w, a[3]); b[3] = fmaf(q[c], q4.x, b[3]); cc[3] = fmaf(k4.w, t4.x, cc[3]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float tb = f_qr * b[u], tc = f_kr * cc[u];
-                acc[0] += a[u];
-                acc[1] = fmaf(a[u], a[u], acc[1]);
-                acc[2] += tb;
-                acc[3] = fmaf(tb, tb, acc[3]);
-                acc[4] += tc;
-                acc[5] = fmaf(tc, tc, acc[5]);
-            }
-        }
-    }
-    float* dst = partials + ((size_t)blockIdx.x * g.SC + hg) * 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float s = wave_sum(acc[k]);
-        if (lane == 0) red[wave * 6 + k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int k = threadIdx.x;
-        const float s = (red[k] + red[6 + k]) + (red[12 + k] + red[18 + k]);
-        dst[(size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
-    }
-}
-
-// --------------------------------------------------------------------------- //
 // Compile-time-L variants (L in {16,32,64,128}: every layer of the 128- and 256-pixel models).
 // On top of the above: (1) the workgroup is persistent over "super-tiles" of SS = NT*S_T adjacent sequences,
 // so the relative tables are staged once per workgroup instead of once per S_T sequences and the NCHW rows
@@ -886,102 +807,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
     }
 }
 
-template <int GP, int AXIS, int L>
-__global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
-                                                                    BnStats qs, const float* __restrict__ relative,
-                                                                    GatePtrs gates, float* __restrict__ partials) {
-    using F = Fast3<GP, L>;
-    constexpr int HQ = F::HQ, NCH = F::NCH, RS = F::RS, CS = F::CS, S_T = F::S_T;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* reg = smem;
-    float* red = reg + S_T * g.nt * RS;                       // LDS is sized for the runtime super-tile (occupancy)
-    float* tab = red + 256;
-    const int grp = blockIdx.x / g.fparts, part = blockIdx.x - grp * g.fparts, hg = blockIdx.y;
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
-    stage_tables_cols<GP>(tab, relative, L, f_kr);              // f_kr folded into the Rk rows, f_qr into q below
-    if (threadIdx.x < NCH) {                                  // bn_qkv's affine for this head group: LDS-resident
-        red[128 + threadIdx.x] = qs.scale[grp * 2 * g.C + hg * NCH + threadIdx.x];
-        red[160 + threadIdx.x] = qs.shift[grp * 2 * g.C + hg * NCH + threadIdx.x];
-    }
-    const float* sc = red + 128;
-    const float* sh = red + 160;
-    const int lsub = threadIdx.x / L, i = threadIdx.x % L;
-    const int r = (3 - i) & 3;
-    const float* tabr = tab + r * CS + (L - 1 - i - r);
-    f2 s_qk = (f2)(0.f), q_qk = (f2)(0.f), s_qr = (f2)(0.f), q_qr = (f2)(0.f), s_kr = (f2)(0.f), q_kr = (f2)(0.f);
-    const int SSr = S_T * g.nt;                               // runtime super-tile (g.nt <= NT sub-tiles)
-    const int nsup = (g.spg + SSr - 1) / SSr;
-    using Map = SuperMap<F, AXIS>;
-    using PF = SuperPrefetch<F, AXIS, GP>;                                          // q and k channels only
-    const unsigned step = (unsigned)g.fparts * SSr;
-    const int dn_step = step / (unsigned)g.Bo, ds_step = step - dn_step * g.Bo;
-    Map cur, nxt;
-    {
-        const unsigned q0 = (unsigned)part * SSr;
-        const int dn = q0 / (unsigned)g.Bo;
-        nxt.set(g, grp * g.npg + dn, q0 - dn * g.Bo, min(SSr, g.spg - (int)q0));
-    }
-    PF pf;
-    if (part < nsup) pf.issue(qkv_raw, g, hg, nxt);
-    for (int u = part; u < nsup; u += g.fparts) {
-        cur = nxt;
-        const int nseq = cur.nseq;
-        __syncthreads();
-        pf.commit(reg, g, cur, sc, sh);
-        {
-            const int un = u + g.fparts;
-            int s0 = cur.s0 + ds_step, n0 = cur.n0 + dn_step;
-            if (s0 >= g.Bo) { s0 -= g.Bo; ++n0; }
-            if (un < nsup) {
-                nxt.set(g, n0, s0, min(SSr, g.spg - un * SSr));
-                pf.issue(qkv_raw, g, hg, nxt);
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int sub = 0; sub < g.nt; ++sub) {
-            const int ls = sub * S_T + lsub;
-            if (ls < nseq) {
-                f2 q[HQ], qf[HQ];
-#pragma unroll
-                for (int c = 0; c < HQ; ++c) { q[c] = (f2)(reg[ls * RS + c * L + i]); qf[c] = q[c] * (f2)(f_qr); }
-                const float* kp = reg + ls * RS + HQ * L;
-#pragma unroll
-                for (int j0 = 0; j0 < L; j0 += 4) {
-                    f2 alo = (f2)(0.f), ahi = (f2)(0.f), blo = (f2)(0.f), bhi = (f2)(0.f), clo = (f2)(0.f), chi = (f2)(0.f);
-#pragma unroll
-                    for (int c = 0; c < HQ; ++c) {
-                        const f4 k4 = *reinterpret_cast<const f4*>(kp + c * L + j0);
-                        const f4 q4 = *reinterpret_cast<const f4*>(tabr + (c * 4) * CS + j0);
-                        const f4 t4 = *reinterpret_cast<const f4*>(tabr + ((HQ + c) * 4) * CS + j0);
-                        alo = q[c] * k4.lo + alo;  ahi = q[c] * k4.hi + ahi;
-                        blo = qf[c] * q4.lo + blo; bhi = qf[c] * q4.hi + bhi;
-                        clo = k4.lo * t4.lo + clo; chi = k4.hi * t4.hi + chi;
-                    }
-                    s_qk += alo + ahi;  q_qk = alo * alo + (ahi * ahi + q_qk);
-                    s_qr += blo + bhi;  q_qr = blo * blo + (bhi * bhi + q_qr);
-                    s_kr += clo + chi;  q_kr = clo * clo + (chi * chi + q_kr);
-                }
-            }
-        }
-    }
-    float acc[6] = {s_qk.x + s_qk.y, q_qk.x + q_qk.y, s_qr.x + s_qr.y, q_qr.x + q_qr.y, s_kr.x + s_kr.y, q_kr.x + q_kr.y};
-    __syncthreads();
-    float* dst = partials + ((size_t)blockIdx.x * g.SC + hg) * 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float s = wave_sum(acc[k]);
-        if (lane == 0) red[wave * 6 + k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int k = threadIdx.x;
-        const float s = (red[k] + red[6 + k]) + (red[12 + k] + red[18 + k]);
-        dst[(size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
-    }
-}
-
 #define MEDT_F3_CASE(KERNEL, GPv, Lv, ...)                                                                          \
     case GPv * 1024 + Lv * 2 + 0:                                                                                   \
         hipLaunchKernelGGL((KERNEL(GPv, 0, Lv)), grid, block, ((Fast3<GPv, Lv>::lds_floats - (size_t)(Fast3<GPv, Lv>::NT - g.nt) * Fast3<GPv, Lv>::S_T * Fast3<GPv, Lv>::RS) * sizeof(float)), s, __VA_ARGS__); \
@@ -1025,13 +850,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void logit_stats3_kernel(AxialGeom g,
         }                                                                                                   \
         return launch_status(#KERNEL);                                                                      \
     } while (0)
-
-int axial_logit_stats_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative,
-                           GatePtrs gates, float* partials, hipStream_t s) {
-#define MEDT_K_STATS(a, b, c) logit_stats3_kernel<a, b, c>
-    if (g.fast3) MEDT_FAST3_DISPATCH(MEDT_K_STATS, g, qkv_raw, qkv, relative, gates, partials);
-    MEDT_FAST_DISPATCH(logit_stats4_kernel, g, qkv_raw, qkv, relative, gates, partials);
-}
 
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {

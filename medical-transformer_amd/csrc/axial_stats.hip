@@ -1,0 +1,234 @@
+// axial_stats.hip -- bn_similarity batch statistics WITHOUT forming the L x L logits.
+//
+// Reference lib/models/axialnet.py:157-167 feeds cat([qk, f_qr*qr, f_kr*kr]) of shape (B*, 3G, L, L) to
+// BatchNorm2d(3G); in training mode the softmax therefore waits on sum / sum-of-squares of every logit
+// channel over (B*, L, L).  Those six moments are separable in q and k (per head, hq = gp/2 channels):
+//
+//   sum_ij qk      = sum_c  Sq_c Sk_c                          Sq_c   = sum_i q_ci          (per sequence)
+//   sum_ij qk^2    = sum_cc' Gq_cc' Gk_cc'                     Gq_cc' = sum_i q_ci q_c'i    (per sequence)
+//   sum_ij qr      = sum_i sum_c   q_ci U_c[i]                 U_c[i]   = sum_{d=i}^{i+L-1} Rq[c,d]
+//   sum_ij qr^2    = sum_i sum_cc' q_ci q_c'i T_cc'[i]         T_cc'[i] = sum_{d=i}^{i+L-1} Rq[c,d] Rq[c',d]
+//   kr likewise with k, Rk and the key index j (kr[i,j] = sum_c k_cj Rk[c, j-i+L-1], :158).
+//
+// U and T are sliding-window sums of the relative table: per layer, batch independent (sim_tables_kernel,
+// 2*(hq + hq(hq+1)/2)*L floats).  The statistics are then ONE read of the q and k channels (C*e*M bytes,
+// O(M*hq^2) flops) instead of the O(M*L*hq) logit recompute.
+//
+// Work decomposition (wave64): a 256-thread workgroup owns 64 whole sequences of one head; lane = sequence, wave =
+// quarter of the positions.  The per-sequence Gram / sum accumulators are lane-private, the position index is
+// wave-uniform (tables come in through the scalar cache).  Height layers read NCHW directly (64 consecutive columns =
+// 256 contiguous bytes per load); width layers stage [channel][sequence][position] chunks through LDS (coalesced along
+// the row, read back transposed with an odd stride).
+#include "axial_tiles.h"
+
+namespace medt {
+
+static inline int npairs(int hq) { return hq * (hq + 1) / 2; }
+
+size_t sim_tables_floats(const AxialGeom& g) { return g.pos ? (size_t)2 * (g.hq + npairs(g.hq)) * g.L : 0; }
+int sim_stats_parts(const AxialGeom& g) { return cdiv(g.spg, 64); }
+
+// tables[(side*L + i)*NR + r]: r < HQ: U_r[i];  r >= HQ: pair (c <= c') in row-major order, off-diagonal pairs
+// carry the factor 2 of the symmetric double sum.  side 0 = q rows of `relative`, 1 = k rows.
+__global__ __launch_bounds__(64) void sim_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
+                                                        int HQ, int L) {
+    const int NR = HQ + HQ * (HQ + 1) / 2, TL = 2 * L - 1;
+    const int side = blockIdx.x / NR, r = blockIdx.x - side * NR;
+    int a = r, b = -1;
+    if (r >= HQ) {
+        int p = r - HQ;
+        a = 0;
+        while (p >= HQ - a) { p -= HQ - a; ++a; }
+        b = a + p;
+    }
+    const float* Ra = relative + (size_t)(side * HQ + a) * TL;
+    const float* Rb = b >= 0 ? relative + (size_t)(side * HQ + b) * TL : nullptr;
+    const double w = (b > a) ? 2.0 : 1.0;
+    for (int i = threadIdx.x; i < L; i += 64) {
+        double acc = 0.0;
+        for (int d = i; d < i + L; ++d) acc += (double)Ra[d] * (Rb ? (double)Rb[d] : 1.0);
+        tables[((size_t)side * L + i) * NR + r] = (float)(w * acc);
+    }
+}
+
+template <int HQ, bool POS, int AXIS>
+__global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
+                                                                 BnStats qs, const float* __restrict__ tables,
+                                                                 GatePtrs gates, float* __restrict__ partials,
+                                                                 int sparts, int pc_log) {
+    constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NV = 2 * NR, RND = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = g.L, PC = 1 << pc_log, PCQ = PC >> 2, RS = PC + 1;
+    const int grp = blockIdx.x / sparts, tile = blockIdx.x - grp * sparts, hg = blockIdx.y;
+    const int seq0 = tile * 64, nseq = min(64, g.spg - seq0);
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool active = lane < nseq;
+    const int NCH = 4 * HQ;                                   // channels per head: q | k | v
+    int* seqoff = (int*)smem;                                 // [64] element offset of (sequence, channel 0 of the head, position 0)
+    float* red = smem + 64;                                   // [3][RND][64] cross-slice reduction rounds, then [4][8]
+    float* stage = smem + 64;                                 // AXIS == 1: [GP][64][PC+1] (dead before `red` is used)
+    const int pstride = AXIS == 1 ? 1 : g.W;                  // element stride between positions of a sequence
+    if (threadIdx.x < 64) {
+        const int b = grp * g.spg + seq0 + min(lane, nseq - 1);
+        const int n = b / g.Bo, sq = b - n * g.Bo;
+        seqoff[lane] = (n * 2 * g.C + hg * NCH) * g.HW + (AXIS == 1 ? sq * g.W : sq);
+    }
+    __syncthreads();
+    const int myoff = seqoff[lane];
+    float sc[GP], sh[GP];
+#pragma unroll
+    for (int ch = 0; ch < GP; ++ch) {
+        sc[ch] = qs.scale[grp * 2 * g.C + hg * NCH + ch];
+        sh[ch] = qs.shift[grp * 2 * g.C + hg * NCH + ch];
+    }
+    // v[0..HQ) = Sq, [HQ..NR) = Gq pairs, [NR..NR+HQ) = Sk, [NR+HQ..NV) = Gk pairs
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.f;
+    float r1q = 0.f, r2q = 0.f, r1k = 0.f, r2k = 0.f;
+    for (int chunk0 = 0; chunk0 < L; chunk0 += PC) {
+        if (AXIS == 1) {
+            for (int e = threadIdx.x; e < GP * 64 * PC; e += MEDT_THREADS) {
+                const int p = e & (PC - 1), ls = (e >> pc_log) & 63, ch = e >> (pc_log + 6);
+                const int i = chunk0 + p;
+                if (ls < nseq && i < L) stage[(ch * 64 + ls) * RS + p] = qkv_raw[(size_t)seqoff[ls] + (size_t)ch * g.HW + i];
+            }
+            __syncthreads();
+        }
+#pragma unroll 4
+        for (int t = 0; t < PCQ; ++t) {
+            const int p = slice * PCQ + t, i = chunk0 + p;        // wave-uniform
+            if (i < L) {
+                float x[GP];
+#pragma unroll
+                for (int ch = 0; ch < GP; ++ch) {
+                    float raw;
+                    if (AXIS == 1) raw = stage[(ch * 64 + lane) * RS + p];
+                    else raw = qkv_raw[(size_t)myoff + (size_t)ch * g.HW + (size_t)i * pstride];
+                    x[ch] = active ? fmaf(raw, sc[ch], sh[ch]) : 0.f;
+                }
+                const float* tq = tables + (size_t)i * NR;
+                const float* tk = tables + (size_t)(L + i) * NR;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    v[c] += x[c];
+                    v[NR + c] += x[HQ + c];
+                    if (POS) {
+                        r1q = fmaf(x[c], tq[c], r1q);
+                        r1k = fmaf(x[HQ + c], tk[c], r1k);
+                    }
+                }
+                int pr = 0;
+#pragma unroll
+                for (int a = 0; a < HQ; ++a) {
+#pragma unroll
+                    for (int b = a; b < HQ; ++b, ++pr) {
+                        const float pq = x[a] * x[b], pk = x[HQ + a] * x[HQ + b];
+                        v[HQ + pr] += pq;
+                        v[NR + HQ + pr] += pk;
+                        if (POS) {
+                            r2q = fmaf(pq, tq[HQ + pr], r2q);
+                            r2k = fmaf(pk, tk[HQ + pr], r2k);
+                        }
+                    }
+                }
+            }
+        }
+        if (AXIS == 1) __syncthreads();
+    }
+    // per-sequence totals: slices 1..3 hand their partial sums to slice 0, RND values per round
+#pragma unroll
+    for (int r0 = 0; r0 < NV; r0 += RND) {
+        if (slice > 0) {
+#pragma unroll
+            for (int k = 0; k < RND; ++k)
+                if (r0 + k < NV) red[((slice - 1) * RND + k) * 64 + lane] = v[r0 + k];
+        }
+        __syncthreads();
+        if (slice == 0) {
+#pragma unroll
+            for (int k = 0; k < RND; ++k)
+                if (r0 + k < NV) v[r0 + k] += (red[k * 64 + lane] + red[(RND + k) * 64 + lane]) + red[(2 * RND + k) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    float acc[6];
+    acc[0] = 0.f;
+    acc[1] = 0.f;
+    if (slice == 0) {
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) acc[0] = fmaf(v[c], v[NR + c], acc[0]);
+        int pr = 0;
+#pragma unroll
+        for (int a = 0; a < HQ; ++a) {
+#pragma unroll
+            for (int b = a; b < HQ; ++b, ++pr) {
+                const float w = (b > a) ? 2.f : 1.f;
+                acc[1] = fmaf(w * v[HQ + pr], v[NR + HQ + pr], acc[1]);
+            }
+        }
+    }
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
+    acc[2] = f_qr * r1q;
+    acc[3] = f_qr * f_qr * r2q;
+    acc[4] = f_kr * r1k;
+    acc[5] = f_kr * f_kr * r2k;
+    constexpr int NA = POS ? 6 : 2;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[slice * 8 + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NA) {                                      // partial layout [grp][part][SC][2], channel x*G + hg
+        const int k = threadIdx.x;
+        const float s = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
+        partials[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
+    }
+}
+
+static int stats_chunk_log(const AxialGeom& g) {
+    int cap = 128 / g.gp;                 // [gp q|k channels][64][PC+1] floats <= ~33 KB
+    if (cap < 4) cap = 4;
+    int pc = 4, lg = 2;
+    while (pc < g.L && pc * 2 <= cap) { pc *= 2; ++lg; }
+    return lg;
+}
+
+int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
+                      float* tables, float* partials, hipStream_t s) {
+    const int sparts = sim_stats_parts(g), lg = stats_chunk_log(g);
+    if (g.pos) {
+        if (!tables) { set_error("sim_stats: no table scratch"); return MEDT_EINVAL; }
+        hipLaunchKernelGGL(sim_tables_kernel, dim3(2 * (g.hq + npairs(g.hq))), dim3(64), 0, s, relative, tables, g.hq, g.L);
+    }
+    const size_t stage = g.axis == 1 ? (size_t)g.gp * 64 * ((1 << lg) + 1) : 0, red = 3 * 16 * 64;
+    const size_t lds = (64 + (stage > red ? stage : red)) * sizeof(float);
+    const dim3 grid(g.groups * sparts, g.G), block(MEDT_THREADS);
+#define MEDT_SS(HQv, POSv, AXv)                                                                                       \
+    hipLaunchKernelGGL((sim_stats_kernel<HQv, POSv, AXv>), grid, block, lds, s, g, qkv_raw, qkv, tables, gates, partials, \
+                       sparts, lg)
+    switch (g.hq * 4 + g.pos * 2 + g.axis) {
+        case 1 * 4 + 0: MEDT_SS(1, false, 0); break;
+        case 1 * 4 + 1: MEDT_SS(1, false, 1); break;
+        case 1 * 4 + 2: MEDT_SS(1, true, 0); break;
+        case 1 * 4 + 3: MEDT_SS(1, true, 1); break;
+        case 2 * 4 + 0: MEDT_SS(2, false, 0); break;
+        case 2 * 4 + 1: MEDT_SS(2, false, 1); break;
+        case 2 * 4 + 2: MEDT_SS(2, true, 0); break;
+        case 2 * 4 + 3: MEDT_SS(2, true, 1); break;
+        case 4 * 4 + 0: MEDT_SS(4, false, 0); break;
+        case 4 * 4 + 1: MEDT_SS(4, false, 1); break;
+        case 4 * 4 + 2: MEDT_SS(4, true, 0); break;
+        case 4 * 4 + 3: MEDT_SS(4, true, 1); break;
+        case 8 * 4 + 0: MEDT_SS(8, false, 0); break;
+        case 8 * 4 + 1: MEDT_SS(8, false, 1); break;
+        case 8 * 4 + 2: MEDT_SS(8, true, 0); break;
+        case 8 * 4 + 3: MEDT_SS(8, true, 1); break;
+        default: set_error("sim_stats: no instantiation for hq=%d", g.hq); return MEDT_EUNSUPPORTED;
+    }
+#undef MEDT_SS
+    return launch_status("sim_stats_kernel");
+}
+
+}  // namespace medt

@@ -35,7 +35,7 @@ struct LayerStats {
 };
 
 struct FwdWs {
-    float *part_qkv, *part_sim, *part_out, *qkv_ksplit;
+    float *part_qkv, *part_sim, *part_out, *qkv_ksplit, *tables;
     unsigned* flag;
     FwdWs(Carver& c, const AxialGeom& g) {
         flag = c.take<unsigned>(4);
@@ -43,7 +43,8 @@ struct FwdWs {
         qkv_ksplit = c.take<float>(kq);
         if (!kq) qkv_ksplit = nullptr;
         part_qkv = c.take<float>((size_t)g.groups * conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1) * 2 * g.C * 2);
-        part_sim = c.take<float>((size_t)g.groups * g.tpg * g.SC * 2);
+        part_sim = c.take<float>((size_t)g.groups * sim_stats_parts(g) * g.SC * 2);
+        tables = c.take<float>(sim_tables_floats(g));
         part_out = c.take<float>((size_t)g.groups * g.tpg * g.OC * 2);
     }
 };
@@ -118,7 +119,7 @@ int medt_axial_core_stats(const medt_axial_desc* d, const medt_axial_params* p, 
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     LayerStats st(sv->stats, g);
     GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
-    return axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.part_sim, (hipStream_t)stream);
+    return axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, (hipStream_t)stream);
 }
 
 int medt_axial_core_fwd(const medt_axial_desc* d, const medt_axial_params* p, const medt_axial_saved* sv, void* ws,
@@ -163,8 +164,8 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
                           st.qkv, s))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
-    if (tr && (rc = axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.part_sim, s))) return rc;
-    if ((rc = bn_finalize(w.part_sim, g.fparts, g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,
+    if (tr && (rc = axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
+    if ((rc = bn_finalize(w.part_sim, sim_stats_parts(g), g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,
                           st.sim, s))) return rc;
     // logits + softmax + gated sv|sve, bn_output batch statistics                                 :157-178
     if ((rc = axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,

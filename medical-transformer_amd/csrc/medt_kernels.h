@@ -114,8 +114,6 @@ size_t axial_core_lds_bytes(const AxialGeom& g, bool backward);
 struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; };
 
 // axial_fast.hip: 16-byte-LDS-read variants for has_pos && L % 4 == 0; return 1 when not applicable
-int axial_logit_stats_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative,
-                           GatePtrs gates, float* partials, hipStream_t s);
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
 int fast3_max_subtiles(int gp, int L, int axis);
@@ -141,9 +139,13 @@ int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const
                              BnStats so, float* coef_qkv, const medt_axial_grads& gr, hipStream_t s);
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
-// logit statistics: partials [group][tile][SC][2]
+// axial_stats.hip: bn_similarity batch statistics in closed form (one read of q and k, no L x L pass).
+// partials [group][sim_stats_parts()][SC][2]; tables: sim_tables_floats() floats of scratch (sliding-window sums
+// of the relative table, rebuilt by every call)
+size_t sim_tables_floats(const AxialGeom& g);
+int sim_stats_parts(const AxialGeom& g);
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      float* partials, hipStream_t s);
+                      float* tables, float* partials, hipStream_t s);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                    GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);

@@ -2,16 +2,21 @@
 
 torch.optim.Adam(list(model.parameters()), lr, weight_decay=1e-5) semantics (coupled L2 decay, bias
 correction, parameters that never receive a gradient are left untouched) over contiguous fp32 buffers:
-parameters become views of one flat tensor, their gradients are packed into a matching flat tensor that
-doubles as the data-parallel all-reduce bucket (dp.py), and medt_adam_step updates everything in one
-launch with the step counter kept on the device (hipGraph-replayable).
+parameters become views of one flat tensor and own a *gradient slot* -- a view of a matching flat
+gradient tensor that doubles as the data-parallel all-reduce bucket.  The backward kernels of
+medt_amd.ops / medt_amd.axial write parameter gradients straight into those slots (no autograd
+AccumulateGrad copies, no packing pass); medt_adam_step then updates everything in one launch with the
+step counter kept on the device (hipGraph-replayable).
 
-Parameters join a flat group the first time they show up with a gradient.  The gates
-(f_qr/f_kr/f_sve/f_sv, requires_grad=False until train.py:169-171 flips them at epoch 10) therefore
-form a second group with its own step counter -- exactly torch.optim.Adam's per-parameter `step`.
+Parameters join a flat group the first time they show up with a gradient (that first gradient comes
+through autograd's ordinary `.grad` and is copied in once).  The gates (f_qr/f_kr/f_sve/f_sv,
+requires_grad=False until train.py:169-171 flips them at epoch 10) therefore form a second group with
+its own step counter -- exactly torch.optim.Adam's per-parameter `step`.  Membership is a property of
+the model, not of the data, so every data-parallel rank builds identical buckets.
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -19,14 +24,47 @@ import torch.distributed as dist
 
 from . import _lib as L
 
-
-import os
-
 FORCE_COLLECTIVES = os.environ.get("MEDT_FORCE_DIST") == "1"      # run the all-reduce even with one rank (tests)
 
 
+def collectives_needed() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+class GradSlot:
+    """Where a parameter's gradient lives: a view into its group's flat gradient bucket.
+
+    `stamp` records the optimizer step in which the slot was last written, so that a parameter used twice
+    in one forward (never the case in the reference's networks) still accumulates instead of overwriting."""
+    __slots__ = ("view", "owner", "stamp")
+
+    def __init__(self, view, owner):
+        self.view, self.owner, self.stamp = view, owner, -1
+
+
+def grad_slot(p):
+    """The live slot of parameter `p`, or None (not adopted by a FlatAdam / frozen / not a leaf)."""
+    s = getattr(p, "_medt_gslot", None)
+    if s is None or not p.requires_grad:
+        return None
+    return s
+
+
+def claim(slot: GradSlot):
+    """-> (tensor to write the gradient into, direct).  direct=False: the slot already holds this step's gradient
+    of another use of the parameter; the caller writes a temporary and calls `accumulate`."""
+    if slot.stamp != slot.owner.stamp:
+        slot.stamp = slot.owner.stamp
+        return slot.view, True
+    return torch.empty_like(slot.view), False
+
+
+def accumulate(slot: GradSlot, tmp):
+    slot.view.add_(tmp)
+
+
 class _Group:
-    def __init__(self, params: List[torch.nn.Parameter]):
+    def __init__(self, params: List[torch.nn.Parameter], owner):
         dev = params[0].device
         self.params = params
         self.numel = sum(p.numel() for p in params)
@@ -35,15 +73,21 @@ class _Group:
         self.exp_avg = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.state = torch.zeros(3, device=dev, dtype=torch.float32)        # [step, 1-b1^t, 1-b2^t]
-        self.gviews = []
         off = 0
         for p in params:
             n = p.numel()
             view = self.flat_p[off:off + n].view(p.shape)
             view.copy_(p.data)
             p.data = view                                     # the module now reads the flat buffer
-            self.gviews.append(self.flat_g[off:off + n].view(p.shape))
+            gview = self.flat_g[off:off + n].view(p.shape)
+            gview.copy_(p.grad)                               # the gradient of the adopting step
+            p.grad = gview                                    # .grad IS the slot from now on
+            p._medt_gslot = GradSlot(gview, owner)
+            p._medt_gslot.stamp = owner.stamp
             off += n
+
+    def tensors(self):
+        return (self.flat_p, self.exp_avg, self.exp_avg_sq, self.state)
 
 
 class FlatAdam:
@@ -52,49 +96,81 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.groups: List[_Group] = []
         self._member = set()
+        self.stamp = 0
 
+    # ---- gradient bookkeeping ------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
+        """Start a new step.  Adopted parameters keep `.grad` pointing at their slot (the backward kernels overwrite
+        it); everything else is reset to None as torch.optim does."""
+        self.stamp += 1
         for p in self.params:
-            p.grad = None
+            if id(p) not in self._member:
+                p.grad = None
 
     def _adopt_new(self):
         new = [p for p in self.params if p.grad is not None and id(p) not in self._member]
         if new:
             for p in new:
-                if not p.is_cuda or p.dtype != torch.float32:
-                    raise L.MedtError("FlatAdam: float32 parameters on the GPU expected")
+                if p.dtype != torch.float32:
+                    raise L.MedtError("FlatAdam: float32 parameters expected")
                 self._member.add(id(p))
-            self.groups.append(_Group(new))
+            self.groups.append(_Group(new, self))
 
     def pack_gradients(self):
-        """Copy the autograd-produced gradients into the flat buckets (a few multi-tensor launches)."""
+        """Adopt parameters that received their first gradient; check that every adopted one was written this step."""
         self._adopt_new()
         for g in self.groups:
-            grads = [p.grad for p in g.params]
-            if any(gr is None for gr in grads):
-                raise L.MedtError("FlatAdam: a parameter that used to receive gradients did not this step")
-            torch._foreach_copy_(g.gviews, grads)
+            for p in g.params:
+                if p.requires_grad and p._medt_gslot.stamp != self.stamp:
+                    raise L.MedtError("FlatAdam: a parameter that used to receive gradients did not this step")
 
+    def signature(self):
+        """What a captured step depends on: group membership and which parameters are trainable."""
+        return (tuple(g.numel for g in self.groups), tuple(p.requires_grad for p in self.params))
+
+    # ---- data parallel -----------------------------------------------------------
     def allreduce(self):
         """Sum the flat buckets over ranks (the 1/world factor is folded into the Adam kernel)."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
+        if collectives_needed():
             for g in self.groups:
                 dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM)
 
-    def apply(self, world: int = 1):
+    # ---- update ----------------------------------------------------------------------
+    def _launch_adam(self, g: _Group, gscale: float):
+        if not g.flat_p.is_cuda:
+            raise L.MedtError("FlatAdam: parameters must live on the GPU (medt_adam_step is a HIP kernel; there is no "
+                              "CPU fallback)")
         lib = L.lib()
         stream = torch.cuda.current_stream().cuda_stream
+        L.check(lib.medt_adam_step(g.flat_p.data_ptr(), g.flat_g.data_ptr(), g.exp_avg.data_ptr(),
+                                   g.exp_avg_sq.data_ptr(), g.state.data_ptr(), g.numel, self.lr, self.betas[0],
+                                   self.betas[1], self.eps, self.weight_decay, gscale, stream), "medt_adam_step")
+
+    def apply(self, world: int = 1):
         for g in self.groups:
-            L.check(lib.medt_adam_step(g.flat_p.data_ptr(), g.flat_g.data_ptr(), g.exp_avg.data_ptr(),
-                                       g.exp_avg_sq.data_ptr(), g.state.data_ptr(), g.numel, self.lr, self.betas[0],
-                                       self.betas[1], self.eps, self.weight_decay, 1.0 / world, stream),
-                    "medt_adam_step")
+            self._launch_adam(g, 1.0 / world)
 
     def step(self):
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.pack_gradients()
         self.allreduce()
         self.apply(world)
+
+    # ---- snapshot / restore (hipGraph warm-up must not advance the optimisation, trainer.py) --------------
+    def snapshot(self):
+        return [tuple(t.clone() for t in g.tensors()) for g in self.groups]
+
+    def restore(self, snap):
+        """Groups that existed at snapshot time get their values back; groups adopted since are reset to a fresh
+        optimizer state (their parameters are restored by the caller, who snapshots the model)."""
+        for i, g in enumerate(self.groups):
+            if i < len(snap):
+                for t, s in zip(g.tensors(), snap[i]):
+                    t.copy_(s)
+            else:
+                g.exp_avg.zero_()
+                g.exp_avg_sq.zero_()
+                g.state.zero_()
 
     # checkpointing parity with torch.optim.Adam is out of scope: the reference never saves optimizer state
     # (train.py:216-217 saves model.state_dict() only).
