@@ -185,9 +185,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_dist = os.environ.get("MEDT_FORCE_DIST") == "1" and "RANK" in os.environ    # exercise the RCCL path on 1 GPU
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+        log(f"rank {rank}/{world}: process group up, backend={dist.get_backend()}")
 
     if args.roofline_only:
         print(json.dumps({"roofline": roofline_leg(device)}))
@@ -215,17 +217,17 @@ def main():
     for _ in range(args.warmup):
         step()
     log("warm-up done; timing")
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -241,6 +243,8 @@ def main():
                                f"BASELINE.json configs[2]" + ("" if world == 1 else f" x{world} data-parallel, flat-bucket all-reduce"),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "final_loss": final_loss, "hip_graph": not args.eager,
+        "collective": (f"{dist.get_backend()} all_reduce(SUM) of the flat gradient bucket, outside the graph"
+                       if distributed else None),
     }
     if rank == 0 and world == 1:
         model.eval()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 4
+#define MEDT_ABI_VERSION 5
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -170,7 +170,10 @@ int medt_logo_merge_fwd(const float* x, const float* yp, float* y, int N, int C,
 int medt_logo_merge_bwd(const float* dy, float* dx, float* dyp, int N, int C, int S, int P, int G, void* stream);
 
 /* LogNLLLoss.forward == F.cross_entropy(mean, ignore_index) (metrics.py:17-20).  logits (N,K,HW) float,
- * target (N,HW) int64.  loss_out: 2 floats [mean loss, number of counted pixels].  partials: medt_ce_partials() floats. */
+ * target (N,HW) int64.  loss_out: 3 floats [mean loss, number of counted pixels, number of targets outside [0,K) that
+ * are not ignore_index].  F.cross_entropy raises on such targets; a kernel cannot, so they are excluded from the mean
+ * and COUNTED -- the host side (medt_amd.ops.cross_entropy, TrainStep.check_targets) raises from the count.  All pixels
+ * ignored -> 0/0 = NaN, as in torch.  partials: medt_ce_partials() floats. */
 size_t medt_ce_partials(int N, int HW);
 int medt_ce_fwd(const float* logits, const int64_t* target, float* partials, float* loss_out, int N, int K, int HW,
                 int ignore_index, void* stream);

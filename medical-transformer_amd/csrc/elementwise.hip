@@ -267,12 +267,13 @@ __global__ __launch_bounds__(MEDT_THREADS) void ce_fwd_kernel(const float* __res
                                                               const int64_t* __restrict__ target,
                                                               float* __restrict__ partials, int K, int HW, int ignore,
                                                               size_t total) {
-    __shared__ float red[MEDT_WAVES * 2];
+    __shared__ float red[MEDT_WAVES * 3];
     const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;     // over N*HW
-    float v[2] = {0.f, 0.f};
+    float v[3] = {0.f, 0.f, 0.f};
     if (idx < total) {
         const size_t n = idx / HW, p = idx - n * HW;
         const int64_t t = target[idx];
+        if (t != ignore && (t < 0 || t >= K)) v[2] = 1.f;      // F.cross_entropy raises on these: counted, reported
         if (t != ignore && t >= 0 && t < K) {
             const float* lp = logits + n * K * HW + p;
             float m = lp[0];
@@ -283,22 +284,24 @@ __global__ __launch_bounds__(MEDT_THREADS) void ce_fwd_kernel(const float* __res
             v[1] = 1.f;
         }
     }
-    block_sum<2>(v, red, partials + (size_t)blockIdx.x * 2);
+    block_sum<3>(v, red, partials + (size_t)blockIdx.x * 3);
 }
 
-// loss_out[0] = sum/count, loss_out[1] = count
+// loss_out[0] = sum/count, loss_out[1] = count, loss_out[2] = number of out-of-range targets
 __global__ __launch_bounds__(64) void ce_finalize_kernel(const float* __restrict__ partials, int nparts,
                                                          float* __restrict__ loss_out) {
-    double s = 0.0, c = 0.0;
+    double s = 0.0, c = 0.0, b = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 64) {
-        s += (double)partials[2 * p];
-        c += (double)partials[2 * p + 1];
+        s += (double)partials[3 * p];
+        c += (double)partials[3 * p + 1];
+        b += (double)partials[3 * p + 2];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); b += __shfl_xor(b, o, 64); }
     if (threadIdx.x == 0) {
         loss_out[0] = (float)(s / c);
         loss_out[1] = (float)c;
+        loss_out[2] = (float)b;
     }
 }
 

@@ -142,6 +142,10 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
     if (!x || !y) { set_error("null x / y"); return MEDT_EINVAL; }
+    if (d->training && g.row_count <= 1.0) {      // nn.BatchNorm raises here too; the unbiased running variance divides by count-1
+        set_error("axial: training-mode BatchNorm needs more than 1 value per channel (got %g)", g.row_count);
+        return MEDT_EINVAL;
+    }
     Carver c(ws, ws_bytes);
     FwdWs w(c, g);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
@@ -319,6 +323,9 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
                           d->K, d->stride, d->pad, d->relu, 1, s);
     const int tr = d->training ? 1 : 0;
     if (!tr && (!bn->running_mean || !bn->running_var)) { set_error("conv fwd: eval mode needs running statistics"); return MEDT_EINVAL; }
+    if (tr && (double)(d->N / d->bn_groups) * g.HoWo <= 1.0) {
+        set_error("conv fwd: training-mode BatchNorm needs more than 1 value per channel"); return MEDT_EINVAL;
+    }
     BnStats st(stats, d->bn_groups * d->Cout);
     if (conv_small_ok(*d)) {
         // small BN groups (local branch): conv + exact block-level statistics + normalise/residual/ReLU in one kernel,
@@ -397,7 +404,7 @@ int medt_logo_merge_bwd(const float* dy, float* dx, float* dyp, int N, int C, in
     if (!dy || !dx || !dyp || G * P > S) { set_error("logo_merge bwd: bad arguments"); return MEDT_EINVAL; }
     return logo_merge_bwd(dy, dx, dyp, N, C, S, P, G, (hipStream_t)stream);
 }
-size_t medt_ce_partials(int N, int HW) { return (size_t)2 * ce_parts((size_t)N * HW); }
+size_t medt_ce_partials(int N, int HW) { return (size_t)3 * ce_parts((size_t)N * HW); }
 int medt_ce_fwd(const float* logits, const int64_t* target, float* partials, float* loss_out, int N, int K, int HW,
                 int ignore_index, void* stream) {
     if (!logits || !target || !partials || !loss_out || K < 1) { set_error("ce fwd: bad arguments"); return MEDT_EINVAL; }

@@ -14,6 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: provides the HIP runtime the lib
 from .build import LIB_PATH
 
 _lib = None
+ABI_VERSION = 5
 
 
 class MedtError(RuntimeError):
@@ -107,7 +108,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.medt_abi_version() != 4:
+        if l.medt_abi_version() != ABI_VERSION:
             raise MedtError("libmedt_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from . import optim as OPT
 
 
 class AxialConfig:
@@ -33,6 +34,13 @@ def _require_device(x: torch.Tensor):
                           "(the CPU restatement under oracle/ is test infrastructure)")
     if x.dtype != torch.float32:
         raise L.MedtError(f"medt_amd: float32 activations expected, got {x.dtype}")
+
+
+def _momentum(bn) -> float:
+    if bn.momentum is None:
+        raise L.MedtError("BatchNorm momentum=None (cumulative moving average) is not implemented by the HIP kernels; "
+                          "the reference uses the default 0.1 everywhere")
+    return float(bn.momentum)
 
 
 def _bn_ptrs(bn, training: bool) -> L.BnPtrs:
@@ -84,6 +92,10 @@ class AxialAttentionFn(torch.autograd.Function):
         L.check(lib.medt_axial_layer_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
                                          ws.data_ptr(), ws_bytes, stream), "medt_axial_layer_fwd")
         ctx.cfg, ctx.training, ctx.has_gates = cfg, training, gates is not None
+        # gradient slots of the parameters (views into FlatAdam's flat bucket): backward writes them directly
+        ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None
+                          for t in (w_qkv, bnq_w, bnq_b, bns_w, bns_b, bno_w, bno_b, relative))
+        ctx.gate_slots = tuple(OPT.grad_slot(t) for t in gates) if gates is not None else None
         ctx.save_for_backward(x, w_qkv, relative, f_qr, f_kr, f_sve, f_sv, qkv_raw, stacked, lse, stats,
                               y if cfg.out_relu else None)
         return y
@@ -101,15 +113,44 @@ class AxialAttentionFn(torch.autograd.Function):
         Cc = x.shape[1]
         SC = (3 if cfg.has_pos else 1) * cfg.groups
         OC = (2 if cfg.has_pos else 1) * Cc
-        # one flat buffer for all the small parameter gradients
-        sizes = [2 * Cc * Cc, 2 * Cc, 2 * Cc, SC, SC, OC, OC, relative.numel() if relative is not None else 0, 4]
-        flat = torch.empty((sum(sizes),), device=dev, dtype=torch.float32)
-        parts = list(torch.split(flat, sizes))
+        sizes = [2 * Cc * Cc, 2 * Cc, 2 * Cc, SC, SC, OC, OC, relative.numel() if relative is not None else 0]
+        shapes = [w_qkv.shape, None, None, None, None, None, None, relative.shape if relative is not None else None]
+        # destinations: the parameter's gradient slot in FlatAdam's flat bucket when it has one (nothing is returned to
+        # autograd then), otherwise a slice of one temporary that is handed back as the gradient
+        dst, ret, pend, need_tmp = [None] * 8, [None] * 8, [], []
+        for k in range(8):
+            if sizes[k] == 0:
+                continue
+            slot = ctx.slots[k]
+            if slot is not None and ctx.needs_input_grad[k + 1]:
+                dst[k], direct = OPT.claim(slot)
+                if not direct:
+                    pend.append((slot, dst[k]))
+            else:
+                need_tmp.append(k)
         want_gates = ctx.has_gates and any(ctx.needs_input_grad[9:13])
+        gate_direct = False
+        if want_gates:
+            gs = ctx.gate_slots
+            if all(g_ is not None for g_ in gs) and all(ctx.needs_input_grad[9:13]) and \
+                    all(gs[i + 1].view.data_ptr() == gs[i].view.data_ptr() + 4 for i in range(3)) and \
+                    all(g_.stamp != g_.owner.stamp for g_ in gs):
+                for g_ in gs:                                   # four adjacent 0-d slots == the ABI's float[4]
+                    OPT.claim(g_)
+                gate_direct = True
+        tmp_sizes = [sizes[k] for k in need_tmp] + ([4] if (want_gates and not gate_direct) else [])
+        if tmp_sizes:
+            parts = list(torch.split(torch.empty((sum(tmp_sizes),), device=dev, dtype=torch.float32), tmp_sizes))
+            for k, part in zip(need_tmp, parts):
+                dst[k] = part
+                if ctx.needs_input_grad[k + 1]:
+                    ret[k] = part.view(shapes[k]) if shapes[k] is not None else part
+        if want_gates:
+            gate_ptr = ctx.gate_slots[0].view.data_ptr() if gate_direct else parts[-1].data_ptr()
+        else:
+            gate_ptr = None
         dx = torch.empty_like(x)
-        grads = L.AxialGrads(*[p.data_ptr() for p in parts[:7]],
-                             parts[7].data_ptr() if relative is not None else None,
-                             parts[8].data_ptr() if want_gates else None)
+        grads = L.AxialGrads(*[L.ptr(t) for t in dst], gate_ptr)
         saved = L.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
         ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
@@ -117,14 +158,14 @@ class AxialAttentionFn(torch.autograd.Function):
         L.check(lib.medt_axial_layer_bwd(C.byref(desc), C.byref(params), x.data_ptr(), L.ptr(y), dy.data_ptr(), C.byref(saved),
                                          dx.data_ptr(), C.byref(grads), ws.data_ptr(), ws_bytes, stream),
                 "medt_axial_layer_bwd")
-        dw = parts[0].view_as(w_qkv)
-        drel = parts[7].view_as(relative) if relative is not None else None
-        if want_gates:
-            gg = parts[8]
-            dg = [gg[0].reshape(()), gg[1].reshape(()), gg[2].reshape(()), gg[3].reshape(())]
+        for slot, tmp in pend:
+            OPT.accumulate(slot, tmp)
+        if want_gates and not gate_direct:
+            gg = parts[-1]
+            dg = [gg[i].reshape(()) if ctx.needs_input_grad[9 + i] else None for i in range(4)]
         else:
             dg = [None] * 4
-        return (dx, dw, parts[1], parts[2], parts[3], parts[4], parts[5], parts[6], drel, dg[0], dg[1], dg[2], dg[3],
+        return (dx, ret[0], ret[1], ret[2], ret[3], ret[4], ret[5], ret[6], ret[7], dg[0], dg[1], dg[2], dg[3],
                 None, None)
 
 
@@ -136,7 +177,7 @@ def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: O
     gates = (f_qr, f_kr, f_sve, f_sv) 0-d tensors or None (ungated: all ones).
     """
     cfg = AxialConfig(groups, 1 if width else 0, relative is not None, stride, bn_qkv, bn_similarity, bn_output,
-                      bn_groups, bn_qkv.eps, bn_qkv.momentum if bn_qkv.momentum is not None else 0.1, out_relu)
+                      bn_groups, bn_qkv.eps, _momentum(bn_qkv), out_relu)
     g = gates if gates is not None else (None, None, None, None)
     return AxialAttentionFn.apply(x, qkv_weight, bn_qkv.weight, bn_qkv.bias, bn_similarity.weight,
                                   bn_similarity.bias, bn_output.weight, bn_output.bias, relative,

@@ -6,10 +6,13 @@ parameter broadcast + scatter/gather + reduce-to-GPU-0 become a one-off paramete
 sum-all-reduce of ~6 MB (MedT: 1,524,546 gradient elements).  BatchNorm statistics stay local to the
 shard, exactly as under DataParallel (per-replica batch statistics; rank 0's running stats are the
 ones checkpointed).
+
+The per-step exchange itself lives where the bucket lives: medt_amd.optim.FlatAdam.allreduce (one
+dist.all_reduce(SUM) per flat gradient bucket, the 1/world factor folded into medt_adam_step), driven by
+medt_amd.trainer.TrainStep.  torch.distributed is the transport boundary (backend "nccl" == RCCL on ROCm):
+the library never owns a communicator, so the same step runs under gloo in the CPU tests.
 """
 from __future__ import annotations
-
-from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
@@ -35,52 +38,3 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
-
-
-class GradBucket:
-    """Flat fp32 bucket over the parameters that receive gradients.
-
-    Every rank must build it over the same parameter list in the same order (parameters without a
-    gradient -- the gates before train.py:169-171 flips them on, MedT's never-used tensors -- are
-    excluded identically everywhere because `.grad is None` is a property of the model, not the data).
-    """
-
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.grad is not None]
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = None
-
-    def signature(self):
-        return tuple(p.numel() for p in self.params)
-
-    def allreduce_mean(self) -> None:
-        if not self.params:
-            return
-        world = dist.get_world_size() if is_distributed() else 1
-        if world == 1:
-            return
-        dev = self.params[0].grad.device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
-        off = 0
-        views = []
-        for p in self.params:
-            n = p.numel()
-            v = self.flat[off:off + n]
-            v.copy_(p.grad.reshape(-1))
-            views.append(v)
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.mul_(1.0 / world)
-        for p, v in zip(self.params, views):
-            p.grad.copy_(v.view_as(p.grad))
-
-
-def allreduce_gradients(module: torch.nn.Module, bucket: GradBucket | None = None) -> GradBucket:
-    """Average gradients over ranks.  Returns the (possibly rebuilt) bucket for reuse next step."""
-    params = list(module.parameters())
-    sig = tuple(p.numel() for p in params if p.grad is not None)
-    if bucket is None or bucket.signature() != sig:
-        bucket = GradBucket(params)
-    bucket.allreduce_mean()
-    return bucket

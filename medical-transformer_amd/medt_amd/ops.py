@@ -8,11 +8,13 @@ PyTorch supplies device memory, the stream and the autograd graph only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
-from .axial import _bn_ptrs, _require_device
+from . import optim as OPT
+from .axial import _bn_ptrs, _momentum, _require_device
 
 
 def _stream():
@@ -35,7 +37,7 @@ def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDe
     return L.ConvDesc(N, Cin, H, W, w.shape[0], w.shape[2], cfg.stride, cfg.pad, int(has_bias), int(bn is not None),
                       int(has_res), int(cfg.relu), int(training), cfg.bn_groups,
                       bn.eps if bn is not None else 1e-5,
-                      (bn.momentum if bn is not None and bn.momentum is not None else 0.1))
+                      _momentum(bn) if bn is not None else 0.1)
 
 
 class ConvBlockFn(torch.autograd.Function):
@@ -63,6 +65,8 @@ class ConvBlockFn(torch.autograd.Function):
                                         C.byref(bnp) if has_bn else None, L.ptr(res), z.data_ptr(), y.data_ptr(),
                                         stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "medt_conv_block_fwd")
         ctx.cfg, ctx.training, ctx.has_bias, ctx.has_res = cfg, training, bias is not None, res is not None
+        # gradient slots of (w, bias, bn.weight, bn.bias) in FlatAdam's flat bucket: backward writes them directly
+        ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None for t in (w, bias, bn_w, bn_b))
         ctx.save_for_backward(x, w, z if has_bn else None, y if (cfg.relu or has_bn) else None,
                               stats if has_bn else None)
         return y
@@ -79,19 +83,32 @@ class ConvBlockFn(torch.autograd.Function):
         Cout = w.shape[0]
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
-        dw = torch.empty_like(w)
-        dbias = torch.empty((Cout,), device=dev, dtype=torch.float32) if ctx.has_bias else None
-        dbn = torch.empty((2, Cout), device=dev, dtype=torch.float32) if has_bn else None
+        present = (True, ctx.has_bias, has_bn, has_bn)
+        shapes = (w.shape, (Cout,), (Cout,), (Cout,))
+        dst, ret, pend = [None] * 4, [None] * 4, []
+        for k in range(4):
+            if not present[k]:
+                continue
+            slot = ctx.slots[k]
+            if slot is not None and ctx.needs_input_grad[k + 1]:
+                dst[k], direct = OPT.claim(slot)
+                if not direct:
+                    pend.append((slot, dst[k]))
+            else:
+                dst[k] = torch.empty(shapes[k], device=dev, dtype=torch.float32)
+                if ctx.needs_input_grad[k + 1]:
+                    ret[k] = dst[k]
         dres = torch.empty_like(dy) if ctx.has_res else None
         ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         bnp = _bn_ptrs(cfg.bn, False) if has_bn else None
         L.check(lib.medt_conv_block_bwd(C.byref(desc), x.data_ptr(), w.data_ptr(), C.byref(bnp) if has_bn else None,
-                                        L.ptr(z), L.ptr(y), L.ptr(stats), dy.data_ptr(), L.ptr(dx), dw.data_ptr(),
-                                        L.ptr(dbias), dbn[0].data_ptr() if has_bn else None,
-                                        dbn[1].data_ptr() if has_bn else None, L.ptr(dres), ws.data_ptr(), ws_bytes,
+                                        L.ptr(z), L.ptr(y), L.ptr(stats), dy.data_ptr(), L.ptr(dx), dst[0].data_ptr(),
+                                        L.ptr(dst[1]), L.ptr(dst[2]), L.ptr(dst[3]), L.ptr(dres), ws.data_ptr(), ws_bytes,
                                         _stream()), "medt_conv_block_bwd")
-        return (dx, dw, dbias, dbn[0] if has_bn else None, dbn[1] if has_bn else None, dres, None, None)
+        for slot, tmp in pend:
+            OPT.accumulate(slot, tmp)
+        return (dx, ret[0], ret[1], ret[2], ret[3], dres, None, None)
 
 
 def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups=1):
@@ -190,15 +207,17 @@ class CrossEntropyFn(torch.autograd.Function):
         N, K = logits.shape[0], logits.shape[1]
         HW = logits[0, 0].numel()
         partials = torch.empty((lib.medt_ce_partials(N, HW),), device=logits.device, dtype=torch.float32)
-        out = torch.empty((2,), device=logits.device, dtype=torch.float32)
+        out = torch.empty((3,), device=logits.device, dtype=torch.float32)
         L.check(lib.medt_ce_fwd(logits.data_ptr(), target.data_ptr(), partials.data_ptr(), out.data_ptr(), N, K, HW,
                                 ignore_index, _stream()), "medt_ce_fwd")
         ctx.save_for_backward(logits, target, out)
         ctx.ignore_index = ignore_index
-        return out[0]
+        loss = out[0]
+        ctx.mark_non_differentiable(out)
+        return loss, out
 
     @staticmethod
-    def backward(ctx, dloss):
+    def backward(ctx, dloss, _dout):
         lib = L.lib()
         logits, target, out = ctx.saved_tensors
         N, K = logits.shape[0], logits.shape[1]
@@ -210,9 +229,28 @@ class CrossEntropyFn(torch.autograd.Function):
         return dlogits, None, None
 
 
+CHECK_TARGETS = os.environ.get("MEDT_CHECK_TARGETS", "1") != "0"
+
+
 def cross_entropy(logits, target, ignore_index=-100):
-    """F.cross_entropy(logits, target) with mean reduction (what LogNLLLoss.forward computes, metrics.py:17-20)."""
-    return CrossEntropyFn.apply(logits, target, ignore_index)
+    """F.cross_entropy(logits, target) with mean reduction (what LogNLLLoss.forward computes, metrics.py:17-20).
+
+    Class indices outside [0, K) that are not `ignore_index` make torch raise; here the kernel counts them and this
+    wrapper raises MedtError from the count (one host sync; skipped while a hipGraph is being captured -- TrainStep
+    checks the same counter after the replay -- and when MEDT_CHECK_TARGETS=0)."""
+    loss, out = CrossEntropyFn.apply(logits, target, ignore_index)
+    loss._medt_ce_out = out                       # [mean loss, counted pixels, out-of-range targets]
+    if CHECK_TARGETS and not torch.cuda.is_current_stream_capturing():
+        raise_on_bad_targets(out, logits.shape[1])
+    return loss
+
+
+def raise_on_bad_targets(out, K):
+    bad = int(out[2].item())
+    if bad:
+        rng = f"[0, {K})" if K > 0 else "[0, num_classes)"
+        raise L.MedtError(f"cross_entropy: {bad} target value(s) outside {rng} that are not ignore_index "
+                          "(torch.nn.functional.cross_entropy raises on these too)")
 
 
 # --------------------------------------------------------------------------- #

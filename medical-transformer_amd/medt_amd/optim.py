@@ -100,12 +100,11 @@ class FlatAdam:
 
     # ---- gradient bookkeeping ------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
-        """Start a new step.  Adopted parameters keep `.grad` pointing at their slot (the backward kernels overwrite
-        it); everything else is reset to None as torch.optim does."""
+        """Start a new step: `.grad` of every parameter is reset to None, as torch.optim does.  The slot-aware backward
+        kernels write into the slots; pack_gradients() then points `.grad` back at them."""
         self.stamp += 1
         for p in self.params:
-            if id(p) not in self._member:
-                p.grad = None
+            p.grad = None
 
     def _adopt_new(self):
         new = [p for p in self.params if p.grad is not None and id(p) not in self._member]
@@ -117,12 +116,30 @@ class FlatAdam:
             self.groups.append(_Group(new, self))
 
     def pack_gradients(self):
-        """Adopt parameters that received their first gradient; check that every adopted one was written this step."""
+        """Make the flat buckets hold this step's gradients.
+
+        Parameters whose backward kernel wrote its slot directly need nothing (the normal case: zero launches);
+        parameters that received their first gradient are adopted into a new group; gradients that arrived through
+        plain autograd (a module that is not slot-aware) are copied into their slot."""
         self._adopt_new()
         for g in self.groups:
+            src, dst = [], []
             for p in g.params:
-                if p.requires_grad and p._medt_gslot.stamp != self.stamp:
+                s = p._medt_gslot
+                if s.stamp == self.stamp:
+                    if p.grad is not None and p.grad is not s.view:          # both routes contributed
+                        s.view.add_(p.grad)
+                elif p.grad is not None:
+                    dst.append(s.view)
+                    src.append(p.grad)
+                    s.stamp = self.stamp
+                elif p.requires_grad:
                     raise L.MedtError("FlatAdam: a parameter that used to receive gradients did not this step")
+                else:
+                    s.view.zero_()
+                p.grad = s.view
+            if src:
+                torch._foreach_copy_(dst, src)
 
     def signature(self):
         """What a captured step depends on: group membership and which parameters are trainable."""

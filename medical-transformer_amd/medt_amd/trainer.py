@@ -23,17 +23,21 @@ def _world():
 
 def _distributed():
     """True when the step must leave the all-reduce (and Adam) outside the captured graph."""
-    from .optim import FORCE_COLLECTIVES
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+    from .optim import collectives_needed
+    return collectives_needed()
 
 
 class TrainStep:
     def __init__(self, model, optimizer: FlatAdam, criterion=None, use_graph: bool = True, warmup: int = 3):
+        if warmup < 1:
+            raise ValueError("TrainStep: at least one warm-up step is needed before capture (FlatAdam adopts the "
+                             "parameters and re-points their storage on the first step)")
         self.model, self.opt = model, optimizer
         self.criterion = criterion if criterion is not None else cross_entropy
         self.use_graph = use_graph
         self.warmup = warmup
         self._graphs = {}          # signature -> (graph, static_x, static_y, static_loss, single)
+        self._ce_out = None        # [loss, counted pixels, out-of-range targets] of the last step (medt cross_entropy)
 
     # ---- eager ------------------------------------------------------------
     def _eager(self, x, y):
@@ -46,19 +50,42 @@ class TrainStep:
         self.opt.apply(_world())
         return loss
 
+    def check_targets(self):
+        """Raise if the last replayed step saw class indices outside [0, K) (what F.cross_entropy raises on).  One
+        host sync: call it where the loss is read anyway (train.py does, next to loss.item())."""
+        if self._ce_out is not None:
+            from .ops import raise_on_bad_targets
+            raise_on_bad_targets(self._ce_out, -1)
+
     # ---- graph ------------------------------------------------------------
     def _signature(self, x, y):
-        return (tuple(x.shape), tuple(y.shape), self.model.training,
-                tuple(p.requires_grad for p in self.opt.params))
+        return (tuple(x.shape), tuple(y.shape), self.model.training, self.opt.signature())
+
+    def _snapshot(self):
+        tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return [t.detach().clone() for t in tensors], self.opt.snapshot()
+
+    def _restore(self, snap):
+        values, opt_snap = snap
+        tensors = list(self.model.parameters()) + list(self.model.buffers())
+        with torch.no_grad():
+            for t, v in zip(tensors, values):
+                t.copy_(v)
+        self.opt.restore(opt_snap)
 
     def _capture(self, x, y):
-        """Note: the warm-up steps are real optimisation steps on (x, y) (the same batch is then replayed)."""
+        """Warm up (allocator pools, FlatAdam adoption, lazy inits), then capture.  The warm-up steps run on the real
+        batch but their effect -- weights, Adam moments and step counters, BatchNorm running statistics,
+        num_batches_tracked -- is rolled back before capture, so capture + replay performs exactly the one update the
+        reference's loop (train.py:159-161) performs for this batch."""
         static_x, static_y = x.clone(), y.clone()
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                  # warm-up: allocator pools, FlatAdam groups, lazy inits
+        with torch.cuda.stream(side):
             for _ in range(self.warmup):
                 self._eager(static_x, static_y)
+            self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         self.opt.zero_grad()
         graph = torch.cuda.CUDAGraph()
@@ -70,7 +97,7 @@ class TrainStep:
             self.opt.pack_gradients()
             if single:
                 self.opt.apply(1)
-        return graph, static_x, static_y, loss.detach(), single
+        return graph, static_x, static_y, loss.detach(), single, getattr(loss, "_medt_ce_out", None)
 
     def __call__(self, x, y):
         if not self.use_graph:
@@ -78,10 +105,11 @@ class TrainStep:
         sig = self._signature(x, y)
         entry = self._graphs.get(sig)
         if entry is None:                              # first call with this shape, or the gates were switched on
-            if any(k[3] != sig[3] for k in self._graphs):          # requires_grad changed (train.py:169-171):
+            if any(k[3] != sig[3] for k in self._graphs):          # trainable set changed (train.py:169-171):
                 self._graphs.clear()                                # graphs captured before are stale
-            entry = self._graphs[sig] = self._capture(x, y)
-        graph, static_x, static_y, static_loss, single = entry
+            entry = self._capture(x, y)
+            self._graphs[self._signature(x, y)] = entry             # (the warm-up may have adopted a new group)
+        graph, static_x, static_y, static_loss, single, self._ce_out = entry
         static_x.copy_(x)
         static_y.copy_(y)
         graph.replay()

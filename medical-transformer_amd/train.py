@@ -65,11 +65,6 @@ def main():
     else:
         from utils import JointTransform2D, ImageToImage2D, Image2D
         imgchant = 3
-    if args.synthetic and rank == 0:
-        make_synthetic_dataset(args.train_dataset, args.synthetic, imgsize or 128, 3000, args.gray == "yes")
-        if args.val_dataset and args.val_dataset != args.train_dataset:
-            make_synthetic_dataset(args.val_dataset, max(2, args.synthetic // 4), imgsize or 128, 3001, args.gray == "yes")
-
     device = torch.device(args.device)
     if device.type == "cuda":
         if device.index is None:
@@ -78,6 +73,15 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
+    if args.synthetic:
+        # rank 0 writes the PNGs; nobody lists the directories before they are complete
+        if rank == 0:
+            make_synthetic_dataset(args.train_dataset, args.synthetic, imgsize or 128, 3000, args.gray == "yes")
+            if args.val_dataset and args.val_dataset != args.train_dataset:
+                make_synthetic_dataset(args.val_dataset, max(2, args.synthetic // 4), imgsize or 128, 3001,
+                                       args.gray == "yes")
+        if world > 1:
+            dist.barrier()
 
     crop = (args.crop, args.crop) if args.crop is not None else None
     tf_train = JointTransform2D(crop=crop, p_flip=0.5, color_jitter_params=None, long_mask=True)
@@ -119,6 +123,7 @@ def main():
             y_batch = y_batch.to(device)
             loss = train_step(X_batch, y_batch)
             epoch_running_loss += loss.item()
+            train_step.check_targets()            # mislabelled masks raise, as F.cross_entropy does in the reference
         if rank == 0:
             print('epoch [{}/{}], loss:{:.4f}'.format(epoch, args.epochs, epoch_running_loss / (batch_idx + 1)))
 

@@ -10,6 +10,7 @@ import torch
 from oracle import medt_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _manifest = None
 
 

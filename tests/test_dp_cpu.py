@@ -1,13 +1,26 @@
-"""Data-parallel host logic on CPU: world_size 2 over gloo (the GPU path uses the same code over RCCL)."""
+"""Data-parallel PRODUCT path on CPU: world_size 2 over gloo.
+
+What runs here is the code train.py / bench.py run per step -- medt_amd.trainer.TrainStep (eager branch) driving
+medt_amd.optim.FlatAdam: slot adoption, identical exclusion of gradient-less parameters on every rank, ONE
+all_reduce(SUM) of each flat bucket, the 1/world factor folded into the Adam update, late-joining gates as a second
+group (train.py:169-171).  Only the Adam *kernel* is substituted (medt_adam_step is a HIP kernel; the CPU stand-in
+below restates its arithmetic and lives in this test, not in the product).  The expectation is a single-process run
+of torch.optim.Adam on the shard-averaged gradients with per-shard BatchNorm statistics -- what the reference's
+nn.DataParallel (train.py:104-107) computes.
+"""
+import copy
 import os
 import socket
 
-import pytest
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import torch.nn.functional as F
 
 import helpers as H  # noqa: F401
+
+STEPS, FLIP_AT, LR, WD = 5, 2, 1e-2, 1e-5
 
 
 def _free_port():
@@ -16,43 +29,125 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class ToyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 4, 3, padding=1, bias=False)    # (a bias before BatchNorm has a ~0 gradient: Adam would amplify its rounding)
+        self.bn = torch.nn.BatchNorm2d(4)
+        self.c2 = torch.nn.Conv2d(4, 2, 1)
+        self.unused = torch.nn.Conv2d(4, 4, 1)                                  # never called: MedT's conv1 / adjust_p (Q5)
+        self.gate = torch.nn.Parameter(torch.tensor(0.5), requires_grad=False)  # frozen until FLIP_AT, like f_qr...
+
+    def forward(self, x):
+        return self.c2(torch.relu(self.bn(self.c1(x)))) * self.gate
+
+
+def _batch(step, rank=None, world=2):
+    g = torch.Generator().manual_seed(7000 + step)
+    x = torch.rand(4, 3, 8, 8, generator=g)
+    y = torch.randint(0, 2, (4, 8, 8), generator=g)
+    if rank is None:
+        return x, y
+    n = 4 // world
+    return x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
+
+
+def _make_cpu_adam():
+    from medt_amd.optim import FlatAdam
+
+    class CpuFlatAdam(FlatAdam):
+        """FlatAdam with medt_adam_step's arithmetic (csrc/elementwise.hip adam_step) restated in torch for CPU tensors."""
+
+        def _launch_adam(self, g, gscale):
+            b1, b2 = self.betas
+            g.state[0] += 1
+            t = float(g.state[0])
+            grad = g.flat_g * gscale + self.weight_decay * g.flat_p
+            g.exp_avg.mul_(b1).add_(grad, alpha=1 - b1)
+            g.exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            denom = (g.exp_avg_sq.sqrt() / (1 - b2 ** t) ** 0.5).add_(self.eps)
+            g.flat_p.addcdiv_(g.exp_avg, denom, value=-self.lr / (1 - b1 ** t))
+
+    return CpuFlatAdam
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from medt_amd import dp
-    torch.manual_seed(100 + rank)                       # deliberately different replicas
-    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
-    frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)      # like the gates before epoch 10
-    model.register_parameter("gate", frozen)
+    from medt_amd.trainer import TrainStep
+    torch.manual_seed(100 + rank)                       # deliberately different replicas before the broadcast
+    model = ToyNet()
     dp.broadcast_parameters(model)
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    x = torch.full((2, 3, 8, 8), float(rank + 1))
-    model(x).sum().backward()
-    local = [p.grad.clone() for p in model.parameters() if p.grad is not None]
-    bucket = dp.allreduce_gradients(model)
-    bucket = dp.allreduce_gradients(model, bucket)      # second call reuses the bucket (averaging an average is a no-op)
-    avg = [p.grad.clone() for p in model.parameters() if p.grad is not None]
-    # plain numpy payloads: torch tensors would travel through shared-memory handles that die with the worker
-    q.put((rank, {k: v.numpy() for k, v in sd.items()}, [g.numpy() for g in local], [g.numpy() for g in avg], bucket.numel))
+    opt = _make_cpu_adam()(list(model.parameters()), lr=LR, weight_decay=WD)
+    step = TrainStep(model, opt, F.cross_entropy, use_graph=False)
+    losses = []
+    for s in range(STEPS):
+        if s == FLIP_AT:
+            for p in model.parameters():
+                p.requires_grad = True                  # train.py:169-171
+        x, y = _batch(s, rank, world)
+        losses.append(float(step(x, y).detach()))
+    sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    q.put((rank, sd, [g.numel for g in opt.groups], losses))
     dist.destroy_process_group()
 
 
-def test_broadcast_and_flat_bucket_allreduce():
+def _single_process_expectation():
+    torch.manual_seed(100)                              # rank 0's initial weights are what the broadcast installs
+    model = ToyNet()
+    opt = torch.optim.Adam(list(model.parameters()), lr=LR, weight_decay=WD)
+    for s in range(STEPS):
+        if s == FLIP_AT:
+            for p in model.parameters():
+                p.requires_grad = True
+        grads = []
+        for r in range(2):                              # every shard: same weights, its own BatchNorm batch statistics
+            rep = model if r == 0 else copy.deepcopy(model)     # replica 0's running stats are the ones kept
+            for p in rep.parameters():
+                p.grad = None
+            x, y = _batch(s, r)
+            F.cross_entropy(rep(x), y).backward()
+            grads.append([None if p.grad is None else p.grad.clone() for p in rep.parameters()])
+        for p, g0, g1 in zip(model.parameters(), *grads):
+            p.grad = None if g0 is None else (g0 + g1) / 2
+        opt.step()
+    return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def test_trainstep_flatadam_allreduce_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, sd0, l0, a0, n0), (_, sd1, l1, a1, n1) = res
-    import numpy as np
+    (_, sd0, groups0, _), (_, sd1, groups1, _) = res
+    want = _single_process_expectation()
+    n_main = 3 * 4 * 9 + 4 + 4 + 4 * 2 + 2                     # c1, bn, c2: everything that gets a gradient from step 0
+    assert groups0 == groups1 == [n_main, 1]                   # `unused` excluded identically; the gate joins as group 2
     for k in sd0:
-        assert np.array_equal(sd0[k], sd1[k]), k           # replicas identical after the broadcast
-    assert n0 == n1 == sum(g.size for g in l0)             # frozen parameter excluded identically on every rank
-    for g0, g1, m0, m1 in zip(l0, l1, a0, a1):
-        want = (g0 + g1) / 2
-        assert np.allclose(m0, want, atol=1e-6) and np.allclose(m1, want, atol=1e-6)
+        if "running" in k or "num_batches" in k:
+            continue                                           # BatchNorm statistics stay local to the shard
+        assert np.array_equal(sd0[k], sd1[k]), k               # replicas stay bit-identical
+        assert np.allclose(sd0[k], want[k], rtol=1e-5, atol=1e-6), (k, np.abs(sd0[k] - want[k]).max())
+    assert np.array_equal(sd0["unused.weight"], want["unused.weight"])          # never touched (no weight decay either)
+    for k in ("bn.running_mean", "bn.running_var"):
+        assert np.allclose(sd0[k], want[k], rtol=1e-5, atol=1e-6), k            # rank 0 == replica 0
+
+
+def test_flatadam_refuses_cpu_update_loudly():
+    """The product optimizer has no CPU path: the Adam update is a HIP kernel."""
+    import pytest
+    from medt_amd import MedtError
+    from medt_amd.optim import FlatAdam
+    p = torch.nn.Parameter(torch.ones(3))
+    opt = FlatAdam([p])
+    opt.zero_grad()
+    (p * 2).sum().backward()
+    with pytest.raises(MedtError):
+        opt.step()

@@ -238,3 +238,25 @@ def test_seg_counts_and_scores(device):
             assert abs(pa[n].item() - tp / ttp) < 1e-12
         else:
             assert f1[n].item() == iou[n].item() == pa[n].item() == 1.0
+
+
+def test_cross_entropy_rejects_out_of_range_targets(device):
+    """F.cross_entropy raises on class indices outside [0, K) that are not ignore_index (a mask left at 255): the
+    kernel counts them and the host raises; ignore_index itself stays legal."""
+    import medt_amd
+    logits = torch.randn(2, 2, 8, 8, device=device)
+    target = torch.randint(0, 2, (2, 8, 8), device=device)
+    target[0, 0, 0] = -100
+    medt_amd.cross_entropy(logits, target)                      # fine: ignored pixel
+    target[1, 3, 3] = 255
+    with pytest.raises(medt_amd.MedtError):
+        medt_amd.cross_entropy(logits, target)
+
+
+def test_batchnorm_momentum_none_is_refused(device):
+    import medt_amd
+    from medt_amd import ops
+    conv = nn.Conv2d(3, 4, 1, bias=False).to(device)
+    bn = nn.BatchNorm2d(4, momentum=None).to(device)
+    with pytest.raises(medt_amd.MedtError):
+        ops.conv_block(torch.randn(2, 3, 4, 4, device=device), conv, bn, training=True)
