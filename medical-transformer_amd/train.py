@@ -8,6 +8,7 @@ Differences, all host-side plumbing:
   * multi-GPU = one process per GPU under torchrun (torch.distributed, RCCL) with a single flat-bucket
     gradient all-reduce per step, instead of nn.DataParallel(device_ids=[0,1]) (train.py:104-107);
     --batch_size stays the GLOBAL batch and is split over the ranks, as DataParallel splits it;
+  * batches are decoded, pinned and copied to the GPU one step ahead (medt_amd.data.DevicePrefetcher);
   * the step runs as a replayed hipGraph with a fused flat Adam (medt_amd.trainer); --eager disables it;
   * --synthetic N writes N synthetic PNG pairs into --train_dataset first (BASELINE.json config 1 plumbing);
   * the per-step threshold-and-copy-to-host of the output (train.py:142-152) is dropped: its result is unused.
@@ -23,7 +24,7 @@ from torch.utils.data import DataLoader
 import lib
 from metrics import LogNLLLoss
 from medt_amd import dp
-from medt_amd.data import imwrite, make_synthetic_dataset
+from medt_amd.data import DevicePrefetcher, imwrite, make_synthetic_dataset
 from medt_amd.optim import FlatAdam
 from medt_amd.trainer import TrainStep
 
@@ -118,7 +119,8 @@ def main():
         if sampler is not None:
             sampler.set_epoch(epoch)
         epoch_running_loss, batch_idx = 0.0, -1
-        for batch_idx, (X_batch, y_batch, *rest) in enumerate(dataloader):
+        # host decode + pinned staging + H2D run one step ahead on a copy stream (reference: blocking .to(), :134-135)
+        for batch_idx, (X_batch, y_batch, *rest) in enumerate(DevicePrefetcher(dataloader, device)):
             X_batch = X_batch.to(device)
             y_batch = y_batch.to(device)
             loss = train_step(X_batch, y_batch)

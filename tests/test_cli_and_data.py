@@ -85,3 +85,40 @@ def test_train_then_test_cli_roundtrip(tmp_path, device):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(os.listdir(res)) == 16
+
+
+def test_prefetcher_cpu_passthrough(tmp_path):
+    """On a CPU device the prefetcher is plain iteration: same batches, same order (np.random-driven flips included)."""
+    from torch.utils.data import DataLoader
+    from medt_amd.data import DevicePrefetcher, make_synthetic_dataset
+    import utils
+    root = make_synthetic_dataset(str(tmp_path / "d"), n=6, size=16, seed=5)
+    tf = utils.JointTransform2D(crop=None, p_flip=0.5, color_jitter_params=None, long_mask=True)
+    ds = utils.ImageToImage2D(root, tf)
+    np.random.seed(3000)
+    want = [(x.clone(), y.clone(), n) for x, y, n in DataLoader(ds, batch_size=2, shuffle=False)]
+    np.random.seed(3000)
+    got = list(DevicePrefetcher(DataLoader(ds, batch_size=2, shuffle=False), "cpu"))
+    assert len(got) == len(want) == 3
+    for (x0, y0, n0), (x1, y1, n1) in zip(want, got):
+        assert torch.equal(x0, x1) and torch.equal(y0, y1) and list(n0) == list(n1)
+
+
+@pytest.mark.gpu
+def test_prefetcher_gpu_matches_blocking_copies(tmp_path, device):
+    """Pinned staging + copy stream deliver exactly what `.to(device)` would, in order, with reused staging buffers."""
+    from torch.utils.data import DataLoader
+    from medt_amd.data import DevicePrefetcher, make_synthetic_dataset
+    import utils
+    root = make_synthetic_dataset(str(tmp_path / "d"), n=14, size=32, seed=6)
+    tf = utils.JointTransform2D(crop=None, p_flip=0.5, color_jitter_params=None, long_mask=True)
+    ds = utils.ImageToImage2D(root, tf)
+    np.random.seed(3000)
+    want = [(x.clone(), y.clone()) for x, y, _ in DataLoader(ds, batch_size=2, shuffle=False)]
+    np.random.seed(3000)
+    n = 0
+    for (x0, y0), (x1, y1, _) in zip(want, DevicePrefetcher(DataLoader(ds, batch_size=2, shuffle=False), device, depth=2)):
+        assert x1.is_cuda and y1.is_cuda
+        assert torch.equal(x0, x1.cpu()) and torch.equal(y0, y1.cpu())
+        n += 1
+    assert n == 7
