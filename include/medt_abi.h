@@ -63,6 +63,9 @@ typedef struct medt_axial_desc {
     float   eps;            /* 1e-5 */
     float   momentum;       /* 0.1  */
     int32_t out_relu;       /* 1: fuse the block's ReLU after the width layer (:333) into the output pass */
+    int32_t gate_mode;      /* 0: f_* multiply as stored (axialnet.py:163-164,175-176);
+                               1: sigmoid(f_*) multiplies -- AxialAttention_gated_sig, lib/models/model_codes.py:279-280,
+                                  292-293; the gate gradients returned are then wrt the stored (pre-sigmoid) values */
 } medt_axial_desc;
 
 typedef struct medt_bn_ptrs {

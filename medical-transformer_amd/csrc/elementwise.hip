@@ -356,6 +356,29 @@ int ce_bwd(const float* logits, const int64_t* target, const float* loss_out, co
 }
 
 // --------------------------------------------------------------------------- //
+// AxialAttention_gated_sig (reference lib/models/model_codes.py:279-280, 292-293): the four gates enter through a sigmoid
+// --------------------------------------------------------------------------- //
+__global__ void gate_sigmoid_fwd_kernel(const float* f_qr, const float* f_kr, const float* f_sve, const float* f_sv,
+                                        float* __restrict__ eff) {
+    const float* src[4] = {f_qr, f_kr, f_sve, f_sv};
+    const int k = threadIdx.x;
+    if (k < 4) eff[k] = 1.f / (1.f + expf(-*src[k]));
+}
+__global__ void gate_sigmoid_bwd_kernel(const float* __restrict__ d_eff, const float* __restrict__ eff,
+                                        float* __restrict__ dgate) {
+    const int k = threadIdx.x;
+    if (k < 4) dgate[k] = d_eff[k] * eff[k] * (1.f - eff[k]);
+}
+int gate_sigmoid_fwd(const float* f_qr, const float* f_kr, const float* f_sve, const float* f_sv, float* eff, hipStream_t s) {
+    hipLaunchKernelGGL(gate_sigmoid_fwd_kernel, dim3(1), dim3(64), 0, s, f_qr, f_kr, f_sve, f_sv, eff);
+    return launch_status("gate_sigmoid_fwd");
+}
+int gate_sigmoid_bwd(const float* d_eff, const float* eff, float* dgate, hipStream_t s) {
+    hipLaunchKernelGGL(gate_sigmoid_bwd_kernel, dim3(1), dim3(64), 0, s, d_eff, eff, dgate);
+    return launch_status("gate_sigmoid_bwd");
+}
+
+// --------------------------------------------------------------------------- //
 // Adam (torch.optim.Adam semantics, coupled L2 weight decay).  The step counter lives on the device so a
 // captured hipGraph replays correctly: adam_tick advances it and derives the bias corrections.
 //   state[0] = step, state[1] = 1 - b1^step, state[2] = 1 - b2^step

@@ -35,10 +35,11 @@ struct LayerStats {
 };
 
 struct FwdWs {
-    float *part_qkv, *part_sim, *part_out, *qkv_ksplit, *tables;
+    float *part_qkv, *part_sim, *part_out, *qkv_ksplit, *tables, *gate_eff;
     unsigned* flag;
     FwdWs(Carver& c, const AxialGeom& g) {
         flag = c.take<unsigned>(4);
+        gate_eff = c.take<float>(4);
         const size_t kq = conv2d_fwd_scratch_floats(g.N, g.groups, g.C, g.H, g.W, 2 * g.C, 1, 1, 0);
         qkv_ksplit = c.take<float>(kq);
         if (!kq) qkv_ksplit = nullptr;
@@ -51,9 +52,11 @@ struct FwdWs {
 
 struct BwdWs {
     float *part_ob, *coef_out, *part_sb, *coef_sim, *dqkv, *part_qb, *coef_qkv, *rel_part, *gate_part, *dw_scratch,
-        *dy_masked;
+        *dy_masked, *gate_eff, *gate_tmp;
     size_t nblocks;
     BwdWs(Carver& c, const AxialGeom& g, int stride, int out_relu) {
+        gate_eff = c.take<float>(4);
+        gate_tmp = c.take<float>(4);
         const int ppg = conv2d_parts_per_group(g.N, g.groups, g.HW), TL = 2 * g.L - 1;
         nblocks = (size_t)g.groups * g.tpg * g.G;
         part_ob = c.take<float>((size_t)g.groups * ppg * g.OC * 2);
@@ -69,6 +72,18 @@ struct BwdWs {
         dy_masked = c.take<float>(out_relu ? (size_t)g.N * g.C * (g.H / stride) * (g.W / stride) : 0);
     }
 };
+
+// The gates the kernels multiply with: the stored scalars, or (gate_mode 1) their sigmoids computed into `eff`.
+static int effective_gates(const medt_axial_desc* d, const medt_axial_params* p, float* eff, hipStream_t s, GatePtrs* out) {
+    *out = GatePtrs{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
+    if (d->gate_mode == 0 || !p->f_qr) return MEDT_OK;
+    if (d->gate_mode != 1) { set_error("axial: gate_mode %d unsupported (0: raw, 1: sigmoid)", d->gate_mode); return MEDT_EUNSUPPORTED; }
+    if (!p->f_kr || !p->f_sve || !p->f_sv) { set_error("axial: gate_mode 1 needs all four gates"); return MEDT_EINVAL; }
+    int rc = gate_sigmoid_fwd(p->f_qr, p->f_kr, p->f_sve, p->f_sv, eff, s);
+    if (rc) return rc;
+    *out = GatePtrs{eff, eff + 1, eff + 2, eff + 3};
+    return MEDT_OK;
+}
 
 static int check_common(const medt_axial_desc* d, const medt_axial_params* p, const medt_axial_saved* sv, AxialGeom* g) {
     if (!d || !p || !sv) { set_error("null descriptor / params / saved"); return MEDT_EINVAL; }
@@ -118,7 +133,8 @@ int medt_axial_core_stats(const medt_axial_desc* d, const medt_axial_params* p, 
     FwdWs w(c, g);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     LayerStats st(sv->stats, g);
-    GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
+    GatePtrs gates;
+    if ((rc = effective_gates(d, p, w.gate_eff, (hipStream_t)stream, &gates))) return rc;
     return axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, (hipStream_t)stream);
 }
 
@@ -131,7 +147,8 @@ int medt_axial_core_fwd(const medt_axial_desc* d, const medt_axial_params* p, co
     FwdWs w(c, g);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     LayerStats st(sv->stats, g);
-    GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
+    GatePtrs gates;
+    if ((rc = effective_gates(d, p, w.gate_eff, (hipStream_t)stream, &gates))) return rc;
     return axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
                           d->training ? w.part_out : nullptr, w.flag, (hipStream_t)stream);
 }
@@ -151,7 +168,8 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
-    GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
+    GatePtrs gates;
+    if ((rc = effective_gates(d, p, w.gate_eff, s, &gates))) return rc;
     const int tr = d->training ? 1 : 0, ppg = conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1);
     if (wopos_small_ok(g, *d)) {
         // tiny position-free layers (MedT's local branch): the whole layer in one workgroup per (BN group, head),
@@ -197,7 +215,8 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
-    GatePtrs gates{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
+    GatePtrs gates;
+    if ((rc = effective_gates(d, p, w.gate_eff, s, &gates))) return rc;
     const int tr = d->training ? 1 : 0, ppg = conv2d_parts_per_group(g.N, g.groups, g.HW), TL = 2 * g.L - 1;
     if (wopos_small_bwd_ok(g, *d)) {
         // tiny position-free layers: dy -> gradient at the qkv_transform output in one workgroup per (BN group, head);
@@ -239,7 +258,11 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
                                 1, 0, g.groups, s))) return rc;
     if (g.pos) {
         if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
-        if (gr->gates && (rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, gr->gates, s))) return rc;
+        if (gr->gates) {
+            const bool sig = d->gate_mode == 1 && p->f_qr;
+            if ((rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, sig ? w.gate_tmp : gr->gates, s))) return rc;
+            if (sig && (rc = gate_sigmoid_bwd(w.gate_tmp, w.gate_eff, gr->gates, s))) return rc;
+        }
     }
     return MEDT_OK;
 }

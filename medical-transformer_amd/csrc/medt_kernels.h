@@ -88,6 +88,9 @@ int ce_fwd(const float* logits, const int64_t* target, float* partials, float* l
            hipStream_t s);
 int ce_bwd(const float* logits, const int64_t* target, const float* loss_out, const float* dloss, float* dlogits, int N,
            int K, int HW, int ignore, hipStream_t s);
+// gated_sig: eff[k] = sigmoid(*f[k]) (k: f_qr, f_kr, f_sve, f_sv);  dgate[k] = d_eff[k] * eff[k] * (1 - eff[k])
+int gate_sigmoid_fwd(const float* f_qr, const float* f_kr, const float* f_sve, const float* f_sv, float* eff, hipStream_t s);
+int gate_sigmoid_bwd(const float* d_eff, const float* eff, float* dgate, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float b1, float b2,
               float eps, float wd, float gscale, hipStream_t s);
 

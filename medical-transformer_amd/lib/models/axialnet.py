@@ -39,6 +39,8 @@ class _AxialAttentionBase(nn.Module):
     """Parameter holder + dispatch for the three attention flavours."""
     _has_pos = True       # relative-position tables, BN2d(3G), BN1d(2C)
     _gated = False        # f_qr / f_kr / f_sve / f_sv
+    _gate_init = (0.1, 0.1, 0.1, 1.0)      # f_qr, f_kr, f_sve, f_sv (:124-127)
+    _gate_mode = 0        # 1: sigmoid(f) multiplies (model_codes.AxialAttention_gated_sig)
 
     def __init__(self, in_planes, out_planes, groups=8, kernel_size=56, stride=1, bias=False, width=False):
         assert (in_planes % groups == 0) and (out_planes % groups == 0)
@@ -54,7 +56,7 @@ class _AxialAttentionBase(nn.Module):
         self.bn_similarity = nn.BatchNorm2d(groups * 3 if pos else groups)
         self.bn_output = nn.BatchNorm1d(out_planes * 2 if pos else out_planes)
         if self._gated:
-            for name, val in (("f_qr", 0.1), ("f_kr", 0.1), ("f_sve", 0.1), ("f_sv", 1.0)):
+            for name, val in zip(("f_qr", "f_kr", "f_sve", "f_sv"), self._gate_init):
                 setattr(self, name, nn.Parameter(torch.tensor(val), requires_grad=False))
         if pos:
             self.relative = nn.Parameter(torch.randn(self.group_planes * 2, kernel_size * 2 - 1), requires_grad=True)
@@ -82,7 +84,7 @@ class _AxialAttentionBase(nn.Module):
         return medt_amd.axial_attention(
             x, self.qkv_transform.weight, self.bn_qkv, self.bn_similarity, self.bn_output,
             self.relative if self._has_pos else None, gates, self.groups, self.width, self.stride,
-            self.training, bn_groups, out_relu)
+            self.training, bn_groups, out_relu, self._gate_mode)
 
 
 class AxialAttention(_AxialAttentionBase):

@@ -19,11 +19,12 @@ from . import optim as OPT
 class AxialConfig:
     """Static geometry + BatchNorm buffers of one attention layer."""
     __slots__ = ("groups", "axis", "has_pos", "stride", "bn_groups", "eps", "momentum",
-                 "bn_qkv", "bn_similarity", "bn_output", "out_relu")
+                 "bn_qkv", "bn_similarity", "bn_output", "out_relu", "gate_mode")
 
     def __init__(self, groups, axis, has_pos, stride, bn_qkv, bn_similarity, bn_output, bn_groups=1,
-                 eps=1e-5, momentum=0.1, out_relu=False):
+                 eps=1e-5, momentum=0.1, out_relu=False, gate_mode=0):
         self.groups, self.axis, self.has_pos, self.stride = groups, axis, has_pos, stride
+        self.gate_mode = gate_mode
         self.bn_groups, self.eps, self.momentum, self.out_relu = bn_groups, eps, momentum, out_relu
         self.bn_qkv, self.bn_similarity, self.bn_output = bn_qkv, bn_similarity, bn_output
 
@@ -53,7 +54,7 @@ def _bn_ptrs(bn, training: bool) -> L.BnPtrs:
 def _desc(x, cfg: AxialConfig, training: bool) -> L.AxialDesc:
     N, Cc, H, W = x.shape
     return L.AxialDesc(N, Cc, H, W, cfg.groups, cfg.axis, int(cfg.has_pos), cfg.stride, int(training),
-                       cfg.bn_groups, cfg.eps, cfg.momentum, int(cfg.out_relu))
+                       cfg.bn_groups, cfg.eps, cfg.momentum, int(cfg.out_relu), int(cfg.gate_mode))
 
 
 def _params(cfg, w_qkv, relative, gates, training) -> L.AxialParams:
@@ -171,13 +172,14 @@ class AxialAttentionFn(torch.autograd.Function):
 
 def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: Optional[torch.Tensor],
                     gates, groups: int, width: bool, stride: int, training: bool, bn_groups: int = 1,
-                    out_relu: bool = False):
+                    out_relu: bool = False, gate_mode: int = 0):
     """Functional entry: modules from lib.models.axialnet pass their own parameters/buffers.
 
     gates = (f_qr, f_kr, f_sve, f_sv) 0-d tensors or None (ungated: all ones).
+    gate_mode 1: sigmoid(f) multiplies (AxialAttention_gated_sig, reference lib/models/model_codes.py:215-313).
     """
     cfg = AxialConfig(groups, 1 if width else 0, relative is not None, stride, bn_qkv, bn_similarity, bn_output,
-                      bn_groups, bn_qkv.eps, _momentum(bn_qkv), out_relu)
+                      bn_groups, bn_qkv.eps, _momentum(bn_qkv), out_relu, gate_mode)
     g = gates if gates is not None else (None, None, None, None)
     return AxialAttentionFn.apply(x, qkv_weight, bn_qkv.weight, bn_qkv.bias, bn_similarity.weight,
                                   bn_similarity.bias, bn_output.weight, bn_output.bias, relative,

@@ -110,14 +110,21 @@ def attention_kind(st: State, prefix: str) -> str:
 
 
 def axial_attention(x: torch.Tensor, st: State, prefix: str, width: bool, stride: int,
-                    training: bool, bn_groups: int = 1, taps: Optional[dict] = None) -> torch.Tensor:
+                    training: bool, bn_groups: int = 1, taps: Optional[dict] = None,
+                    gate_mode: str = "raw") -> torch.Tensor:
     """One axial-attention layer on an NCHW tensor.
 
     width=False attends along H (one sequence per (n, w)); width=True along W.
     ``taps`` (optional dict) receives the intermediate tensors the kernels
     exchange (qkv after bn_qkv, the logits, the stacked sv|sve) for unit tests.
+    ``gate_mode`` selects the experimental gate flavours of the reference's model_codes.py:
+    "raw" = axialnet.py (gates multiply as stored), "sigmoid" = AxialAttention_gated_sig (model_codes.py:215-313:
+    sigmoid(f) multiplies, :279-280,292-293), "data" = AxialAttention_gated_data (:316-443: four gates per SEQUENCE
+    from sigmoid(relu(fcn2(relu(fcn1(mean_L x))))), :371-380,406-407,420-421).
     """
     kind = attention_kind(st, prefix)
+    if gate_mode == "data":
+        kind = "dynamic"
     N, C, H, W = x.shape
     G = GROUPS
     gp = C // G
@@ -128,6 +135,16 @@ def axial_attention(x: torch.Tensor, st: State, prefix: str, width: bool, stride
     L = X.shape[3]
     X = X.reshape(N * Bo, C, L)
     B = N * Bo
+    if gate_mode == "sigmoid":
+        f_qr, f_kr, f_sv, f_sve = (torch.sigmoid(st[prefix + n]) for n in (".f_qr", ".f_kr", ".f_sv", ".f_sve"))
+    elif gate_mode == "data":
+        xn = X.mean(dim=2)                                                     # AdaptiveAvgPool2d((1,1)) over L (:371)
+        xn = torch.relu(F.linear(xn, st[prefix + ".fcn1.weight"], st[prefix + ".fcn1.bias"]))
+        xn = torch.relu(F.linear(xn, st[prefix + ".fcn2.weight"], st[prefix + ".fcn2.bias"]))
+        sig = torch.sigmoid(xn).reshape(B, 4, 1, 1, 1)
+        f_qr, f_kr, f_sv, f_sve = sig[:, 0], sig[:, 1], sig[:, 2], sig[:, 3]   # sig3 -> sv, sig4 -> sve (:420-421)
+    elif kind == "dynamic":
+        f_qr, f_kr, f_sv, f_sve = (st[prefix + n] for n in (".f_qr", ".f_kr", ".f_sv", ".f_sve"))
     # BN groups follow the image index n, which is the slow part of b = n*Bo + s
     Wqkv = st[prefix + ".qkv_transform.weight"].reshape(2 * C, C)          # Conv1d k=1, no bias (:114)
     qkv = torch.einsum("oc,bcl->bol", Wqkv, X)
@@ -147,8 +164,8 @@ def axial_attention(x: torch.Tensor, st: State, prefix: str, width: bool, stride
         qr = torch.einsum("bgci,cij->bgij", q, Rq[:, d])                        # q[c,i]*Rq[c,i-j+L-1]
         kr = torch.einsum("bgcj,cij->bgij", k, Rk[:, d.t()])                    # k[c,j]*Rk[c,j-i+L-1]  (:158)
         if kind == "dynamic":
-            qr = qr * st[prefix + ".f_qr"]                                      # :163-164
-            kr = kr * st[prefix + ".f_kr"]
+            qr = qr * f_qr                                                      # :163-164
+            kr = kr * f_kr
         S = torch.cat([qk, qr, kr], dim=1)                                      # channel order qk|qr|kr (:166)
         S = batch_norm(S, st, prefix + ".bn_similarity", training, bn_groups)   # BN2d(3G)
         Z = S[:, :G] + S[:, G:2 * G] + S[:, 2 * G:]                             # .view(B,3,G,L,L).sum(1)
@@ -160,8 +177,8 @@ def axial_attention(x: torch.Tensor, st: State, prefix: str, width: bool, stride
     else:
         sve = torch.einsum("bgij,cij->bgci", P, Rv[:, d])                       # :172
         if kind == "dynamic":
-            sv = sv * st[prefix + ".f_sv"]                                      # :175-176
-            sve = sve * st[prefix + ".f_sve"]
+            sv = sv * f_sv                                                      # :175-176
+            sve = sve * f_sve
         # cat(dim=-1).view(B, 2C, L): channel 2*(g*gp+c)+0 <- sv, +1 <- sve   (:178)
         stacked = torch.stack([sv, sve], dim=3).reshape(B, 2 * C, L)
         out = batch_norm(stacked, st, prefix + ".bn_output", training, bn_groups)  # BN1d(2C)

@@ -53,6 +53,24 @@ def load():
     return sys.modules[name]
 
 
+def load_model_codes():
+    """The reference's lib/models/model_codes.py (experimental gate variants, unreachable from its CLI)."""
+    load()
+    full = f"{_PKG}.models.model_codes"
+    if full in sys.modules:
+        return sys.modules[full]
+    old = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True
+    try:
+        spec = importlib.util.spec_from_file_location(full, os.path.join(REFERENCE_ROOT, "lib", "models", "model_codes.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+    finally:
+        sys.dont_write_bytecode = old
+    return mod
+
+
 def load_metrics():
     """The reference's metrics.py (LogNLLLoss)."""
     name = _PKG + "_metrics"

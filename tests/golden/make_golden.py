@@ -123,7 +123,10 @@ def model_fixture(model_name, S, N, seed, mode):
 def layer_fixture(kind, C, L, width, stride, N, seed):
     """One attention layer of the reference, everything stored in full (float64)."""
     ax = ref_loader.load()
-    cls = {"dynamic": ax.AxialAttention_dynamic, "plain": ax.AxialAttention, "wopos": ax.AxialAttention_wopos}[kind]
+    if kind == "gatedsig":                           # experimental zoo, lib/models/model_codes.py:215-313
+        cls = ref_loader.load_model_codes().AxialAttention_gated_sig
+    else:
+        cls = {"dynamic": ax.AxialAttention_dynamic, "plain": ax.AxialAttention, "wopos": ax.AxialAttention_wopos}[kind]
     torch.manual_seed(seed)
     layer = cls(C, C, groups=8, kernel_size=L, stride=stride, width=width)
     sd = O.randomize_state(layer.state_dict(), seed)
@@ -174,9 +177,16 @@ def manifest():
 
 
 def main():
+    """`python make_golden.py` regenerates everything; `python make_golden.py layer_gatedsig` only the fixtures whose
+    file name starts with the given prefix (the others are deterministic re-runs of the same reference code)."""
+    import sys
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     torch.set_num_threads(os.cpu_count())
-    manifest()
+    if not only:
+        manifest()
     layer_cases = [
+        ("gatedsig", 32, 16, True, 2, 2, 17),
+        ("gatedsig", 16, 32, False, 1, 2, 18),
         ("dynamic", 16, 16, False, 1, 2, 11),
         ("dynamic", 32, 8, True, 2, 2, 12),
         ("plain", 16, 8, True, 1, 2, 13),
@@ -186,8 +196,10 @@ def main():
     ]
     for case in layer_cases:
         kind, C, L, width, stride, N, seed = case
-        fx = layer_fixture(*case)
         fn = f"layer_{kind}_C{C}_L{L}_{'w' if width else 'h'}_s{stride}.npz"
+        if not fn.startswith(only):
+            continue
+        fx = layer_fixture(*case)
         np.savez_compressed(os.path.join(HERE, fn), **fx)
         print("wrote", fn)
     model_cases = [
@@ -200,8 +212,10 @@ def main():
         ("MedT", 256, 1, 105, "eval"),
     ]
     for name, S, N, seed, mode in model_cases:
-        fx = model_fixture(name, S, N, seed, mode)
         fn = f"model_{name}_S{S}_N{N}_{mode}.npz"
+        if not fn.startswith(only):
+            continue
+        fx = model_fixture(name, S, N, seed, mode)
         np.savez_compressed(os.path.join(HERE, fn), **fx)
         print("wrote", fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KB")
 

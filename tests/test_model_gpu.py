@@ -147,7 +147,13 @@ def test_graphed_train_step_equals_eager(device):
         if k.endswith("num_batches_tracked"):
             assert int(s0[k].item()) == int(s1[k].item()), k          # 4 (x16 on the patch branch), not 4 + warm-up
         elif s0[k].is_floating_point():
-            assert H.rel_err(s1[k], s0[k]) < 1e-3, k
+            # Not bit-equal: the relative-table gradients use LDS float atomics (summation order varies run to run), and
+            # Adam turns a noise-level gradient (e.g. bn_similarity.bias, whose true gradient is 0) into a +-lr step.
+            # So: no element may differ by more than the 4 steps could move it, and all but a few must agree closely.
+            d = (s1[k].double() - s0[k].double()).abs()
+            assert d.max().item() <= 2 * 4 * 1e-3, k
+            if "bn_similarity.bias" not in k and d.numel() >= 64:
+                assert (d > 2e-4 * max(1.0, s0[k].abs().max().item())).double().mean().item() < 0.05, k
     assert len(o0) == len(o1) == 1 and float(o0[0][0]) == float(o1[0][0]) == 4.0     # Adam's step counter
 
 

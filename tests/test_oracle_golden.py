@@ -40,12 +40,13 @@ def test_layer_oracle_matches_reference_fixture(fn):
     x = torch.from_numpy(fx["x"]).double()
     # eval
     st_e = O.clone_state(st, torch.float64)
-    out = O.axial_attention(x, st_e, "m", bool(width), stride, training=False)
+    gm = "sigmoid" if fn.split("_")[1] == "gatedsig" else "raw"
+    out = O.axial_attention(x, st_e, "m", bool(width), stride, training=False, gate_mode=gm)
     assert H.rel_err(out, fx["out_eval"]) < 1e-10
     # train: forward, backward, running stats
     st_t = O.clone_state(st, torch.float64, requires_grad=True)
     xg = x.clone().requires_grad_(True)
-    out = O.axial_attention(xg, st_t, "m", bool(width), stride, training=True)
+    out = O.axial_attention(xg, st_t, "m", bool(width), stride, training=True, gate_mode=gm)
     assert H.rel_err(out, fx["out_train"]) < 1e-10
     (out * torch.from_numpy(fx["dout"])).sum().backward()
     assert H.rel_err(xg.grad, fx["dx"]) < 1e-9
