@@ -63,8 +63,10 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     desc = _desc(x, cfg, True)
     gates = (layer.f_qr, layer.f_kr, layer.f_sve, layer.f_sv)
     params = _params(cfg, layer.qkv_transform.weight, layer.relative, gates, True)
-    qkv_raw = torch.empty((N, 2 * C, H, W), device=device)
-    stacked = torch.empty((N, 2 * C, H, W), device=device)
+    sdt = torch.bfloat16 if cfg.act_dtype == 1 else torch.float32      # medt_amd.set_activation_dtype (--dtype bf16)
+    e = 2 if cfg.act_dtype == 1 else 4
+    qkv_raw = torch.empty((N, 2 * C, H, W), device=device, dtype=sdt)
+    stacked = torch.empty((N, 2 * C, H, W), device=device, dtype=sdt)
     lse = torch.empty((N, 8, H, W), device=device)
     stats = torch.empty((lib.medt_axial_stats_floats(ctypes.byref(desc)),), device=device)
     ws_bytes = lib.medt_axial_workspace_bytes(ctypes.byref(desc))
@@ -92,21 +94,22 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     t_stats = timed(lambda: ML.check(lib.medt_axial_core_stats(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
                                                                ws.data_ptr(), ws_bytes, stream), "core_stats"))
     M = N * H * W
-    bytes_main = 4 * C * 4 * M
-    bytes_stats = C * 4 * M
+    bytes_main = 4 * C * e * M
+    bytes_stats = C * e * M
     flops_main = 7.0 * M * L * C
     # the launch = memset of the repair flag + the bound-referenced four-rows-per-lane kernel + the exact kernel's
     # early exit; MEDT_ROWS4=0 / MEDT_BOUND_PATH=0 select the other variants
     kname = ("attn_fwd4r_kernel<AXIS=%d,L=%d,EXACT=false>" if C // 8 == 2 else "attn_fwd3_kernel<GP=%d,AXIS=%%d,L=%%d,EXACT=false>" % (C // 8))
     roof = {"bound": "hbm", "kernel": kname % (1 if width else 0, L),
-            "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main},
+            "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main,
+                      "storage": "bf16" if e == 2 else "f32"},
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "launch_ms": t_main * 1e3, "valu_tflops": flops_main / t_main / 1e12,
             "stats_kernel": {"achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
                              "bytes_per_launch": bytes_stats}}
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tf) and (C, L) == (16, 64):
+    if os.path.exists(tf) and (C, L) == (16, 64) and e == 4:
         try:
             roof["traffic"] = json.load(open(tf)).get("attn_fwd_bytes_per_launch")
         except Exception:
@@ -163,6 +166,15 @@ def cpu_baseline_leg(steps=8):
                       f"(torch CPU, {cores} threads), fwd+CE+backward+Adam", "s_per_step": dt}
 
 
+def baseline_config(args):
+    """Which BASELINE.json configuration a (model, imgsize, per-GPU batch, dtype) line corresponds to."""
+    key = (args.model, args.imgsize, args.batch, args.dtype)
+    return {("MedT", 128, 4, "f32"): "configs[2] (per GPU: also configs[3]'s shard)",
+            ("gatedaxialunet", 128, 8, "bf16"): "configs[1]",
+            ("gatedaxialunet", 128, 4, "f32"): "configs[0]'s shape on the GPU",
+            ("MedT", 256, 2, "f32"): "configs[4]'s per-GPU shard"}.get(key, "(not a BASELINE.json configuration)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +184,9 @@ def main():
     ap.add_argument("--imgsize", type=int, default=IMG)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch")
     ap.add_argument("--eager", action="store_true", help="launch kernels from Python every step (no hipGraph replay)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage of the attention layers' saved activations (bf16 = BASELINE.json configs[1]); "
+                         "arithmetic and statistics are f32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the attention-kernel microbenchmark (for rocprofv3)")
@@ -191,11 +206,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
         log(f"rank {rank}/{world}: process group up, backend={dist.get_backend()}")
 
+    import medt_amd
+    medt_amd.set_activation_dtype(args.dtype)
     if args.roofline_only:
         print(json.dumps({"roofline": roofline_leg(device)}))
         return
 
-    import medt_amd
     from medt_amd import dp
     from medt_amd.optim import FlatAdam
     torch.manual_seed(3000)                              # train.py:118
@@ -238,10 +254,13 @@ def main():
         "metric": "training images/sec (MedT, 3x128x128)", "value": world * args.batch * args.steps / elapsed,
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} imgsize={args.imgsize} bs={args.batch}/GPU train step (fwd+CE+bwd+Adam), "
-                               f"BASELINE.json configs[2]" + ("" if world == 1 else f" x{world} data-parallel, flat-bucket all-reduce"),
+                               f"BASELINE.json {baseline_config(args)}" + ("" if world == 1 else f" x{world} data-parallel, flat-bucket all-reduce"),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+        "precision": ("f32 storage, f32 arithmetic" if args.dtype == "f32" else
+                      "bf16 storage of the position-encoded attention layers' qkv / sv|sve activations, f32 arithmetic, "
+                      "statistics, layer inputs/outputs and gradients"),
         "final_loss": final_loss, "hip_graph": not args.eager,
         "collective": (f"{dist.get_backend()} all_reduce(SUM) of the flat gradient bucket, outside the graph"
                        if distributed else None),

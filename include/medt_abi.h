@@ -66,6 +66,9 @@ typedef struct medt_axial_desc {
     int32_t gate_mode;      /* 0: f_* multiply as stored (axialnet.py:163-164,175-176);
                                1: sigmoid(f_*) multiplies -- AxialAttention_gated_sig, lib/models/model_codes.py:279-280,
                                   292-293; the gate gradients returned are then wrt the stored (pre-sigmoid) values */
+    int32_t act_dtype;      /* storage type of saved->qkv_raw and saved->stacked: 0 float32 (the reference's arithmetic and
+                               storage), 1 bfloat16 (BASELINE.json configs[1]: half the attention path's HBM bytes;
+                               accumulation, statistics, x / y / dx and every gradient stay float32).  has_pos only. */
 } medt_axial_desc;
 
 typedef struct medt_bn_ptrs {
@@ -90,9 +93,9 @@ typedef struct medt_axial_params {
 
 /* Activations kept between forward and backward (caller-allocated). */
 typedef struct medt_axial_saved {
-    float* qkv_raw;   /* (N, 2C, H, W)  qkv_transform output before bn_qkv                     */
-    float* stacked;   /* (N, OC, H, W)  sv|sve before bn_output, channel 2(g*gp+c)+{0:sv,1:sve};
-                         OC = 2C (has_pos) or C (wopos: sv only)                               */
+    void*  qkv_raw;   /* (N, 2C, H, W)  qkv_transform output before bn_qkv; float32 or bfloat16 (desc.act_dtype) */
+    void*  stacked;   /* (N, OC, H, W)  sv|sve before bn_output, channel 2(g*gp+c)+{0:sv,1:sve};
+                         OC = 2C (has_pos) or C (wopos: sv only); float32 or bfloat16 (desc.act_dtype)  */
     float* lse;       /* (N, G, H, W)   log2-domain log-sum-exp of every softmax row           */
     float* stats;     /* medt_axial_stats_floats() floats: per-BN mean / rstd / scale / shift  */
 } medt_axial_saved;

@@ -45,6 +45,12 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
     }
     g->N = d.N; g->C = d.C; g->H = d.H; g->W = d.W; g->G = d.G; g->gp = gp; g->hq = gp / 2;
     g->axis = d.axis; g->pos = d.has_pos ? 1 : 0;
+    if (d.act_dtype != 0 && d.act_dtype != 1) { set_error("axial: act_dtype %d unsupported (0 f32, 1 bf16)", d.act_dtype); return MEDT_EUNSUPPORTED; }
+    if (d.act_dtype == 1 && !d.has_pos) {
+        set_error("axial: bfloat16 storage is implemented for the position-encoded layers only");
+        return MEDT_EUNSUPPORTED;
+    }
+    g->bf16 = d.act_dtype;
     g->L = d.axis ? d.W : d.H;
     g->Bo = d.axis ? d.H : d.W;
     if (g->L > MEDT_THREADS) {
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, con
     float* tv = tk + HQ * TL;
     const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
-    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t);
+    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, g.bf16);
     const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
     const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
     const float a_qr = POS ? ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E : 0.f;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, con
         reg[ls * RS + NCH * L + i] = lse;
     }
     __syncthreads();
-    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t);
+    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t, g.bf16);
     if (lse_out) tile_store<AXIS>(reg, RS, NCH, lse_out, g.G, hg, 1, t);
     if (out_partials) {
         float v[2 * OCG];
@@ -296,8 +302,8 @@ __device__ __forceinline__ void bwd_stage(const AxialGeom& g, BwdLds<GP, POS>& S
                                           const float* __restrict__ out_coef, int pool, float (&rawv)[2 * GP]) {
     constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = POS ? 2 * GP : GP;
     const int L = g.L, TL = S.TL;
-    tile_load<AXIS>(S.reg, S.RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t);
-    tile_load<AXIS>(S.g2, S.R2, 0, stacked, g.OC, hg * OCG, OCG, t);
+    tile_load<AXIS>(S.reg, S.RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, g.bf16);
+    tile_load<AXIS>(S.g2, S.R2, 0, stacked, g.OC, hg * OCG, OCG, t, g.bf16);
     tile_load_pooled<AXIS>(S.g3, S.R3, 0, dy, g.C, hg * GP, GP, g.H, pool, t);
     tile_load<AXIS>(S.g3, S.R3, GP, lse, g.G, hg, 1, t);
     if (POS) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
     float* tab = red + 256;
     const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
-    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t);
+    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, g.bf16);
     const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
     const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
     const float a_qr = ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
         reg[ls * RS + NCH * L + i] = lse;
     }
     __syncthreads();
-    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t);
+    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t, g.bf16);
     if (lse_out) tile_store<AXIS>(reg, RS, NCH, lse_out, g.G, hg, 1, t);
     if (out_partials) {
         float v[2 * OCG];
@@ -217,6 +217,25 @@ __device__ __forceinline__ float ldg_u(const float* __restrict__ ubase, unsigned
 __device__ __forceinline__ void stg_u(float* __restrict__ ubase, unsigned byteoff, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
 }
+// Activation-storage variants (qkv_raw / stacked): element offsets; BF = stored as bfloat16
+template <bool BF>
+__device__ __forceinline__ const float* act_base(const float* p, size_t elems) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + elems * (BF ? 2 : 4));
+}
+template <bool BF>
+__device__ __forceinline__ float* act_base(float* p, size_t elems) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * (BF ? 2 : 4));
+}
+template <bool BF>
+__device__ __forceinline__ float lda_u(const float* __restrict__ ubase, unsigned elemoff) {
+    if (BF) return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(ubase) + elemoff * 2u));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + elemoff * 4u);
+}
+template <bool BF>
+__device__ __forceinline__ void sta_u(float* __restrict__ ubase, unsigned elemoff, float v) {
+    if (BF) *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ubase) + elemoff * 2u) = f32_to_bf16_bits(v);
+    else *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + elemoff * 4u) = v;
+}
 
 // Where the elements of one super-tile live.  (n0, s0, nseq) are wave-uniform (first image, first sequence inside
 // it, sequences in the tile); element t of a thread is e = threadIdx.x + 256 t, laid out with lanes along the
@@ -265,18 +284,23 @@ struct SuperPrefetch {
     static_assert(NTA * NCHL <= 32, "prefetch registers");
     float v[NTA * NCHL];
 
-    __device__ __forceinline__ void issue(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
-        const float* base = qkv_raw + ((size_t)m.n0 * 2 * g.C + hg * F::NCH) * g.HW;      // uniform
+    template <bool BF>
+    __device__ __forceinline__ void issue_t(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
+        const float* base = act_base<BF>(qkv_raw, ((size_t)m.n0 * 2 * g.C + hg * F::NCH) * g.HW);      // uniform
         const int img = 2 * g.C * g.HW;
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
             int lo, dn, pix;
             if (m.locate(g, t, lo, dn, pix)) {
-                const unsigned off = (unsigned)(dn * img + pix) * 4u;
+                const unsigned off = (unsigned)(dn * img + pix);
 #pragma unroll
-                for (int ch = 0; ch < NCHL; ++ch) v[t * NCHL + ch] = ldg_u(base, off + (unsigned)(ch * g.HW) * 4u);
+                for (int ch = 0; ch < NCHL; ++ch) v[t * NCHL + ch] = lda_u<BF>(base, off + (unsigned)(ch * g.HW));
             }
         }
+    }
+    __device__ __forceinline__ void issue(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
+        if (g.bf16) issue_t<true>(qkv_raw, g, hg, m);
+        else issue_t<false>(qkv_raw, g, hg, m);
     }
     __device__ __forceinline__ void commit(float* reg, const AxialGeom& g, const Map& m, const float* __restrict__ sc,
                                            const float* __restrict__ sh) const {
@@ -292,21 +316,28 @@ struct SuperPrefetch {
 };
 
 // LDS -> global, `nch` channels starting at LDS channel lch0 (height axis: re-maps rows to lanes for coalescing).
-template <class F, int AXIS>
-__device__ __forceinline__ void store_super(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
-                                            const AxialGeom& g, const SuperMap<F, AXIS>& m) {
+template <class F, int AXIS, bool BF>
+__device__ __forceinline__ void store_super_t(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
+                                              const AxialGeom& g, const SuperMap<F, AXIS>& m) {
     constexpr int L = F::LEN;
-    float* base = dst + ((size_t)m.n0 * CH + ch0) * g.HW;                                   // uniform
+    float* base = act_base<BF>(dst, ((size_t)m.n0 * CH + ch0) * g.HW);                      // uniform
     const int img = CH * g.HW;
 #pragma unroll
     for (int t = 0; t < F::nta(AXIS) * F::EPT; ++t) {
         int lo, dn, pix;
         if (m.locate(g, t, lo, dn, pix)) {
-            const unsigned off = (unsigned)(dn * img + pix) * 4u;
+            const unsigned off = (unsigned)(dn * img + pix);
             const float* src = reg + lo + lch0 * L;
-            for (int ch = 0; ch < nch; ++ch) stg_u(base, off + (unsigned)(ch * g.HW) * 4u, src[ch * L]);
+            for (int ch = 0; ch < nch; ++ch) sta_u<BF>(base, off + (unsigned)(ch * g.HW), src[ch * L]);
         }
     }
+}
+// bf16 != 0: dst is stored as bfloat16 (only ever the `stacked` tensor; lse and the rest stay float32)
+template <class F, int AXIS>
+__device__ __forceinline__ void store_super(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
+                                            const AxialGeom& g, const SuperMap<F, AXIS>& m, int bf16 = 0) {
+    if (bf16) store_super_t<F, AXIS, true>(reg, lch0, dst, CH, ch0, nch, g, m);
+    else store_super_t<F, AXIS, false>(reg, lch0, dst, CH, ch0, nch, g, m);
 }
 
 // EXACT = true : online softmax (running max, one rescale per 4-column chunk); if `flag` is given the kernel only
@@ -539,11 +570,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                     int dn, sq;
                     cur.image_of(g, ls, dn, sq);
                     const int pix = sq * g.W + i;
-                    float* bo = stacked + ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW;            // uniform
-                    const unsigned off = (unsigned)(dn * g.OC * g.HW + pix) * 4u;
+                    const unsigned off = (unsigned)(dn * g.OC * g.HW + pix);
+                    if (g.bf16) {
+                        float* bo = act_base<true>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);     // uniform
+#pragma unroll
+                        for (int k = 0; k < OCG; ++k) sta_u<true>(bo, off + (unsigned)(k * g.HW), outv[k]);
+                    } else {
+                        float* bo = act_base<false>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);    // uniform
+#pragma unroll
+                        for (int k = 0; k < OCG; ++k) sta_u<false>(bo, off + (unsigned)(k * g.HW), outv[k]);
+                    }
 #pragma unroll
                     for (int k = 0; k < OCG; ++k) {
-                        stg_u(bo, off + (unsigned)(k * g.HW) * 4u, outv[k]);
                         st_sum[k] += outv[k];
                         st_sq[k] = fmaf(outv[k], outv[k], st_sq[k]);
                     }
@@ -567,7 +605,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
         }
         if constexpr (AXIS == 0) {
             __syncthreads();
-            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
+            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, g.bf16);
             if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
         }
     }
@@ -794,7 +832,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
             }
         }
         __syncthreads();
-        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
+        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, g.bf16);
         if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
     }
     if (!EXACT && bad) atomicOr(flag, 1u);

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
             for (int e = threadIdx.x; e < GP * 64 * PC; e += MEDT_THREADS) {
                 const int p = e & (PC - 1), ls = (e >> pc_log) & 63, ch = e >> (pc_log + 6);
                 const int i = chunk0 + p;
-                if (ls < nseq && i < L) stage[(ch * 64 + ls) * RS + p] = qkv_raw[(size_t)seqoff[ls] + (size_t)ch * g.HW + i];
+                if (ls < nseq && i < L)
+                    stage[(ch * 64 + ls) * RS + p] = ld_act(qkv_raw, (size_t)seqoff[ls] + (size_t)ch * g.HW + i, g.bf16);
             }
             __syncthreads();
         }
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
                 for (int ch = 0; ch < GP; ++ch) {
                     float raw;
                     if (AXIS == 1) raw = stage[(ch * 64 + lane) * RS + p];
-                    else raw = qkv_raw[(size_t)myoff + (size_t)ch * g.HW + (size_t)i * pstride];
+                    else raw = ld_act(qkv_raw, (size_t)myoff + (size_t)ch * g.HW + (size_t)i * pstride, g.bf16);
                     x[ch] = active ? fmaf(raw, sc[ch], sh[ch]) : 0.f;
                 }
                 const float* tq = tables + (size_t)i * NR;

@@ -11,7 +11,7 @@ struct TileCtx {
 // lds[ls*stride + (lch0+ch)*L + i] = src[n][ch0+ch][pixel(seq0+ls, i)]
 template <int AXIS>
 __device__ __forceinline__ void tile_load(float* lds, int stride, int lch0, const float* __restrict__ src, int CH,
-                                          int ch0, int nch, const TileCtx& t) {
+                                          int ch0, int nch, const TileCtx& t, int bf16 = 0) {
     const int per = t.nseq * t.L;
     for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
         const int ch = e / per, r = e - ch * per;
@@ -19,13 +19,13 @@ __device__ __forceinline__ void tile_load(float* lds, int stride, int lch0, cons
         if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
         const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
         const size_t off = ((size_t)n * CH + ch0 + ch) * t.HW + (AXIS == 1 ? s * t.W + i : i * t.W + s);
-        lds[ls * stride + (lch0 + ch) * t.L + i] = src[off];
+        lds[ls * stride + (lch0 + ch) * t.L + i] = ld_act(src, off, bf16);
     }
 }
 
 template <int AXIS>
 __device__ __forceinline__ void tile_store(const float* lds, int stride, int lch0, float* __restrict__ dst, int CH,
-                                           int ch0, int nch, const TileCtx& t) {
+                                           int ch0, int nch, const TileCtx& t, int bf16 = 0) {
     const int per = t.nseq * t.L;
     for (int e = threadIdx.x; e < nch * per; e += MEDT_THREADS) {
         const int ch = e / per, r = e - ch * per;
@@ -33,7 +33,7 @@ __device__ __forceinline__ void tile_store(const float* lds, int stride, int lch
         if (AXIS == 1) { ls = r / t.L; i = r - ls * t.L; } else { i = r / t.nseq; ls = r - i * t.nseq; }
         const int b = t.seq0 + ls, n = b / t.Bo, s = b - n * t.Bo;
         const size_t off = ((size_t)n * CH + ch0 + ch) * t.HW + (AXIS == 1 ? s * t.W + i : i * t.W + s);
-        dst[off] = lds[ls * stride + (lch0 + ch) * t.L + i];
+        st_act(dst, off, lds[ls * stride + (lch0 + ch) * t.L + i], bf16);
     }
 }
 

@@ -20,7 +20,7 @@ template <int K, int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
-    int npg) {
+    int npg, int y_bf16) {
     constexpr int KK = K * K;
     __shared__ float red[MEDT_WAVES * OT * 2];
     const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
@@ -53,9 +53,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
         }
     }
     if (ok) {
-        float* yp = y + ((size_t)n * Cout + o0) * HoWo + p;
+        const size_t yo = ((size_t)n * Cout + o0) * HoWo + p;
 #pragma unroll
-        for (int o = 0; o < OT; ++o) yp[(size_t)o * HoWo] = relu ? fmaxf(acc[o], 0.f) : acc[o];
+        for (int o = 0; o < OT; ++o) st_act(y, yo + (size_t)o * HoWo, relu ? fmaxf(acc[o], 0.f) : acc[o], y_bf16);
     }
     if (partials) {
         float v[2 * OT];
@@ -83,12 +83,12 @@ static int pick_tile(int C, int max_tile, long position_blocks) {
 template <int K>
 static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin,
                         int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, int groups,
-                        hipStream_t s) {
+                        hipStream_t s, int y_bf16) {
     const int npg = N / groups;
     const unsigned gx = (unsigned)(groups * conv2d_parts_per_group(N, groups, Ho * Wo));
 #define MEDT_LAUNCH_FWD(OT)                                                                                        \
     hipLaunchKernelGGL((conv2d_fwd_kernel<K, OT>), dim3(gx, Cout / OT), dim3(MEDT_THREADS), 0, s, x, w, bias, y, partials, \
-                       Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg)
+                       Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg, y_bf16)
     switch (pick_tile(Cout, K == 7 ? 8 : 16, gx)) {
         case 16: if constexpr (K != 7) { MEDT_LAUNCH_FWD(16); } break;
         case 8: MEDT_LAUNCH_FWD(8); break;
@@ -118,15 +118,16 @@ size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, in
 }
 
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
-               int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s) {
+               int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
+               int y_bf16) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    if (conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
+    if (!y_bf16 && conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
         (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
         return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
     switch (K) {
-        case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
-        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
-        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s);
+        case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
+        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
+        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
     }
     set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K);
     return MEDT_EUNSUPPORTED;

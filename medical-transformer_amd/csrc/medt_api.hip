@@ -129,13 +129,15 @@ int medt_axial_core_stats(const medt_axial_desc* d, const medt_axial_params* p, 
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
+    float* qkv_raw = (float*)sv->qkv_raw;         // float32 or bfloat16 storage (g.bf16)
+    float* stacked = (float*)sv->stacked;
     Carver c(ws, ws_bytes);
     FwdWs w(c, g);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     LayerStats st(sv->stats, g);
     GatePtrs gates;
     if ((rc = effective_gates(d, p, w.gate_eff, (hipStream_t)stream, &gates))) return rc;
-    return axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, (hipStream_t)stream);
+    return axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, (hipStream_t)stream);
 }
 
 int medt_axial_core_fwd(const medt_axial_desc* d, const medt_axial_params* p, const medt_axial_saved* sv, void* ws,
@@ -143,13 +145,15 @@ int medt_axial_core_fwd(const medt_axial_desc* d, const medt_axial_params* p, co
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
+    float* qkv_raw = (float*)sv->qkv_raw;         // float32 or bfloat16 storage (g.bf16)
+    float* stacked = (float*)sv->stacked;
     Carver c(ws, ws_bytes);
     FwdWs w(c, g);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     LayerStats st(sv->stats, g);
     GatePtrs gates;
     if ((rc = effective_gates(d, p, w.gate_eff, (hipStream_t)stream, &gates))) return rc;
-    return axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
+    return axial_attn_fwd(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse,
                           d->training ? w.part_out : nullptr, w.flag, (hipStream_t)stream);
 }
 
@@ -158,6 +162,8 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
+    float* qkv_raw = (float*)sv->qkv_raw;         // float32 or bfloat16 storage (g.bf16)
+    float* stacked = (float*)sv->stacked;
     if (!x || !y) { set_error("null x / y"); return MEDT_EINVAL; }
     if (d->training && g.row_count <= 1.0) {      // nn.BatchNorm raises here too; the unbiased running variance divides by count-1
         set_error("axial: training-mode BatchNorm needs more than 1 value per channel (got %g)", g.row_count);
@@ -174,28 +180,28 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if (wopos_small_ok(g, *d)) {
         // tiny position-free layers (MedT's local branch): the whole layer in one workgroup per (BN group, head),
         // then one finalisation launch for the saved statistics and the ordered running-stat updates
-        if ((rc = wopos_small_fwd(g, *d, *p, x, y, sv->qkv_raw, sv->stacked, sv->lse, w.part_qkv, w.part_sim, w.part_out,
+        if ((rc = wopos_small_fwd(g, *d, *p, x, y, qkv_raw, stacked, sv->lse, w.part_qkv, w.part_sim, w.part_out,
                                   s))) return rc;
         return bn_finalize3(w.part_qkv, 2 * g.C, g.row_count, p->bn_qkv, st.qkv, w.part_sim, g.SC, g.sim_count,
                             p->bn_similarity, st.sim, w.part_out, g.OC, g.row_count, p->bn_output, st.out, 1, g.groups,
                             d->momentum, d->eps, tr, s);
     }
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
-    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, sv->qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
-                         2 * g.C, 1, 1, 0, 0, g.groups, s))) return rc;
+    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
+                         2 * g.C, 1, 1, 0, 0, g.groups, s, g.bf16))) return rc;
     if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
                           st.qkv, s))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
-    if (tr && (rc = axial_logit_stats(g, sv->qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
+    if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
     if ((rc = bn_finalize(w.part_sim, sim_stats_parts(g), g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,
                           st.sim, s))) return rc;
     // logits + softmax + gated sv|sve, bn_output batch statistics                                 :157-178
-    if ((rc = axial_attn_fwd(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse,
+    if ((rc = axial_attn_fwd(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse,
                              tr ? w.part_out : nullptr, w.flag, s))) return rc;
     if ((rc = bn_finalize(w.part_out, g.oparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
                           st.out, s))) return rc;
     // bn_output + pair-sum + AvgPool                                                              :179-187
-    return axial_out_fwd(*d, sv->stacked, st.out, y, s);
+    return axial_out_fwd(*d, stacked, st.out, y, s);
 }
 
 int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, const float* y,
@@ -204,6 +210,8 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     AxialGeom g;
     int rc = check_common(d, p, sv, &g);
     if (rc) return rc;
+    float* qkv_raw = (float*)sv->qkv_raw;         // float32 or bfloat16 storage (g.bf16)
+    float* stacked = (float*)sv->stacked;
     if (!x || !dy || !dx || !gr || !sv->lse) { set_error("null x / dy / dx / grads / lse"); return MEDT_EINVAL; }
     if (!gr->w_qkv || !gr->bn_qkv_weight || !gr->bn_qkv_bias || !gr->bn_sim_weight || !gr->bn_sim_bias ||
         !gr->bn_out_weight || !gr->bn_out_bias || (g.pos && !gr->relative)) {
@@ -222,13 +230,13 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         // tiny position-free layers: dy -> gradient at the qkv_transform output in one workgroup per (BN group, head);
         // one finalisation launch then sums the per-group partials into the BatchNorm parameter gradients and writes
         // bn_qkv's backward coefficients for the conv kernels
-        if ((rc = wopos_small_bwd(g, *d, *p, y, dy, sv->qkv_raw, sv->stacked, sv->lse, st.qkv, st.sim, st.out, w.dqkv,
+        if ((rc = wopos_small_bwd(g, *d, *p, y, dy, qkv_raw, stacked, sv->lse, st.qkv, st.sim, st.out, w.dqkv,
                                   w.part_ob, w.part_sb, w.part_qb, s))) return rc;
         if ((rc = wopos_small_bwd_finalize(g, *d, *p, w.part_ob, w.part_sb, w.part_qb, st.qkv, st.sim, st.out, w.coef_qkv,
                                            *gr, s))) return rc;
-        if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
+        if ((rc = conv1x1_bwd_data(w.dqkv, qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
             return rc;
-        return conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C,
+        return conv2d_bwd_weight(w.dqkv, qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C,
                                  1, 1, 0, g.groups, s);
     }
     if (d->out_relu) {               // fused ReLU after the layer: mask the incoming gradient by the output sign
@@ -236,25 +244,31 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         dy = w.dy_masked;
     }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
-    if ((rc = axial_out_bwd_stats(*d, sv->stacked, dy, st.out, w.part_ob, s))) return rc;
+    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
     if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, 1.f / (float)(d->stride * d->stride),
                               st.out, p->bn_output.weight, tr, w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s)))
         return rc;
     // bn_similarity backward statistics (pass A), coefficients
-    if ((rc = axial_attn_bwd_stats(g, sv->qkv_raw, st.qkv, st.sim, p->relative, gates, sv->stacked, sv->lse, dy,
+    if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse, dy,
                                    w.coef_out, d->stride, w.part_sb, s))) return rc;
     if ((rc = axial_sim_bwd_finalize(g, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, gr->bn_sim_weight,
                                      gr->bn_sim_bias, s))) return rc;
     // attention backward (pass B)
-    if ((rc = axial_attn_bwd(g, sv->qkv_raw, st.qkv, st.sim, w.coef_sim, p->relative, gates, sv->stacked, sv->lse, dy,
+    if ((rc = axial_attn_bwd(g, qkv_raw, st.qkv, st.sim, w.coef_sim, p->relative, gates, stacked, sv->lse, dy,
                              w.coef_out, d->stride, w.dqkv, w.part_qb, w.rel_part, gr->gates ? w.gate_part : nullptr,
                              s))) return rc;
     // bn_qkv backward, qkv_transform backward
     if ((rc = bn_bwd_finalize(w.part_qb, g.tpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
-    if ((rc = conv1x1_bwd_data(w.dqkv, sv->qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
+    const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
+    if (g.bf16) {       // bf16 storage: materialise the bn_qkv backward in fp32, then the plain 1x1 dgrad / wgrad
+        if ((rc = bn_bwd_apply_raw_bf16(w.dqkv, qkv_raw, w.coef_qkv, g.N, 2 * g.C, g.HW, g.groups, s))) return rc;
+        bq_raw = nullptr;
+        bq_coef = nullptr;
+    }
+    if ((rc = conv1x1_bwd_data(w.dqkv, bq_raw, bq_coef, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;
-    if ((rc = conv2d_bwd_weight(w.dqkv, sv->qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
+    if ((rc = conv2d_bwd_weight(w.dqkv, bq_raw, bq_coef, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
                                 1, 0, g.groups, s))) return rc;
     if (g.pos) {
         if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;

@@ -40,6 +40,23 @@ struct BnStats {
 };
 
 // ---- device side ----------------------------------------------------------
+// Activation storage of the attention layer's saved tensors (qkv_raw, stacked): float32, or bfloat16 when
+// medt_axial_desc.act_dtype == 1.  Arithmetic is always fp32: bf16 is widened on load (exact) and rounded to
+// nearest-even on store.  Pointers keep the type float*; `bf` says what they really point to.
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float ld_act(const float* p, size_t i, int bf) {
+    return bf ? bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p)[i]) : p[i];
+}
+__device__ __forceinline__ void st_act(float* p, size_t i, float v, int bf) {
+    if (bf) reinterpret_cast<unsigned short*>(p)[i] = f32_to_bf16_bits(v);
+    else p[i] = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -30,6 +30,9 @@ int bn_bwd_finalize(const float* partials, int parts_per_group, int groups, int 
 
 // bn_output apply + pair-sum + AvgPool2d(stride):  stacked (N,OC,H,W) -> y (N,C,H/s,W/s)
 int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s);
+// d[i] = c0*d[i] + c1*raw[i] + c2 per (group, channel) with raw stored as bfloat16: materialises the bn_qkv backward
+// so the fp32 1x1 dgrad / wgrad kernels run without their (raw, coef) operands
+int bn_bwd_apply_raw_bf16(float* d, const float* raw_bf16, const float* coef, int N, int CH, int HW, int groups, hipStream_t s);
 // partials [n][ptile][OC][2] of [sum dstk, sum dstk*xhat] with dstk = dy (un-pooled, unscaled)
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st,
                         float* partials, hipStream_t s);
@@ -41,8 +44,10 @@ int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
 // partials (optional): [group][part][Cout][2], part = 256-position chunk of the group's npg*Ho*Wo positions
 int conv2d_parts_per_group(int N, int groups, int HoWo);       // VALU kernel (256 positions per part)
 int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride);   // whichever kernel runs
+// y_bf16: store y as bfloat16 (VALU path only: the 1x1 qkv_transform of a bf16-storage attention layer)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
-               int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
+               int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
+               int y_bf16 = 0);
 size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // wt_scratch: Cout*Cin*K*K floats (used by the MFMA path for the flipped weights; may be NULL -> VALU path)
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
@@ -97,6 +102,7 @@ int adam_step(float* p, const float* g, float* m, float* v, float* state, size_t
 // ---- axial_core.hip ---------------------------------------------------------
 struct AxialGeom {
     int N, C, H, W, G, gp, hq, L, Bo, axis, pos, OC, OCg, SC;
+    int bf16;               // 1: qkv_raw / stacked are stored as bfloat16 (medt_axial_desc.act_dtype)
     int groups, npg;        // BN groups, images per group
     int spg;                // sequences per group = npg * Bo
     int S_T;                // sequences per workgroup tile

@@ -426,7 +426,7 @@ int bn_bwd_finalize(const float* partials, int ppg, int groups, int CH, double c
 // --------------------------------------------------------------------------- //
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float* __restrict__ stk, BnStats st,
                                                                      float* __restrict__ y, int N, int C, int H, int W,
-                                                                     int OC, int stride, int npg, int relu) {
+                                                                     int OC, int stride, int npg, int relu, int bf16) {
     const int Ho = H / stride, Wo = W / stride;
     const size_t total = (size_t)N * C * Ho * Wo;
     const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
@@ -441,10 +441,11 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float
     for (int t = 0; t < per; ++t) {
         const int ch = c * per + t;
         const float sc = st.scale[grp * OC + ch], sh = st.shift[grp * OC + ch];
-        const float* src = stk + ((size_t)n * OC + ch) * H * W;
+        const size_t src = ((size_t)n * OC + ch) * H * W;
         float a = 0.f;
         for (int dh = 0; dh < stride; ++dh)
-            for (int dw = 0; dw < stride; ++dw) a += fmaf(sc, src[(size_t)(ho * stride + dh) * W + wo * stride + dw], sh);
+            for (int dw = 0; dw < stride; ++dw)
+                a += fmaf(sc, ld_act(stk, src + (size_t)(ho * stride + dh) * W + wo * stride + dw, bf16), sh);
         acc += a;
     }
     acc *= 1.f / (float)(stride * stride);
@@ -456,7 +457,7 @@ int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, fl
     const size_t total = (size_t)d.N * d.C * (d.H / d.stride) * (d.W / d.stride);
     hipLaunchKernelGGL(axial_out_fwd_kernel, dim3((unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS)),
                        dim3(MEDT_THREADS), 0, s, stacked, st, y, d.N, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups,
-                       d.out_relu);
+                       d.out_relu, d.act_dtype);
     return launch_status("axial_out_fwd");
 }
 
@@ -465,7 +466,7 @@ int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, fl
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const float* __restrict__ stk,
                                                                            const float* __restrict__ dy, BnStats st,
                                                                            float* __restrict__ partials, int C, int H,
-                                                                           int W, int OC, int stride, int npg) {
+                                                                           int W, int OC, int stride, int npg, int bf16) {
     __shared__ float red[MEDT_WAVES * 2];
     const int HW = H * W, Ho = H / stride, Wo = W / stride;
     const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
         const int ho = h / stride, wo = w / stride;
         if (ho < Ho && wo < Wo) {
             const float d = dy[((size_t)(n * C + c) * Ho + ho) * Wo + wo];
-            const float xh = (stk[((size_t)n * OC + ch) * HW + p] - st.mean[grp * OC + ch]) * st.rstd[grp * OC + ch];
+            const float xh = (ld_act(stk, ((size_t)n * OC + ch) * HW + p, bf16) - st.mean[grp * OC + ch]) * st.rstd[grp * OC + ch];
             v[0] = d;
             v[1] = d * xh;
         }
@@ -492,8 +493,27 @@ int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const fl
     const int OC = d.has_pos ? 2 * d.C : d.C;
     const int npg = d.N / d.bn_groups, ppg = cdiv(npg * d.H * d.W, MEDT_THREADS);
     hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(d.bn_groups * ppg, OC), dim3(MEDT_THREADS), 0, s, stacked, dy, st,
-                       partials, d.C, d.H, d.W, OC, d.stride, npg);
+                       partials, d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype);
     return launch_status("axial_out_bwd_stats");
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void bn_bwd_apply_raw_bf16_kernel(float* __restrict__ d,
+                                                                             const unsigned short* __restrict__ raw,
+                                                                             const float* __restrict__ coef, int CH, int HW,
+                                                                             int npg, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)((idx / HW) % CH), n = (int)(idx / ((size_t)HW * CH));
+    const float* cf = coef + ((size_t)(n / npg) * CH + ch) * 3;
+    d[idx] = fmaf(cf[0], d[idx], fmaf(cf[1], bf16_bits_to_f32(raw[idx]), cf[2]));
+}
+
+int bn_bwd_apply_raw_bf16(float* d, const float* raw_bf16, const float* coef, int N, int CH, int HW, int groups, hipStream_t s) {
+    const size_t total = (size_t)N * CH * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_raw_bf16_kernel, dim3((unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS)),
+                       dim3(MEDT_THREADS), 0, s, d, reinterpret_cast<const unsigned short*>(raw_bf16), coef, CH, HW,
+                       N / groups, total);
+    return launch_status("bn_bwd_apply_raw_bf16");
 }
 
 }  // namespace medt

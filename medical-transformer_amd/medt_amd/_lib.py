@@ -25,7 +25,7 @@ class AxialDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("G", C.c_int32),
                 ("axis", C.c_int32), ("has_pos", C.c_int32), ("stride", C.c_int32), ("training", C.c_int32),
                 ("bn_groups", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float), ("out_relu", C.c_int32),
-                ("gate_mode", C.c_int32)]
+                ("gate_mode", C.c_int32), ("act_dtype", C.c_int32)]
 
 
 class ConvDesc(C.Structure):

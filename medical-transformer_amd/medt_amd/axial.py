@@ -16,15 +16,33 @@ from . import _lib as L
 from . import optim as OPT
 
 
+ACT_BF16 = False
+
+
+def set_activation_dtype(dtype) -> None:
+    """Storage type of the attention layers' saved activations (qkv_transform output and sv|sve): torch.float32 -- the
+    reference's -- or torch.bfloat16 (BASELINE.json configs[1]).  Arithmetic, statistics, layer inputs/outputs and all
+    gradients stay float32 either way; position-free (wopos) layers always store float32."""
+    global ACT_BF16
+    if dtype in (torch.bfloat16, "bf16", "bfloat16"):
+        ACT_BF16 = True
+    elif dtype in (torch.float32, "f32", "fp32", "float32"):
+        ACT_BF16 = False
+    else:
+        raise L.MedtError(f"activation storage dtype {dtype!r} unsupported (float32 or bfloat16)")
+
+
 class AxialConfig:
     """Static geometry + BatchNorm buffers of one attention layer."""
     __slots__ = ("groups", "axis", "has_pos", "stride", "bn_groups", "eps", "momentum",
-                 "bn_qkv", "bn_similarity", "bn_output", "out_relu", "gate_mode")
+                 "bn_qkv", "bn_similarity", "bn_output", "out_relu", "gate_mode", "act_dtype")
 
     def __init__(self, groups, axis, has_pos, stride, bn_qkv, bn_similarity, bn_output, bn_groups=1,
                  eps=1e-5, momentum=0.1, out_relu=False, gate_mode=0):
         self.groups, self.axis, self.has_pos, self.stride = groups, axis, has_pos, stride
         self.gate_mode = gate_mode
+        # storage of the layer's saved qkv_raw / stacked tensors: bf16 only for the position-encoded layers
+        self.act_dtype = 1 if (ACT_BF16 and has_pos) else 0
         self.bn_groups, self.eps, self.momentum, self.out_relu = bn_groups, eps, momentum, out_relu
         self.bn_qkv, self.bn_similarity, self.bn_output = bn_qkv, bn_similarity, bn_output
 
@@ -54,7 +72,7 @@ def _bn_ptrs(bn, training: bool) -> L.BnPtrs:
 def _desc(x, cfg: AxialConfig, training: bool) -> L.AxialDesc:
     N, Cc, H, W = x.shape
     return L.AxialDesc(N, Cc, H, W, cfg.groups, cfg.axis, int(cfg.has_pos), cfg.stride, int(training),
-                       cfg.bn_groups, cfg.eps, cfg.momentum, int(cfg.out_relu), int(cfg.gate_mode))
+                       cfg.bn_groups, cfg.eps, cfg.momentum, int(cfg.out_relu), int(cfg.gate_mode), int(cfg.act_dtype))
 
 
 def _params(cfg, w_qkv, relative, gates, training) -> L.AxialParams:
@@ -78,8 +96,9 @@ class AxialAttentionFn(torch.autograd.Function):
         params = _params(cfg, w_qkv, relative, gates, training)
         OC = 2 * Cc if cfg.has_pos else Cc
         dev = x.device
-        qkv_raw = torch.empty((N, 2 * Cc, H, W), device=dev, dtype=torch.float32)
-        stacked = torch.empty((N, OC, H, W), device=dev, dtype=torch.float32)
+        sdt = torch.bfloat16 if cfg.act_dtype == 1 else torch.float32
+        qkv_raw = torch.empty((N, 2 * Cc, H, W), device=dev, dtype=sdt)
+        stacked = torch.empty((N, OC, H, W), device=dev, dtype=sdt)
         lse = torch.empty((N, cfg.groups, H, W), device=dev, dtype=torch.float32)
         nstats = lib.medt_axial_stats_floats(C.byref(desc))
         if nstats == 0:

@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib):
 def test_struct_layouts_match_header():
     """sizeof of the ctypes mirrors == what the C compiler lays out (checked via the documented field lists)."""
     from medt_amd import _lib
-    assert ctypes.sizeof(_lib.AxialDesc) == 14 * 4
+    assert ctypes.sizeof(_lib.AxialDesc) == 15 * 4
     assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
     assert ctypes.sizeof(_lib.BnPtrs) == 5 * 8
     assert ctypes.sizeof(_lib.AxialParams) == 8 + 3 * 40 + 5 * 8

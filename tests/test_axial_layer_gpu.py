@@ -63,18 +63,18 @@ def run_case(layer, st, x, dout, kind, width, stride, device, training=True, bn_
     return got, want
 
 
-def compare(got, want, tol=TOL):
+def compare(got, want, tol=TOL, grad_floor=1e-3, grad_tol=None):
     gscale = max(want[k].abs().max().item() for k in want if k.startswith("grad/"))
     bad = []
     for k in want:
         a, b = got[k].detach().double().cpu(), want[k].detach().double().cpu()
         if k.startswith("grad/"):
             # gradients that are mathematically zero (bn_similarity.bias, ...) are compared on the layer's scale
-            scale = max(b.abs().max().item(), 1e-3 * gscale)
+            scale = max(b.abs().max().item(), grad_floor * gscale)
         else:
             scale = max(b.abs().max().item(), 1e-30)
         err = (a - b).abs().max().item() / scale
-        if not err < tol:
+        if not err < (grad_tol if (grad_tol is not None and k.startswith("grad/")) else tol):
             bad.append((k, err))
     assert not bad, bad
 
@@ -162,6 +162,42 @@ def test_layer_vs_reference_fixture(fn, device):
             assert err < TOL, (k, err)
         if k.startswith("buf/"):
             assert H.rel_err(layer.state_dict()[k[4:]].double(), fx[k]) < TOL, k
+
+
+BF16_TOL = 3e-2      # bf16 storage of qkv_raw / stacked: 2^-9 relative rounding per stored element (fp32 arithmetic)
+
+
+@pytest.mark.parametrize("case", [("dynamic", 16, 64, True, 1, 2, 8), ("dynamic", 32, 32, False, 2, 2, 32),
+                                  ("dynamic", 64, 16, True, 1, 3, 16), ("dynamic", 128, 8, False, 2, 2, 8),
+                                  ("plain", 32, 128, True, 1, 1, 4), ("gatedsig", 16, 24, True, 1, 2, 5)],
+                         ids=lambda c: "-".join(str(v) for v in c))
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_layer_bf16_storage_vs_oracle(case, training, device):
+    """BASELINE.json configs[1]: qkv_transform output and sv|sve kept as bfloat16 between the kernels and for backward,
+    fp32 arithmetic and statistics.  Against the fp64 oracle (which rounds nothing) within BF16_TOL."""
+    import medt_amd
+    kind, C, L, width, stride, N, other = case
+    medt_amd.set_activation_dtype(torch.bfloat16)
+    try:
+        layer = make_layer(kind, C, L, width, stride, device)
+        st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 300 + C + L)
+        g = torch.Generator().manual_seed(17 + L)
+        shape = (N, C, other, L) if width else (N, C, L, other)
+        x = torch.randn(shape, generator=g)
+        dout = torch.randn((N, C, shape[2] // stride, shape[3] // stride), generator=g)
+        got, want = run_case(layer, st, x, dout, kind, width, stride, device, training)
+    finally:
+        medt_amd.set_activation_dtype(torch.float32)
+    if not training:
+        got = {k: v for k, v in got.items() if not k.startswith("buf/")}
+        want = {k: v for k, v in want.items() if not k.startswith("buf/")}
+    # parameter gradients that are sums with heavy cancellation (the gates, bn_similarity.bias == 0 analytically) carry
+    # the rounding noise of the stored activations: they are judged on 10 % of the layer's largest gradient, at 2x the
+    # activation tolerance (observed worst: gate gradients, 3.3e-2)
+    compare(got, want, BF16_TOL, grad_floor=0.1, grad_tol=2 * BF16_TOL)
+    # and it is not silently the fp32 path: the result differs from the fp32-storage run beyond fp32 noise
+    got32, _ = run_case(layer, st, x, dout, kind, width, stride, device, training)
+    assert H.rel_err(got["y"], got32["y"]) > 1e-5
 
 
 def test_large_batch_property(device):
