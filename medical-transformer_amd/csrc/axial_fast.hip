@@ -11,9 +11,27 @@
 //     16 distinct 16-byte slots (copy stride = 16 floats mod 64): conflict-free.
 //   * softmax runs online over the 4-column chunks (running max, one rescale per chunk), so the logits are
 //     computed once instead of twice.
+//
+// This file is compiled twice (medt_amd/build.py): MEDT_FAST_BF16=0 -> float32 storage of qkv_raw / stacked
+// (axial_attn_fwd_fast), MEDT_FAST_BF16=1 -> bfloat16 storage (axial_attn_fwd_fast_bf16).  The storage type is a
+// compile-time constant of the hot loops (kBF); the two sets of kernels live in distinct namespaces.
 #include "axial_tiles.h"
 
+#ifndef MEDT_FAST_BF16
+#define MEDT_FAST_BF16 0
+#endif
+#if MEDT_FAST_BF16
+#define MEDT_FAST_NS fast_bf16
+#define MEDT_FAST_FN axial_attn_fwd_fast_bf16
+#else
+#define MEDT_FAST_NS fast_f32
+#define MEDT_FAST_FN axial_attn_fwd_fast
+#endif
+
 namespace medt {
+namespace MEDT_FAST_NS {
+
+constexpr bool kBF = MEDT_FAST_BF16 != 0;
 
 __host__ __device__ static inline int copy_stride(int L) {
     const int two = 2 * L;
@@ -62,7 +80,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
     float* tab = red + 256;
     const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
-    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, g.bf16);
+    tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, kBF ? 1 : 0);
     const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
     const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
     const float a_qr = ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E;
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
         reg[ls * RS + NCH * L + i] = lse;
     }
     __syncthreads();
-    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t, g.bf16);
+    tile_store<AXIS>(reg, RS, 0, stacked, g.OC, hg * OCG, OCG, t, kBF ? 1 : 0);
     if (lse_out) tile_store<AXIS>(reg, RS, NCH, lse_out, g.G, hg, 1, t);
     if (out_partials) {
         float v[2 * OCG];
@@ -200,6 +218,8 @@ struct Fast3 {
     static constexpr int nta(int axis) { return axis == 1 ? (NT < 2 ? NT : 2) : NT; }
 };
 
+}  // namespace MEDT_FAST_NS
+#if !MEDT_FAST_BF16
 int fast3_max_subtiles(int gp, int L, int axis) {     // host mirror of Fast3<GP,L>::nta(axis) (0 = no compile-time variant)
     if (L != 16 && L != 32 && L != 64 && L != 128) return 0;
     const int S_T = MEDT_THREADS / L, RS = (2 * gp + 1) * L + 4;
@@ -207,6 +227,8 @@ int fast3_max_subtiles(int gp, int L, int axis) {     // host mirror of Fast3<GP
     NT = NT < 1 ? 1 : (NT > 8 ? 8 : NT);
     return axis == 1 && NT > 2 ? 2 : NT;
 }
+#endif
+namespace MEDT_FAST_NS {
 
 // Global accesses of the fast kernels go through a wave-uniform 64-bit base plus a 32-bit per-lane byte offset:
 // the compiler then uses the saddr form of global_load/global_store and the phases around the sweep spend no VALU
@@ -299,8 +321,7 @@ struct SuperPrefetch {
         }
     }
     __device__ __forceinline__ void issue(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
-        if (g.bf16) issue_t<true>(qkv_raw, g, hg, m);
-        else issue_t<false>(qkv_raw, g, hg, m);
+        issue_t<kBF>(qkv_raw, g, hg, m);
     }
     __device__ __forceinline__ void commit(float* reg, const AxialGeom& g, const Map& m, const float* __restrict__ sc,
                                            const float* __restrict__ sh) const {
@@ -336,7 +357,7 @@ __device__ __forceinline__ void store_super_t(const float* reg, int lch0, float*
 template <class F, int AXIS>
 __device__ __forceinline__ void store_super(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
                                             const AxialGeom& g, const SuperMap<F, AXIS>& m, int bf16 = 0) {
-    if (bf16) store_super_t<F, AXIS, true>(reg, lch0, dst, CH, ch0, nch, g, m);
+    if (kBF && bf16) store_super_t<F, AXIS, true>(reg, lch0, dst, CH, ch0, nch, g, m);
     else store_super_t<F, AXIS, false>(reg, lch0, dst, CH, ch0, nch, g, m);
 }
 
@@ -571,17 +592,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                     cur.image_of(g, ls, dn, sq);
                     const int pix = sq * g.W + i;
                     const unsigned off = (unsigned)(dn * g.OC * g.HW + pix);
-                    if (g.bf16) {
-                        float* bo = act_base<true>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);     // uniform
-#pragma unroll
-                        for (int k = 0; k < OCG; ++k) sta_u<true>(bo, off + (unsigned)(k * g.HW), outv[k]);
-                    } else {
-                        float* bo = act_base<false>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);    // uniform
-#pragma unroll
-                        for (int k = 0; k < OCG; ++k) sta_u<false>(bo, off + (unsigned)(k * g.HW), outv[k]);
-                    }
+                    float* bo = act_base<kBF>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);      // uniform
 #pragma unroll
                     for (int k = 0; k < OCG; ++k) {
+                        sta_u<kBF>(bo, off + (unsigned)(k * g.HW), outv[k]);
                         st_sum[k] += outv[k];
                         st_sq[k] = fmaf(outv[k], outv[k], st_sq[k]);
                     }
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
         }
         if constexpr (AXIS == 0) {
             __syncthreads();
-            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, g.bf16);
+            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, 1);
             if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
         }
     }
@@ -643,8 +657,12 @@ struct Fast4 {
     static constexpr size_t lds_floats(int nt) { return (size_t)S_T * nt * RS + 256 + 8 * CS; }
 };
 
+}  // namespace MEDT_FAST_NS
+#if !MEDT_FAST_BF16
 int fast4_subtile_sequences(int L) { return MEDT_THREADS / (L / 4); }
 int fast4_max_subtiles(int axis) { return axis == 1 ? 1 : 2; }
+#endif
+namespace MEDT_FAST_NS {
 
 template <int AXIS, int L, bool EXACT>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
@@ -832,7 +850,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
             }
         }
         __syncthreads();
-        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, g.bf16);
+        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, 1);
         if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
     }
     if (!EXACT && bad) atomicOr(flag, 1u);
@@ -889,7 +907,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
         return launch_status(#KERNEL);                                                                      \
     } while (0)
 
-int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+}  // namespace MEDT_FAST_NS
+using namespace MEDT_FAST_NS;
+
+int MEDT_FAST_FN(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
 #define MEDT_K_EXACT(a, b, c) attn_fwd3_kernel<a, b, c, true>
 #define MEDT_K_BOUND(a, b, c) attn_fwd3_kernel<a, b, c, false>

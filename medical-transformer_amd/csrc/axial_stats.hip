@@ -20,6 +20,7 @@
 // 256 contiguous bytes per load); width layers stage [channel][sequence][position] chunks through LDS (coalesced along
 // the row, read back transposed with an odd stride).
 #include "axial_tiles.h"
+#include "sim_tables.h"
 
 namespace medt {
 
@@ -30,25 +31,18 @@ int sim_stats_parts(const AxialGeom& g) { return cdiv(g.spg, 64); }
 
 // tables[(side*L + i)*NR + r]: r < HQ: U_r[i];  r >= HQ: pair (c <= c') in row-major order, off-diagonal pairs
 // carry the factor 2 of the symmetric double sum.  side 0 = q rows of `relative`, 1 = k rows.
+int sim_tables_blocks(const AxialGeom& g) { return g.pos ? 2 * (g.hq + npairs(g.hq)) : 0; }
+
 __global__ __launch_bounds__(64) void sim_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
                                                         int HQ, int L) {
-    const int NR = HQ + HQ * (HQ + 1) / 2, TL = 2 * L - 1;
-    const int side = blockIdx.x / NR, r = blockIdx.x - side * NR;
-    int a = r, b = -1;
-    if (r >= HQ) {
-        int p = r - HQ;
-        a = 0;
-        while (p >= HQ - a) { p -= HQ - a; ++a; }
-        b = a + p;
-    }
-    const float* Ra = relative + (size_t)(side * HQ + a) * TL;
-    const float* Rb = b >= 0 ? relative + (size_t)(side * HQ + b) * TL : nullptr;
-    const double w = (b > a) ? 2.0 : 1.0;
-    for (int i = threadIdx.x; i < L; i += 64) {
-        double acc = 0.0;
-        for (int d = i; d < i + L; ++d) acc += (double)Ra[d] * (Rb ? (double)Rb[d] : 1.0);
-        tables[((size_t)side * L + i) * NR + r] = (float)(w * acc);
-    }
+    __shared__ float lds[512];
+    sim_tables_block(blockIdx.x, relative, tables, HQ, L, lds);
+}
+
+int sim_tables(const AxialGeom& g, const float* relative, float* tables, hipStream_t s) {
+    if (!g.pos) return MEDT_OK;
+    hipLaunchKernelGGL(sim_tables_kernel, dim3(sim_tables_blocks(g)), dim3(64), 0, s, relative, tables, g.hq, g.L);
+    return launch_status("sim_tables");
 }
 
 template <int HQ, bool POS, int AXIS>
@@ -88,11 +82,34 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
     float r1q = 0.f, r2q = 0.f, r1k = 0.f, r2k = 0.f;
     for (int chunk0 = 0; chunk0 < L; chunk0 += PC) {
         if (AXIS == 1) {
-            for (int e = threadIdx.x; e < GP * 64 * PC; e += MEDT_THREADS) {
-                const int p = e & (PC - 1), ls = (e >> pc_log) & 63, ch = e >> (pc_log + 6);
-                const int i = chunk0 + p;
-                if (ls < nseq && i < L)
-                    stage[(ch * 64 + ls) * RS + p] = ld_act(qkv_raw, (size_t)seqoff[ls] + (size_t)ch * g.HW + i, g.bf16);
+            if ((L & 3) == 0) {
+                // rows are contiguous: 16-byte (8-byte for bf16) loads, four independent ones in flight per thread
+                const int pq_log = pc_log - 2, PC4 = PC >> 2;
+#pragma unroll 4
+                for (int e = threadIdx.x; e < GP * 64 * PC4; e += MEDT_THREADS) {
+                    const int p4 = e & (PC4 - 1), ls = (e >> pq_log) & 63, ch = e >> (pq_log + 6);
+                    const int i = chunk0 + 4 * p4;
+                    if (ls < nseq && i < L) {
+                        const size_t src = (size_t)seqoff[ls] + (size_t)ch * g.HW + i;
+                        float4 v;
+                        if (g.bf16) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(qkv_raw) + src);
+                            v = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                                            __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+                        } else {
+                            v = *reinterpret_cast<const float4*>(qkv_raw + src);
+                        }
+                        float* dst = stage + (ch * 64 + ls) * RS + 4 * p4;
+                        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                    }
+                }
+            } else {
+                for (int e = threadIdx.x; e < GP * 64 * PC; e += MEDT_THREADS) {
+                    const int p = e & (PC - 1), ls = (e >> pc_log) & 63, ch = e >> (pc_log + 6);
+                    const int i = chunk0 + p;
+                    if (ls < nseq && i < L)
+                        stage[(ch * 64 + ls) * RS + p] = ld_act(qkv_raw, (size_t)seqoff[ls] + (size_t)ch * g.HW + i, g.bf16);
+                }
             }
             __syncthreads();
         }
@@ -197,12 +214,9 @@ static int stats_chunk_log(const AxialGeom& g) {
 }
 
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      float* tables, float* partials, hipStream_t s) {
+                      const float* tables, float* partials, hipStream_t s) {
     const int sparts = sim_stats_parts(g), lg = stats_chunk_log(g);
-    if (g.pos) {
-        if (!tables) { set_error("sim_stats: no table scratch"); return MEDT_EINVAL; }
-        hipLaunchKernelGGL(sim_tables_kernel, dim3(2 * (g.hq + npairs(g.hq))), dim3(64), 0, s, relative, tables, g.hq, g.L);
-    }
+    if (g.pos && !tables) { set_error("sim_stats: no tables"); return MEDT_EINVAL; }
     const size_t stage = g.axis == 1 ? (size_t)g.gp * 64 * ((1 << lg) + 1) : 0, red = 3 * 16 * 64;
     const size_t lds = (64 + (stage > red ? stage : red)) * sizeof(float);
     const dim3 grid(g.groups * sparts, g.G), block(MEDT_THREADS);

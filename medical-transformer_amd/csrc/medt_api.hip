@@ -137,6 +137,7 @@ int medt_axial_core_stats(const medt_axial_desc* d, const medt_axial_params* p, 
     LayerStats st(sv->stats, g);
     GatePtrs gates;
     if ((rc = effective_gates(d, p, w.gate_eff, (hipStream_t)stream, &gates))) return rc;
+    if ((rc = sim_tables(g, p->relative, w.tables, (hipStream_t)stream))) return rc;
     return axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, (hipStream_t)stream);
 }
 
@@ -189,8 +190,10 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
     if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
                          2 * g.C, 1, 1, 0, 0, g.groups, s, g.bf16))) return rc;
+    // (+ the sliding-window tables of the statistics kernel below as extra blocks of this launch)
+    const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
     if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
-                          st.qkv, s))) return rc;
+                          st.qkv, s, &tj))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
     if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
     if ((rc = bn_finalize(w.part_sim, sim_stats_parts(g), g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,

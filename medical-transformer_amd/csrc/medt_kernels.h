@@ -16,8 +16,10 @@ int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const
                      int N, int Cin, int Cout, int HW, int groups, hipStream_t s);
 // Batch-norm statistics: partials [group][parts_per_group][CH][2] -> mean/rstd/scale/shift per (group, ch),
 // running-stat recurrence over the groups in order.  training==0: fold the running stats instead.
+struct TablesJob { const float* relative; float* tables; int HQ, L, blocks; };   // optional: see sim_tables_blocks()
 int bn_finalize(const float* partials, int parts_per_group, int groups, int CH, double count,
-                const medt_bn_ptrs& bn, float momentum, float eps, int training, BnStats out, hipStream_t s);
+                const medt_bn_ptrs& bn, float momentum, float eps, int training, BnStats out, hipStream_t s,
+                const TablesJob* tables = nullptr);
 // Backward: partials [group][parts][CH][2] = [sum d, sum d*xhat] (d still to be multiplied by dscale).
 // Writes coef[group][CH][3] with  dx = c0*d + c1*x + c2,  and dweight[CH], dbias[CH].
 int bn_finalize3(const float* p0, int CH0, double n0, const medt_bn_ptrs& bn0, BnStats o0,
@@ -125,6 +127,10 @@ struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; };
 // axial_fast.hip: 16-byte-LDS-read variants for has_pos && L % 4 == 0; return 1 when not applicable
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
+// same kernels compiled for bfloat16 storage of qkv_raw / stacked (axial_fast.hip with -DMEDT_FAST_BF16=1)
+int axial_attn_fwd_fast_bf16(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                             GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag,
+                             hipStream_t s);
 int fast3_max_subtiles(int gp, int L, int axis);
 int fast4_subtile_sequences(int L);
 int fast4_max_subtiles(int axis);
@@ -149,12 +155,15 @@ int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // axial_stats.hip: bn_similarity batch statistics in closed form (one read of q and k, no L x L pass).
-// partials [group][sim_stats_parts()][SC][2]; tables: sim_tables_floats() floats of scratch (sliding-window sums
-// of the relative table, rebuilt by every call)
+// partials [group][sim_stats_parts()][SC][2]; tables: sim_tables_floats() floats, the sliding-window sums of the
+// relative table.  They are built by sim_tables(), or by sim_tables_blocks() extra blocks appended to the bn_qkv
+// bn_finalize launch that precedes the statistics kernel in the layer (no launch of their own).
 size_t sim_tables_floats(const AxialGeom& g);
+int sim_tables_blocks(const AxialGeom& g);
 int sim_stats_parts(const AxialGeom& g);
+int sim_tables(const AxialGeom& g, const float* relative, float* tables, hipStream_t s);
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      float* tables, float* partials, hipStream_t s);
+                      const float* tables, float* partials, hipStream_t s);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                    GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);

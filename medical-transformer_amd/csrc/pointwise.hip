@@ -5,6 +5,7 @@
 // HBM-bound streaming kernels: lanes run along the contiguous pixel dimension, weights and
 // per-channel constants come through the scalar path (wave-uniform addresses).
 #include "medt_kernels.h"
+#include "sim_tables.h"
 
 namespace medt {
 
@@ -302,7 +303,12 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
                                                          double count, const float* __restrict__ weight,
                                                          const float* __restrict__ bias, float* running_mean,
                                                          float* running_var, int64_t* nbt, float momentum, float eps,
-                                                         int training, BnStats out) {
+                                                         int training, BnStats out, TablesJob tj) {
+    if ((int)blockIdx.x >= CH) {         // appended blocks: sliding-window tables of the layer's relative table
+        __shared__ float lds[512];
+        sim_tables_block(blockIdx.x - CH, tj.relative, tj.tables, tj.HQ, tj.L, lds);
+        return;
+    }
     bn_finalize_body(blockIdx.x, partials, ppg, groups, CH, count, weight, bias, running_mean, running_var, nbt, momentum,
                      eps, training, out);
 }
@@ -349,9 +355,10 @@ int bn_finalize3(const float* p0, int CH0, double n0, const medt_bn_ptrs& bn0, B
 }
 
 int bn_finalize(const float* partials, int ppg, int groups, int CH, double count, const medt_bn_ptrs& bn,
-                float momentum, float eps, int training, BnStats out, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(CH), dim3(64), 0, s, partials, ppg, groups, CH, count, bn.weight,
-                       bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, momentum, eps, training, out);
+                float momentum, float eps, int training, BnStats out, hipStream_t s, const TablesJob* tables) {
+    const TablesJob tj = tables ? *tables : TablesJob{nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(CH + tj.blocks), dim3(64), 0, s, partials, ppg, groups, CH, count, bn.weight,
+                       bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, momentum, eps, training, out, tj);
     return launch_status("bn_finalize");
 }
 

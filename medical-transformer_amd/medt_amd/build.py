@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmedt_hip.so")
 SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip", "conv.hip", "elementwise.hip", "axial_fast.hip", "conv_mfma.hip", "axial_small.hip", "conv_small.hip", "axial_stats.hip"]
-HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
+HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", "sim_tables.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
 
 
 def _stale() -> bool:
@@ -34,10 +34,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
     procs = []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
-    for s in SOURCES:                      # one hipcc per translation unit, in parallel
-        o = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
+    units = [(s, s.replace(".hip", ".o"), []) for s in SOURCES]
+    # the bandwidth-tuned attention kernels once more with bfloat16 storage as a compile-time constant
+    units.append(("axial_fast.hip", "axial_fast_bf16.o", ["-DMEDT_FAST_BF16=1"]))
+    for s, oname, extra in units:          # one hipcc per translation unit, in parallel
+        o = os.path.join(CSRC, "build", oname)
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO_ROOT, "include"),
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, "-I", os.path.join(REPO_ROOT, "include"),
                "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
