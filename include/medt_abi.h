@@ -43,6 +43,25 @@ int         medt_abi_version(void);
 const char* medt_last_error(void);
 
 /* ------------------------------------------------------------------------- *
+ * Deferred, grouped execution of the work no later LAYER waits for (optional).
+ *   The reference's loss.backward() / optimizer.step() (train.py:159-161) makes every Conv2d weight gradient, bias
+ *   gradient and BatchNorm bookkeeping update its own kernel launch in the middle of the dependent chain.  With a
+ *   queue bound to a stream, the layer entry points below RECORD those launches instead (weight / bias gradients and
+ *   the reductions of their partial slabs, the relative-table / gate reductions, the saved-statistics + running-stat
+ *   finalisation and BatchNorm parameter gradients of the fused small-layer kernels) and medt_queue_flush() issues
+ *   everything recorded as a few grouped launches -- call it after the forward pass (backward reads the saved
+ *   statistics) and after the backward pass (the optimizer reads the gradients).  The caller must keep every buffer
+ *   it passed to a recording call (inputs, outputs, saved tensors, workspace) alive and unmodified until the flush.
+ *   Results are bit-identical to the immediate launches (same kernels bodies, same summation order).
+ *   Without a bound queue every call launches immediately (the default).
+ * ------------------------------------------------------------------------- */
+void*  medt_queue_create(void);
+int    medt_queue_destroy(void* queue);
+int    medt_queue_bind(void* queue, void* stream);      /* queue == NULL: unbind the stream */
+size_t medt_queue_pending(const void* queue);            /* recorded, not yet flushed */
+int    medt_queue_flush(void* queue, void* stream);      /* enqueue everything recorded on `stream` */
+
+/* ------------------------------------------------------------------------- *
  * Axial attention layer
  *   replaces AxialAttention.forward          lib/models/axialnet.py:52-92
  *            AxialAttention_dynamic.forward  lib/models/axialnet.py:142-189

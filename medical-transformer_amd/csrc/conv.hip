@@ -6,7 +6,7 @@
 // written directly: lanes run along output pixels (coalesced NCHW rows), every lane keeps OT output
 // channels in registers, the K*K taps of one input channel are loaded once per lane and the weights
 // arrive through the scalar path (wave-uniform addresses, K*K contiguous floats per (o,c) pair).
-#include "medt_kernels.h"
+#include "defer.h"
 
 namespace medt {
 
@@ -228,19 +228,19 @@ int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratc
 // to dY on load (qkv_transform's gradient, whose dY is still in normalised space).
 // --------------------------------------------------------------------------- //
 template <int K, int TO, int TC>          // TO x TC output tile (16 | 32 | 64 each): small layers do not pay for 64 x 64
-__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
+__device__ __forceinline__ void conv_wgrad_body(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
-    int stride, int pad, int QS, int npg) {
+    int stride, int pad, int QS, int npg, int bx, int by, int bz) {
     constexpr int KK = K * K, RO = TO / 16, RC = TC / 16;
     // row stride 68: 16-byte aligned rows for ds_read_b128 along the position index, and 68 mod 64 = 4 puts the 16
     // B rows a wave reads at once on disjoint 4-bank groups
     __shared__ __attribute__((aligned(16))) float A[TO][68];
     __shared__ __attribute__((aligned(16))) float B[TC][68];
     const int Ktot = Cin * KK, HoWo = Ho * Wo;
-    const int o0 = blockIdx.x * TO, k0 = blockIdx.y * TC;
+    const int o0 = bx * TO, k0 = by * TC;
     const long NP = (long)N * HoWo;
-    const long q_begin = (long)blockIdx.z * QS;
+    const long q_begin = (long)bz * QS;
     const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
     const int to = threadIdx.x >> 4, tc = threadIdx.x & 15;
     const int j = threadIdx.x & 63, r0 = threadIdx.x >> 6;          // staging: fixed position j, rows r0, r0+4, ...
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
         }
         __syncthreads();
     }
-    float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
+    float* out = scratch + (size_t)bz * Cout * Ktot;
 #pragma unroll
     for (int a = 0; a < RO; ++a)
 #pragma unroll
@@ -323,6 +323,27 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
             const int o = o0 + to + 16 * a, k = k0 + tc + 16 * b;
             if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[a][b];
         }
+}
+
+template <int K, int TO, int TC>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+    int stride, int pad, int QS, int npg) {
+    conv_wgrad_body<K, TO, TC>(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, blockIdx.x,
+                               blockIdx.y, blockIdx.z);
+}
+
+// The weight gradients of many layers in one launch (defer.h): every job has this kernel's (K, TO, TC).
+using WBatch = JobBatch<WJob, 32>;
+template <int K, int TO, int TC>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_grouped_kernel(WBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    const WJob& w = b.job[j];
+    const int local = blockIdx.x - b.start[j];
+    const int bx = local % w.gx, t = local / w.gx, by = t % w.gy, bz = t / w.gy;
+    conv_wgrad_body<K, TO, TC>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride,
+                               w.pad, w.QS, w.npg, bx, by, bz);
 }
 
 static inline int wgrad_tile(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
@@ -343,7 +364,8 @@ int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo) {
 }
 
 int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
-                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s) {
+                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s,
+                      Queue* q) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     const long NP = (long)N * Ho * Wo;
     const int Ktot = Cin * K * K, QS = wgrad_chunk(Cout, Ktot, NP);
@@ -354,7 +376,17 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
         int rc = conv_wgrad_mfma(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits,
                                  N / groups, s);
         if (rc) return rc;
-        return splits == 1 ? MEDT_OK : reduce_rows(scratch, splits, Cout * Ktot, dw, s);
+        if (splits == 1) return MEDT_OK;
+        if (q) { q->reduce.push_back(RJob{scratch, dw, splits, Cout * Ktot}); return MEDT_OK; }
+        return reduce_rows(scratch, splits, Cout * Ktot, dw, s);
+    }
+    if (q) {                                               // deferred: grouped with the other layers' at the flush
+        if (K != 1 && K != 3 && K != 7) { set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K); return MEDT_EUNSUPPORTED; }
+        const int TO = wgrad_tile(Cout), TC = wgrad_tile(Ktot);
+        q->wgrad.push_back(WJob{dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups,
+                                cdiv(Cout, TO), cdiv(Ktot, TC), splits, K, TO, TC});
+        if (splits > 1) q->reduce.push_back(RJob{scratch, dw, splits, Cout * Ktot});
+        return MEDT_OK;
     }
     {
         const int TO = wgrad_tile(Cout), TC = wgrad_tile(Ktot);
@@ -383,10 +415,9 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
 
 // per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients); two stages, deterministic
 #define CS_SPLITS 16
-__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                                   int N, int C, int HW) {
+__device__ __forceinline__ void channel_sum_body(const float* __restrict__ x, float* __restrict__ part, int N, int C,
+                                                 int HW, int c, int sp) {
     __shared__ float red[MEDT_WAVES];
-    const int c = blockIdx.x, sp = blockIdx.y;
     float v[1] = {0.f};
     const long total = (long)N * HW;
     const long per = (total + CS_SPLITS - 1) / CS_SPLITS, beg = sp * per, end = beg + per < total ? beg + per : total;
@@ -397,11 +428,80 @@ __global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* 
     block_sum<1>(v, red, part + (size_t)sp * C + c);
 }
 
+__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                                   int N, int C, int HW) {
+    channel_sum_body(x, part, N, C, HW, blockIdx.x, blockIdx.y);
+}
+
+int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
+    std::vector<char> done(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        const int K = jobs[i].K, TO = jobs[i].TO, TC = jobs[i].TC;
+        WBatch b;
+        b.n = 0;
+        int blocks = 0;
+        auto launch = [&]() -> int {
+            b.start[b.n] = blocks;
+#define MEDT_WGG(KV, TOV, TCV) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<KV, TOV, TCV>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b)
+#define MEDT_WGG_TC(KV, TOV) do { if (TC == 16) MEDT_WGG(KV, TOV, 16); else if (TC == 32) MEDT_WGG(KV, TOV, 32); else MEDT_WGG(KV, TOV, 64); } while (0)
+#define MEDT_WGG_TO(KV) do { if (TO == 16) MEDT_WGG_TC(KV, 16); else if (TO == 32) MEDT_WGG_TC(KV, 32); else MEDT_WGG_TC(KV, 64); } while (0)
+            switch (K) {
+                case 1: MEDT_WGG_TO(1); break;
+                case 3: MEDT_WGG_TO(3); break;
+                default: MEDT_WGG_TO(7); break;
+            }
+#undef MEDT_WGG_TO
+#undef MEDT_WGG_TC
+#undef MEDT_WGG
+            b.n = 0;
+            blocks = 0;
+            return launch_status("conv_wgrad_grouped");
+        };
+        for (int j = i; j < n; ++j) {
+            if (done[j] || jobs[j].K != K || jobs[j].TO != TO || jobs[j].TC != TC) continue;
+            done[j] = 1;
+            b.job[b.n] = jobs[j];
+            b.start[b.n] = blocks;
+            blocks += jobs[j].gx * jobs[j].gy * jobs[j].gz;
+            if (++b.n == 32) { int rc = launch(); if (rc) return rc; }
+        }
+        if (b.n) { int rc = launch(); if (rc) return rc; }
+    }
+    return MEDT_OK;
+}
+
+using CBatch = JobBatch<CJob, 96>;
+__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_grouped_kernel(CBatch b);
+
 int channel_sum(const float* x, float* out, float* scratch, int N, int C, int HW, hipStream_t s) {
     hipLaunchKernelGGL(channel_sum_kernel, dim3(C, CS_SPLITS), dim3(MEDT_THREADS), 0, s, x, scratch, N, C, HW);
     int rc = launch_status("channel_sum");
     if (rc) return rc;
     return reduce_rows(scratch, CS_SPLITS, C, out, s);
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void channel_sum_grouped_kernel(CBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    const CJob& c = b.job[j];
+    const int local = blockIdx.x - b.start[j];
+    channel_sum_body(c.x, c.part, c.N, c.C, c.HW, local % c.C, local / c.C);
+}
+
+int channel_sum_splits() { return CS_SPLITS; }
+
+int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 96) {
+        CBatch b;
+        b.n = n - i0 < 96 ? n - i0 : 96;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[i0 + i]; b.start[i] = blocks; blocks += jobs[i0 + i].C * CS_SPLITS; }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(channel_sum_grouped_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        int rc = launch_status("channel_sum_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
 }
 
 }  // namespace medt

@@ -1,0 +1,82 @@
+// defer.h -- deferred, grouped execution of the work nothing in the layer chain waits for.
+//
+// At BASELINE.json's batch sizes a training step is ~600 dependent launches of a few microseconds each
+// (SURVEY.md H2): latency, not bandwidth.  A third of those launches produce results that no later *layer* consumes --
+// weight / bias gradients and the reductions of their split partial slabs (only the optimizer reads them), the
+// saved-statistics + running-stat bookkeeping of the fused small-layer kernels (only backward reads them), the
+// BatchNorm parameter gradients of the fused small backward.  With a queue bound to the caller's stream
+// (medt_queue_bind) the entry points record those launches as jobs instead of issuing them, and medt_queue_flush
+// issues everything recorded as a handful of GROUPED launches (one kernel, many problems: job table in the kernel
+// arguments, block -> job by prefix sums), at the end of the forward and of the backward pass.  The caller keeps
+// every buffer it handed to a deferring call alive until the flush.
+#pragma once
+#include "medt_kernels.h"
+#include <vector>
+
+namespace medt {
+
+struct BnFin {                       // one BatchNorm statistics finalisation (see bn_finalize)
+    const float* partials;
+    int ppg, CH;
+    double count;
+    const float *weight, *bias;
+    float *running_mean, *running_var;
+    int64_t* nbt;
+    BnStats out;
+};
+struct FinJob { BnFin f; int groups, training; float momentum, eps; };
+struct BfinJob {                     // bn_bwd_finalize
+    const float* partials;
+    int ppg, groups, CH, training;
+    double count;
+    float dscale;
+    BnStats st;
+    const float* weight;
+    float *coef, *dweight, *dbias;
+};
+struct RJob { const float* src; float* dst; int P, K; };                         // reduce_rows
+struct CJob { const float* x; float* part; int N, C, HW; };                      // channel_sum, first stage
+struct WJob {                        // conv_wgrad_kernel<K, TO, TC> over a (gx, gy, gz) grid
+    const float *dy, *raw, *coef, *x;
+    float* scratch;
+    int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K, TO, TC;
+};
+
+struct Queue {
+    std::vector<FinJob> fin;
+    std::vector<BfinJob> bfin;
+    std::vector<CJob> csum;
+    std::vector<WJob> wgrad;
+    std::vector<RJob> reduce;
+    size_t pending() const { return fin.size() + bfin.size() + csum.size() + wgrad.size() + reduce.size(); }
+};
+
+Queue* queue_for(hipStream_t s);     // the queue bound to this stream, or nullptr (immediate launches)
+
+BnFin make_fin(const float* partials, int ppg, int CH, double count, const medt_bn_ptrs& bn, BnStats out);
+
+// grouped launchers (each may issue several launches when the job table exceeds one kernel-argument block)
+int bn_finalize_grouped(const FinJob* jobs, int n, hipStream_t s);
+int bn_bwd_finalize_grouped(const BfinJob* jobs, int n, hipStream_t s);
+int reduce_rows_grouped(const RJob* jobs, int n, hipStream_t s);
+int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s);
+int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);
+
+// Job table passed by value in the kernel arguments (< 4 KB): block b belongs to job j with start[j] <= b < start[j+1].
+template <class J, int MAXJ>
+struct JobBatch {
+    int n;
+    int start[MAXJ + 1];
+    J job[MAXJ];
+};
+template <class B>
+__device__ __forceinline__ int find_job(const B& b, int block) {       // block-uniform binary search
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (block >= b.start[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+}  // namespace medt

@@ -1,0 +1,65 @@
+// defer.hip -- the queue registry and flush of defer.h, and its C entry points (include/medt_abi.h: medt_queue_*).
+#include "defer.h"
+#include <mutex>
+
+namespace medt {
+
+static std::mutex g_mu;
+static std::vector<std::pair<hipStream_t, Queue*>> g_bound;
+
+Queue* queue_for(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& e : g_bound)
+        if (e.first == s) return e.second;
+    return nullptr;
+}
+
+}  // namespace medt
+
+using namespace medt;
+
+extern "C" {
+
+void* medt_queue_create(void) { return new Queue(); }
+
+int medt_queue_destroy(void* q) {
+    if (!q) return MEDT_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = g_bound.size(); i-- > 0;)
+            if (g_bound[i].second == (Queue*)q) g_bound.erase(g_bound.begin() + i);
+    }
+    delete (Queue*)q;
+    return MEDT_OK;
+}
+
+int medt_queue_bind(void* q, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_bound.size(); ++i)
+        if (g_bound[i].first == (hipStream_t)stream) {
+            if (q) g_bound[i].second = (Queue*)q;
+            else g_bound.erase(g_bound.begin() + i);
+            return MEDT_OK;
+        }
+    if (q) g_bound.emplace_back((hipStream_t)stream, (Queue*)q);
+    return MEDT_OK;
+}
+
+size_t medt_queue_pending(const void* q) { return q ? ((const Queue*)q)->pending() : 0; }
+
+int medt_queue_flush(void* qv, void* stream) {
+    if (!qv) { set_error("queue flush: null queue"); return MEDT_EINVAL; }
+    Queue& q = *(Queue*)qv;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MEDT_OK;
+    // order: statistics bookkeeping; first-stage sums and weight gradients; then the reductions of their partial slabs
+    if (!rc && !q.fin.empty()) rc = bn_finalize_grouped(q.fin.data(), (int)q.fin.size(), s);
+    if (!rc && !q.bfin.empty()) rc = bn_bwd_finalize_grouped(q.bfin.data(), (int)q.bfin.size(), s);
+    if (!rc && !q.csum.empty()) rc = channel_sum_grouped(q.csum.data(), (int)q.csum.size(), s);
+    if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
+    if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
+    q.fin.clear(); q.bfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
+    return rc;
+}
+
+}  // extern "C"

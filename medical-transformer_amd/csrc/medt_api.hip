@@ -1,7 +1,7 @@
 // medt_api.hip -- the extern "C" surface declared in include/medt_abi.h.
 // Each entry point validates its descriptor, carves the caller's workspace and enqueues
 // the kernel chain on the caller's stream; nothing here allocates or synchronises.
-#include "medt_kernels.h"
+#include "defer.h"
 #include <string.h>
 
 namespace medt {
@@ -183,6 +183,14 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
         // then one finalisation launch for the saved statistics and the ordered running-stat updates
         if ((rc = wopos_small_fwd(g, *d, *p, x, y, qkv_raw, stacked, sv->lse, w.part_qkv, w.part_sim, w.part_out,
                                   s))) return rc;
+        // (saved statistics + ordered running-stat updates: y is final already, nothing in the forward chain reads
+        // them -> recorded for the grouped flush when a queue is bound)
+        if (Queue* q = queue_for(s)) {
+            q->fin.push_back(FinJob{make_fin(w.part_qkv, 1, 2 * g.C, g.row_count, p->bn_qkv, st.qkv), g.groups, tr, d->momentum, d->eps});
+            q->fin.push_back(FinJob{make_fin(w.part_sim, 1, g.SC, g.sim_count, p->bn_similarity, st.sim), g.groups, tr, d->momentum, d->eps});
+            q->fin.push_back(FinJob{make_fin(w.part_out, 1, g.OC, g.row_count, p->bn_output, st.out), g.groups, tr, d->momentum, d->eps});
+            return MEDT_OK;
+        }
         return bn_finalize3(w.part_qkv, 2 * g.C, g.row_count, p->bn_qkv, st.qkv, w.part_sim, g.SC, g.sim_count,
                             p->bn_similarity, st.sim, w.part_out, g.OC, g.row_count, p->bn_output, st.out, 1, g.groups,
                             d->momentum, d->eps, tr, s);
@@ -240,7 +248,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         if ((rc = conv1x1_bwd_data(w.dqkv, qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
             return rc;
         return conv2d_bwd_weight(w.dqkv, qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C,
-                                 1, 1, 0, g.groups, s);
+                                 1, 1, 0, g.groups, s, queue_for(s));
     }
     if (d->out_relu) {               // fused ReLU after the layer: mask the incoming gradient by the output sign
         if ((rc = relu_mask(dy, y, w.dy_masked, (size_t)g.N * g.C * (g.H / d->stride) * (g.W / d->stride), s))) return rc;
@@ -271,14 +279,19 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     }
     if ((rc = conv1x1_bwd_data(w.dqkv, bq_raw, bq_coef, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;
+    Queue* q = queue_for(s);          // parameter gradients: recorded for the grouped flush when a queue is bound
     if ((rc = conv2d_bwd_weight(w.dqkv, bq_raw, bq_coef, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
-                                1, 0, g.groups, s))) return rc;
+                                1, 0, g.groups, s, q))) return rc;
     if (g.pos) {
-        if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
+        if (q) q->reduce.push_back(RJob{w.rel_part, gr->relative, (int)w.nblocks, 2 * g.gp * TL});
+        else if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
         if (gr->gates) {
             const bool sig = d->gate_mode == 1 && p->f_qr;
-            if ((rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, sig ? w.gate_tmp : gr->gates, s))) return rc;
-            if (sig && (rc = gate_sigmoid_bwd(w.gate_tmp, w.gate_eff, gr->gates, s))) return rc;
+            if (q && !sig) q->reduce.push_back(RJob{w.gate_part, gr->gates, (int)w.nblocks, 4});
+            else {
+                if ((rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, sig ? w.gate_tmp : gr->gates, s))) return rc;
+                if (sig && (rc = gate_sigmoid_bwd(w.gate_tmp, w.gate_eff, gr->gates, s))) return rc;
+            }
         }
     }
     return MEDT_OK;
@@ -371,6 +384,11 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
         // small BN groups (local branch): conv + exact block-level statistics + normalise/residual/ReLU in one kernel,
         // then the saved statistics and the ordered running-stat updates
         if ((rc = conv_small_fwd(*d, x, w, *bn, res, z, y, cw.partials, s))) return rc;
+        if (Queue* q = queue_for(s)) {
+            q->fin.push_back(FinJob{make_fin(cw.partials, 1, d->Cout, (double)(d->N / d->bn_groups) * g.HoWo, *bn, st),
+                                    d->bn_groups, tr, d->momentum, d->eps});
+            return MEDT_OK;
+        }
         return bn_finalize(cw.partials, 1, d->bn_groups, d->Cout, (double)(d->N / d->bn_groups) * g.HoWo, *bn, d->momentum,
                            d->eps, tr, st, s);
     }
@@ -402,8 +420,13 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
             // produces the parameter gradients (one partial slot per group)
             if ((rc = bn_act_bwd_small(*d, dy, y, z, st, bn->weight, (d->has_res && dres) ? dres : nullptr, cw.dz,
                                        cw.partials, g.HoWo, s))) return rc;
-            if ((rc = bn_bwd_finalize(cw.partials, 1, d->bn_groups, d->Cout, (double)(d->N / d->bn_groups) * g.HoWo, 1.f,
-                                      st, bn->weight, d->training ? 1 : 0, cw.coef, dbn_weight, dbn_bias, s))) return rc;
+            // (only the BatchNorm parameter gradients come out of this one: dz is already final)
+            if (Queue* q = queue_for(s))
+                q->bfin.push_back(BfinJob{cw.partials, 1, d->bn_groups, d->Cout, d->training ? 1 : 0,
+                                          (double)(d->N / d->bn_groups) * g.HoWo, 1.f, st, bn->weight, cw.coef, dbn_weight,
+                                          dbn_bias});
+            else if ((rc = bn_bwd_finalize(cw.partials, 1, d->bn_groups, d->Cout, (double)(d->N / d->bn_groups) * g.HoWo, 1.f,
+                                           st, bn->weight, d->training ? 1 : 0, cw.coef, dbn_weight, dbn_bias, s))) return rc;
         } else {
         if ((rc = bn_act_bwd_stats(dy, y, z, st, gb, cw.partials, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s))) return rc;
         if ((rc = bn_bwd_finalize(cw.partials, g.ppg_bwd, d->bn_groups, d->Cout,
@@ -419,9 +442,15 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         grad_out = dy;
     }
     if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
-    if (d->has_bias && (rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, s))) return rc;
+    Queue* q = queue_for(s);          // parameter gradients: recorded for the grouped flush when a queue is bound
+    if (d->has_bias) {
+        if (q) {
+            q->csum.push_back(CJob{grad_out, cw.bias_scratch, d->N, d->Cout, g.HoWo});
+            q->reduce.push_back(RJob{cw.bias_scratch, dbias, channel_sum_splits(), d->Cout});
+        } else if ((rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, s))) return rc;
+    }
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
-                             d->pad, 1, s);
+                             d->pad, 1, s, q);
 }
 
 int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream) {

@@ -58,8 +58,11 @@ size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, in
 // dw[o,c,kh,kw] = sum_{n,ho,wo} val * x[...], val = coef ? c0*dy + c1*raw + c2 : dy (coef [group][Cout][3]);
 // scratch: conv2d_bwd_weight_splits() * Cout*Cin*K*K floats
 int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo);
+struct Queue;      // defer.h: when given, the launch (and the reduction of its partial slabs) is recorded, not issued
 int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
-                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s);
+                      int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s,
+                      Queue* q = nullptr);
+int channel_sum_splits();
 int channel_sum(const float* x, float* out, float* scratch /* 16*C floats */, int N, int C, int HW, hipStream_t s);
 
 // ---- conv_mfma.hip (fp32 matrix-core implicit GEMM; chosen by conv_use_mfma) -----------

@@ -4,7 +4,7 @@
 //   bn_output apply + pair-sum + AvgPool (axialnet.py:179-187) and its backward statistics.
 // HBM-bound streaming kernels: lanes run along the contiguous pixel dimension, weights and
 // per-channel constants come through the scalar path (wave-uniform addresses).
-#include "medt_kernels.h"
+#include "defer.h"
 #include "sim_tables.h"
 
 namespace medt {
@@ -172,10 +172,10 @@ int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const
 // --------------------------------------------------------------------------- //
 // out[k] = sum_p in[p][k]      (deterministic: fixed order, no atomics)
 // --------------------------------------------------------------------------- //
-__global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_kernel(const float* __restrict__ in, int P, int K,
-                                                                   float* __restrict__ out) {
+__device__ __forceinline__ void reduce_rows_body(const float* __restrict__ in, int P, int K, float* __restrict__ out,
+                                                 int block) {
     __shared__ float red[4][64];
-    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int k = block * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
     float s = 0.f;
     if (k < K) {
@@ -193,6 +193,36 @@ __global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_kernel(const float* 
     red[slice][threadIdx.x & 63] = s;
     __syncthreads();
     if (slice == 0 && k < K) out[k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_kernel(const float* __restrict__ in, int P, int K,
+                                                                   float* __restrict__ out) {
+    reduce_rows_body(in, P, K, out, blockIdx.x);
+}
+
+// many reductions, one launch (defer.h)
+using RBatch = JobBatch<RJob, 144>;
+__global__ __launch_bounds__(MEDT_THREADS) void reduce_rows_grouped_kernel(RBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    reduce_rows_body(b.job[j].src, b.job[j].P, b.job[j].K, b.job[j].dst, blockIdx.x - b.start[j]);
+}
+
+int reduce_rows_grouped(const RJob* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 144) {
+        RBatch b;
+        b.n = n - i0 < 144 ? n - i0 : 144;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.job[i] = jobs[i0 + i];
+            b.start[i] = blocks;
+            blocks += cdiv(jobs[i0 + i].K, 64);
+        }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(reduce_rows_grouped_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        int rc = launch_status("reduce_rows_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
 }
 
 int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s) {
@@ -314,15 +344,6 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
 }
 
 // Three BatchNorms of one layer in one launch (the fused small-layer forward, axial_small.hip): block -> (BN, channel).
-struct BnFin {
-    const float* partials;
-    int ppg, CH;
-    double count;
-    const float *weight, *bias;
-    float *running_mean, *running_var;
-    int64_t* nbt;
-    BnStats out;
-};
 __global__ __launch_bounds__(64) void bn_finalize3_kernel(BnFin a, BnFin b, BnFin c, int groups, float momentum, float eps,
                                                           int training) {
     int ch = blockIdx.x;
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(64) void bn_finalize3_kernel(BnFin a, BnFin b, BnFi
                      f->nbt, momentum, eps, training, f->out);
 }
 
-static BnFin make_fin(const float* partials, int ppg, int CH, double count, const medt_bn_ptrs& bn, BnStats out) {
+BnFin make_fin(const float* partials, int ppg, int CH, double count, const medt_bn_ptrs& bn, BnStats out) {
     BnFin f;
     f.partials = partials; f.ppg = ppg; f.CH = CH; f.count = count;
     f.weight = bn.weight; f.bias = bn.bias; f.running_mean = bn.running_mean; f.running_var = bn.running_var;
@@ -378,12 +399,12 @@ __device__ __forceinline__ void bn_bwd_coef(double s1, double s2, double count, 
     }
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int ppg, int groups,
-                                                             int CH, double count, float dscale, BnStats st,
-                                                             const float* __restrict__ weight, int training,
-                                                             float* __restrict__ coef, float* __restrict__ dweight,
-                                                             float* __restrict__ dbias) {
-    const int ch = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void bn_bwd_finalize_body(int ch, const float* __restrict__ partials, int ppg, int groups,
+                                                     int CH, double count, float dscale, BnStats st,
+                                                     const float* __restrict__ weight, int training,
+                                                     float* __restrict__ coef, float* __restrict__ dweight,
+                                                     float* __restrict__ dbias) {
+    const int lane = threadIdx.x;
     double dg = 0.0, db = 0.0;
     double sums[2];
     const int which[2] = {0, 1};
@@ -419,6 +440,58 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
         if (dweight) dweight[ch] = (float)dg;
         if (dbias) dbias[ch] = (float)db;
     }
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int ppg, int groups,
+                                                             int CH, double count, float dscale, BnStats st,
+                                                             const float* __restrict__ weight, int training,
+                                                             float* __restrict__ coef, float* __restrict__ dweight,
+                                                             float* __restrict__ dbias) {
+    bn_bwd_finalize_body(blockIdx.x, partials, ppg, groups, CH, count, dscale, st, weight, training, coef, dweight, dbias);
+}
+
+using BfBatch = JobBatch<BfinJob, 32>;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_grouped_kernel(BfBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    const BfinJob& f = b.job[j];
+    bn_bwd_finalize_body(blockIdx.x - b.start[j], f.partials, f.ppg, f.groups, f.CH, f.count, f.dscale, f.st, f.weight,
+                         f.training, f.coef, f.dweight, f.dbias);
+}
+
+int bn_bwd_finalize_grouped(const BfinJob* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 32) {
+        BfBatch b;
+        b.n = n - i0 < 32 ? n - i0 : 32;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[i0 + i]; b.start[i] = blocks; blocks += jobs[i0 + i].CH; }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(bn_bwd_finalize_grouped_kernel, dim3(blocks), dim3(64), 0, s, b);
+        int rc = launch_status("bn_bwd_finalize_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
+}
+
+using FBatch = JobBatch<FinJob, 32>;
+__global__ __launch_bounds__(64) void bn_finalize_grouped_kernel(FBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    const FinJob& q = b.job[j];
+    bn_finalize_body(blockIdx.x - b.start[j], q.f.partials, q.f.ppg, q.groups, q.f.CH, q.f.count, q.f.weight, q.f.bias,
+                     q.f.running_mean, q.f.running_var, q.f.nbt, q.momentum, q.eps, q.training, q.f.out);
+}
+
+int bn_finalize_grouped(const FinJob* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 32) {
+        FBatch b;
+        b.n = n - i0 < 32 ? n - i0 : 32;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[i0 + i]; b.start[i] = blocks; blocks += jobs[i0 + i].f.CH; }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3(blocks), dim3(64), 0, s, b);
+        int rc = launch_status("bn_finalize_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
 }
 
 int bn_bwd_finalize(const float* partials, int ppg, int groups, int CH, double count, float dscale, BnStats st,

@@ -60,6 +60,11 @@ class AxialGrads(C.Structure):
 SIGNATURES = {
     "medt_abi_version": (C.c_int, []),
     "medt_last_error": (C.c_char_p, []),
+    "medt_queue_create": (C.c_void_p, []),
+    "medt_queue_destroy": (C.c_int, [C.c_void_p]),
+    "medt_queue_bind": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "medt_queue_pending": (C.c_size_t, [C.c_void_p]),
+    "medt_queue_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
     "medt_axial_stats_floats": (C.c_size_t, [C.POINTER(AxialDesc)]),
     "medt_axial_workspace_bytes": (C.c_size_t, [C.POINTER(AxialDesc)]),
     "medt_axial_layer_fwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.c_void_p, C.c_void_p,

@@ -14,6 +14,7 @@ import torch
 
 from . import _lib as L
 from . import optim as OPT
+from . import defer as DEFER
 
 
 ACT_BF16 = False
@@ -109,8 +110,11 @@ class AxialAttentionFn(torch.autograd.Function):
         y = torch.empty((N, Cc, H // cfg.stride, W // cfg.stride), device=dev, dtype=torch.float32)
         saved = L.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
         stream = torch.cuda.current_stream().cuda_stream
+        q = DEFER.recording()
         L.check(lib.medt_axial_layer_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
                                          ws.data_ptr(), ws_bytes, stream), "medt_axial_layer_fwd")
+        if q is not None:
+            q.hold(ws, stats)
         ctx.cfg, ctx.training, ctx.has_gates = cfg, training, gates is not None
         # gradient slots of the parameters (views into FlatAdam's flat bucket): backward writes them directly
         ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None
@@ -175,9 +179,15 @@ class AxialAttentionFn(torch.autograd.Function):
         ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         stream = torch.cuda.current_stream().cuda_stream
+        # parameter gradients may only be recorded for the grouped flush when they all land in persistent slots
+        q = DEFER.recording(allow=not pend and all(r is None for r in ret) and (not want_gates or gate_direct))
         L.check(lib.medt_axial_layer_bwd(C.byref(desc), C.byref(params), x.data_ptr(), L.ptr(y), dy.data_ptr(), C.byref(saved),
                                          dx.data_ptr(), C.byref(grads), ws.data_ptr(), ws_bytes, stream),
                 "medt_axial_layer_bwd")
+        if q is not None:                      # recorded weight-gradient / reduction jobs read these at the flush
+            q.hold(ws, x, qkv_raw, stats, *dst)
+            if tmp_sizes:
+                q.hold(*parts)
         for slot, tmp in pend:
             OPT.accumulate(slot, tmp)
         if want_gates and not gate_direct:

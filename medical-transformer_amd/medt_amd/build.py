@@ -15,8 +15,8 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # me
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmedt_hip.so")
-SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip", "conv.hip", "elementwise.hip", "axial_fast.hip", "conv_mfma.hip", "axial_small.hip", "conv_small.hip", "axial_stats.hip"]
-HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", "sim_tables.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
+SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip", "conv.hip", "elementwise.hip", "axial_fast.hip", "conv_mfma.hip", "axial_small.hip", "conv_small.hip", "axial_stats.hip", "defer.hip"]
+HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", "sim_tables.h", "defer.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
 
 
 def _stale() -> bool:

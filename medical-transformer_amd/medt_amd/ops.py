@@ -14,6 +14,7 @@ import torch
 
 from . import _lib as L
 from . import optim as OPT
+from . import defer as DEFER
 from .axial import _bn_ptrs, _momentum, _require_device
 
 
@@ -61,9 +62,12 @@ class ConvBlockFn(torch.autograd.Function):
             raise L.MedtError("conv block: " + lib.medt_last_error().decode())
         ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
         bnp = _bn_ptrs(cfg.bn, training) if has_bn else None
+        q = DEFER.recording() if has_bn else None
         L.check(lib.medt_conv_block_fwd(C.byref(desc), x.data_ptr(), w.data_ptr(), L.ptr(bias),
                                         C.byref(bnp) if has_bn else None, L.ptr(res), z.data_ptr(), y.data_ptr(),
                                         stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "medt_conv_block_fwd")
+        if q is not None:
+            q.hold(ws, stats)
         ctx.cfg, ctx.training, ctx.has_bias, ctx.has_res = cfg, training, bias is not None, res is not None
         # gradient slots of (w, bias, bn.weight, bn.bias) in FlatAdam's flat bucket: backward writes them directly
         ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None for t in (w, bias, bn_w, bn_b))
@@ -102,10 +106,14 @@ class ConvBlockFn(torch.autograd.Function):
         ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
         ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         bnp = _bn_ptrs(cfg.bn, False) if has_bn else None
+        # parameter gradients may only be recorded for the grouped flush when they all land in persistent slots
+        q = DEFER.recording(allow=not pend and all(r is None for r in ret))
         L.check(lib.medt_conv_block_bwd(C.byref(desc), x.data_ptr(), w.data_ptr(), C.byref(bnp) if has_bn else None,
                                         L.ptr(z), L.ptr(y), L.ptr(stats), dy.data_ptr(), L.ptr(dx), dst[0].data_ptr(),
                                         L.ptr(dst[1]), L.ptr(dst[2]), L.ptr(dst[3]), L.ptr(dres), ws.data_ptr(), ws_bytes,
                                         _stream()), "medt_conv_block_bwd")
+        if q is not None:                      # recorded weight / bias gradient jobs read these at the flush
+            q.hold(ws, x, dy, stats, dres, *dst)
         for slot, tmp in pend:
             OPT.accumulate(slot, tmp)
         return (dx, ret[0], ret[1], ret[2], ret[3], dres, None, None)

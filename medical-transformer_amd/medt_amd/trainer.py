@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .defer import StepQueue
 from .optim import FlatAdam
 from .ops import cross_entropy
 
@@ -37,15 +38,34 @@ class TrainStep:
         self.use_graph = use_graph
         self.warmup = warmup
         self._graphs = {}          # signature -> (graph, static_x, static_y, static_loss, single)
+        self._queue = None         # deferred, grouped launches (medt_amd.defer); created on first use (needs the GPU library)
         self._ce_out = None        # [loss, counted pixels, out-of-range targets] of the last step (medt cross_entropy)
 
     # ---- eager ------------------------------------------------------------
-    def _eager(self, x, y):
-        out = self.model(x)
-        loss = self.criterion(out, y)
-        self.opt.zero_grad()
-        loss.backward()
+    def _fwd_bwd(self, x, y):
+        """forward -> loss -> backward.  On the GPU the work no later layer waits for (weight / bias gradients and their
+        slab reductions, statistics bookkeeping of the fused small-layer kernels) is recorded and issued as grouped
+        launches at the end of each pass: before backward reads the saved statistics, before the optimizer reads the
+        gradients."""
+        if not x.is_cuda:
+            out = self.model(x)
+            loss = self.criterion(out, y)
+            self.opt.zero_grad()
+            loss.backward()
+        else:
+            if self._queue is None:
+                self._queue = StepQueue()
+            with self._queue.active() as q:
+                out = self.model(x)
+                loss = self.criterion(out, y)
+                q.flush()
+                self.opt.zero_grad()
+                loss.backward()
         self.opt.pack_gradients()
+        return loss
+
+    def _eager(self, x, y):
+        loss = self._fwd_bwd(x, y)
         self.opt.allreduce()
         self.opt.apply(_world())
         return loss
@@ -87,14 +107,10 @@ class TrainStep:
                 self._eager(static_x, static_y)
             self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
-        self.opt.zero_grad()
         graph = torch.cuda.CUDAGraph()
         single = not _distributed()
         with torch.cuda.graph(graph):
-            out = self.model(static_x)
-            loss = self.criterion(out, static_y)
-            loss.backward()
-            self.opt.pack_gradients()
+            loss = self._fwd_bwd(static_x, static_y)
             if single:
                 self.opt.apply(1)
         return graph, static_x, static_y, loss.detach(), single, getattr(loss, "_medt_ce_out", None)
