@@ -52,7 +52,8 @@ const char* medt_last_error(void);
  *   everything recorded as a few grouped launches -- call it after the forward pass (backward reads the saved
  *   statistics) and after the backward pass (the optimizer reads the gradients).  The caller must keep every buffer
  *   it passed to a recording call (inputs, outputs, saved tensors, workspace) alive and unmodified until the flush.
- *   Results are bit-identical to the immediate launches (same kernels bodies, same summation order).
+ *   Same kernel bodies as the immediate launches; results are identical except that weight gradients are summed over
+ *   differently sized position chunks (fp32 rounding, ~1e-7 relative).
  *   Without a bound queue every call launches immediately (the default).
  * ------------------------------------------------------------------------- */
 void*  medt_queue_create(void);

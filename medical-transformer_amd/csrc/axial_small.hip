@@ -11,7 +11,7 @@
 // The saved tensors (qkv_raw, stacked, lse, statistics) are exactly those of the layer-by-layer path, so the
 // backward entry point does not care which forward ran.
 #include "medt_common.h"
-#include "medt_kernels.h"
+#include "defer.h"
 #include <type_traits>
 
 namespace medt {
@@ -324,6 +324,9 @@ struct SmallBwdArgs {
     const float *w_out, *w_sim;                         // bn_output.weight (C), bn_similarity.weight (G)
     float *dqkv;                                        // (N, 2C, H, W)
     float *part_ob, *part_sb, *part_qb;                 // [groups][C][2], [groups][G][4], [groups][2C][2]
+    const float* w_qkv_bn;                              // bn_qkv.weight (2C)
+    float* coef_qkv;                                    // [groups][2C][3]: bn_qkv backward as dx = c0*d + c1*x + c2
+    double row_count;
     int N, C, H, W, G, npg, stride, training, out_relu;
 };
 
@@ -525,6 +528,19 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
         if (lane == 0) {
             a.part_qb[((size_t)grp * 2 * C + ch) * 2] = s1;
             a.part_qb[((size_t)grp * 2 * C + ch) * 2 + 1] = s2;
+            // bn_qkv's backward coefficients of this (group, channel) only need this workgroup's own sums: written here
+            // so the 1x1 dgrad behind does not wait for the finalisation launch (which is left with parameter gradients)
+            const double A = (double)a.w_qkv_bn[ch] * (double)rstd;
+            float* cf = a.coef_qkv + ((size_t)grp * 2 * C + ch) * 3;
+            cf[0] = (float)A;
+            if (a.training) {
+                const double m1 = (double)s1 / a.row_count, m2 = (double)s2 / a.row_count;
+                cf[1] = (float)(-A * (double)rstd * m2);
+                cf[2] = (float)(A * ((double)rstd * (double)mean * m2 - m1));
+            } else {
+                cf[1] = 0.f;
+                cf[2] = 0.f;
+            }
         }
     }
 }
@@ -540,8 +556,10 @@ bool wopos_small_bwd_ok(const AxialGeom& g, const medt_axial_desc& d) {
 
 int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* y,
                     const float* dy, const float* qkv_raw, const float* stacked, const float* lse, BnStats sq, BnStats ss,
-                    BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, hipStream_t s) {
+                    BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, float* coef_qkv,
+                    hipStream_t s) {
     SmallBwdArgs a;
+    a.w_qkv_bn = p.bn_qkv.weight; a.coef_qkv = coef_qkv; a.row_count = g.row_count;
     a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.y = y;
     a.sq = sq; a.ss = ss; a.so = so;
     a.w_out = p.bn_output.weight; a.w_sim = p.bn_similarity.weight;
@@ -574,26 +592,14 @@ int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axi
 // Parameter gradients of the three BatchNorms (sum over the BN groups of the per-group partials written by the kernel
 // above) and bn_qkv's backward coefficients for the conv kernels, in one launch: block -> (BN, channel), lane -> group.
 // Same formulas as bn_bwd_finalize_kernel (pointwise.hip) and sim_bwd_finalize_kernel (axial_core.hip).
-struct SmallFinArgs {
-    const float *part_ob, *part_sb, *part_qb;
-    BnStats so, ss, sq;
-    const float* w_qkv_bn;              // bn_qkv.weight (2C)
-    float *coef_qkv;                    // [groups][2C][3]
-    float *d_out_w, *d_out_b, *d_sim_w, *d_sim_b, *d_qkv_w, *d_qkv_b;
-    int C, G, groups, training;
-    double row_count, sim_count;
-    float dscale_out;
-};
-
 __device__ __forceinline__ double small_wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-__global__ __launch_bounds__(64) void wopos_small_bwd_finalize_kernel(SmallFinArgs a) {
+__device__ __forceinline__ void wopos_small_bwd_finalize_body(const SmallFinArgs& a, int ch) {
     const int lane = threadIdx.x, C = a.C, G = a.G;
-    int ch = blockIdx.x;
     double dg = 0.0, db = 0.0;
     if (ch < C) {                                               // bn_output
         for (int grp = lane; grp < a.groups; grp += 64) {
@@ -620,44 +626,56 @@ __global__ __launch_bounds__(64) void wopos_small_bwd_finalize_kernel(SmallFinAr
         if (lane == 0) { a.d_sim_w[ch] = (float)dg; a.d_sim_b[ch] = (float)db; }
         return;
     }
-    ch -= G;                                                    // bn_qkv: coefficients dx = c0*d + c1*x + c2 as well
+    ch -= G;                                                    // bn_qkv (its coefficients come from the backward kernel)
     const int CH = 2 * C;
     for (int grp = lane; grp < a.groups; grp += 64) {
         const float* q = a.part_qb + ((size_t)grp * CH + ch) * 2;
-        const double s1 = q[0], s2 = q[1];
-        const double mean = a.sq.mean[grp * CH + ch], rstd = a.sq.rstd[grp * CH + ch], A = (double)a.w_qkv_bn[ch] * rstd;
-        float* cf = a.coef_qkv + ((size_t)grp * CH + ch) * 3;
-        cf[0] = (float)A;
-        if (a.training) {
-            const double m1 = s1 / a.row_count, m2 = s2 / a.row_count;
-            cf[1] = (float)(-A * rstd * m2);
-            cf[2] = (float)(A * (rstd * mean * m2 - m1));
-        } else {
-            cf[1] = 0.f;
-            cf[2] = 0.f;
-        }
-        dg += s2;
-        db += s1;
+        dg += (double)q[1];
+        db += (double)q[0];
     }
     dg = small_wave_sum_d(dg);
     db = small_wave_sum_d(db);
     if (lane == 0) { a.d_qkv_w[ch] = (float)dg; a.d_qkv_b[ch] = (float)db; }
 }
 
+__global__ __launch_bounds__(64) void wopos_small_bwd_finalize_kernel(SmallFinArgs a) {
+    wopos_small_bwd_finalize_body(a, blockIdx.x);
+}
+
+using SfBatch = JobBatch<SmallFinArgs, 16>;
+__global__ __launch_bounds__(64) void wopos_small_bwd_finalize_grouped_kernel(SfBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    wopos_small_bwd_finalize_body(b.job[j], blockIdx.x - b.start[j]);
+}
+
+int wopos_small_bwd_finalize_grouped(const SmallFinArgs* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        SfBatch b;
+        b.n = n - i0 < 16 ? n - i0 : 16;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[i0 + i]; b.start[i] = blocks; blocks += 3 * jobs[i0 + i].C + jobs[i0 + i].G; }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(wopos_small_bwd_finalize_grouped_kernel, dim3(blocks), dim3(64), 0, s, b);
+        int rc = launch_status("wopos_small_bwd_finalize_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
+}
+
+// BatchNorm parameter gradients of the layer (sums over the groups); recorded into `q` when given
 int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p,
                              const float* part_ob, const float* part_sb, const float* part_qb, BnStats sq, BnStats ss,
-                             BnStats so, float* coef_qkv, const medt_axial_grads& gr, hipStream_t s) {
+                             BnStats so, const medt_axial_grads& gr, hipStream_t s, Queue* q) {
     SmallFinArgs a;
     a.part_ob = part_ob; a.part_sb = part_sb; a.part_qb = part_qb;
     a.so = so; a.ss = ss; a.sq = sq;
-    a.w_qkv_bn = p.bn_qkv.weight;
-    a.coef_qkv = coef_qkv;
     a.d_out_w = gr.bn_out_weight; a.d_out_b = gr.bn_out_bias;
     a.d_sim_w = gr.bn_sim_weight; a.d_sim_b = gr.bn_sim_bias;
     a.d_qkv_w = gr.bn_qkv_weight; a.d_qkv_b = gr.bn_qkv_bias;
     a.C = g.C; a.G = g.G; a.groups = g.groups; a.training = d.training ? 1 : 0;
     a.row_count = g.row_count; a.sim_count = g.sim_count;
     a.dscale_out = 1.f / (float)(d.stride * d.stride);
+    if (q) { q->sfin.push_back(a); return MEDT_OK; }
     hipLaunchKernelGGL(wopos_small_bwd_finalize_kernel, dim3(g.C + g.G + 2 * g.C), dim3(64), 0, s, a);
     return launch_status("wopos_small_bwd_finalize");
 }

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
 #pragma unroll
     for (int o = 0; o < OT; ++o) acc[o] = bias ? bias[o0 + o] : 0.f;
     const float* xn = x + (size_t)n * Cin * H * W;
-#pragma unroll K == 1 ? 4 : 1
+#pragma unroll K == 1 ? 4 : (K == 3 ? 2 : 1)
     for (int c = 0; c < Cin; ++c) {
         float xv[KK];
 #pragma unroll
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
     const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
-#pragma unroll K == 1 ? 4 : 1
+#pragma unroll K == 1 ? 4 : (K == 3 ? 4 : 1)
     for (int o = 0; o < Cout; ++o) {
         float dv[KK];
 #pragma unroll
@@ -335,14 +335,16 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
 }
 
 // The weight gradients of many layers in one launch (defer.h): every job has this kernel's (K, TO, TC).
-using WBatch = JobBatch<WJob, 32>;
-template <int K, int TO, int TC>
+// One tile shape (64 x 64) for every job: the launch holds thousands of workgroups across all layers, so per-layer tile
+// sizing (which exists to give ONE layer enough workgroups) is not needed and the launch count drops to one per kernel size.
+using WBatch = JobBatch<WJob, 36>;
+template <int K>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_grouped_kernel(WBatch b) {
     const int j = find_job(b, blockIdx.x);
     const WJob& w = b.job[j];
     const int local = blockIdx.x - b.start[j];
     const int bx = local % w.gx, t = local / w.gx, by = t % w.gy, bz = t / w.gy;
-    conv_wgrad_body<K, TO, TC>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride,
+    conv_wgrad_body<K, 64, 64>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride,
                                w.pad, w.QS, w.npg, bx, by, bz);
 }
 
@@ -357,10 +359,19 @@ static int wgrad_chunk(int Cout, int Ktot, long NP) {
     return QS;
 }
 
-int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo) {
+// recorded (grouped) launches: ~32 position chunks per job, at most 64 partial slabs
+static int wgrad_chunk_grouped(long NP) {
+    int QS = 64;
+    while (QS < 512 && (NP + QS - 1) / QS > 32) QS <<= 1;
+    while ((NP + QS - 1) / QS > 64) QS <<= 1;
+    return QS;
+}
+
+int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo) {      // slabs of scratch: either mode
     const long NP = (long)N * Ho * Wo;
-    const int QS = wgrad_chunk(Cout, Cin * K * K, NP);
-    return (int)((NP + QS - 1) / QS);
+    const int QS = wgrad_chunk(Cout, Cin * K * K, NP), QG = wgrad_chunk_grouped(NP);
+    const int a = (int)((NP + QS - 1) / QS), b = (int)((NP + QG - 1) / QG);
+    return a > b ? a : b;
 }
 
 int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
@@ -368,11 +379,13 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
                       Queue* q) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     const long NP = (long)N * Ho * Wo;
-    const int Ktot = Cin * K * K, QS = wgrad_chunk(Cout, Ktot, NP);
+    const int Ktot = Cin * K * K;
+    const bool mfma = conv_use_mfma(Cin, Cout, K, stride, NP) && Cout >= 64;
+    const int QS = (q && !mfma) ? wgrad_chunk_grouped(NP) : wgrad_chunk(Cout, Ktot, NP);
     const int splits = (int)((NP + QS - 1) / QS);
     const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
     if (splits == 1) scratch = dw;                         // a single slab is the result: no reduction pass
-    if (conv_use_mfma(Cin, Cout, K, stride, NP) && Cout >= 64) {
+    if (mfma) {
         int rc = conv_wgrad_mfma(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits,
                                  N / groups, s);
         if (rc) return rc;
@@ -382,9 +395,8 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     }
     if (q) {                                               // deferred: grouped with the other layers' at the flush
         if (K != 1 && K != 3 && K != 7) { set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K); return MEDT_EUNSUPPORTED; }
-        const int TO = wgrad_tile(Cout), TC = wgrad_tile(Ktot);
         q->wgrad.push_back(WJob{dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups,
-                                cdiv(Cout, TO), cdiv(Ktot, TC), splits, K, TO, TC});
+                                cdiv(Cout, 64), cdiv(Ktot, 64), splits, K});
         if (splits > 1) q->reduce.push_back(RJob{scratch, dw, splits, Cout * Ktot});
         return MEDT_OK;
     }
@@ -433,38 +445,27 @@ __global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* 
     channel_sum_body(x, part, N, C, HW, blockIdx.x, blockIdx.y);
 }
 
-int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
-    std::vector<char> done(n, 0);
-    for (int i = 0; i < n; ++i) {
-        if (done[i]) continue;
-        const int K = jobs[i].K, TO = jobs[i].TO, TC = jobs[i].TC;
+int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s) {
+    static const int KS[3] = {1, 3, 7};
+    for (int K : KS) {
         WBatch b;
         b.n = 0;
         int blocks = 0;
         auto launch = [&]() -> int {
             b.start[b.n] = blocks;
-#define MEDT_WGG(KV, TOV, TCV) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<KV, TOV, TCV>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b)
-#define MEDT_WGG_TC(KV, TOV) do { if (TC == 16) MEDT_WGG(KV, TOV, 16); else if (TC == 32) MEDT_WGG(KV, TOV, 32); else MEDT_WGG(KV, TOV, 64); } while (0)
-#define MEDT_WGG_TO(KV) do { if (TO == 16) MEDT_WGG_TC(KV, 16); else if (TO == 32) MEDT_WGG_TC(KV, 32); else MEDT_WGG_TC(KV, 64); } while (0)
-            switch (K) {
-                case 1: MEDT_WGG_TO(1); break;
-                case 3: MEDT_WGG_TO(3); break;
-                default: MEDT_WGG_TO(7); break;
-            }
-#undef MEDT_WGG_TO
-#undef MEDT_WGG_TC
-#undef MEDT_WGG
+            if (K == 1) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<1>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+            else if (K == 3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<3>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+            else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<7>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
             b.n = 0;
             blocks = 0;
-            return launch_status("conv_wgrad_grouped");
+            return launch_status("conv_wgrad_grouped_valu");
         };
-        for (int j = i; j < n; ++j) {
-            if (done[j] || jobs[j].K != K || jobs[j].TO != TO || jobs[j].TC != TC) continue;
-            done[j] = 1;
+        for (int j = 0; j < n; ++j) {
+            if (jobs[j].K != K) continue;
             b.job[b.n] = jobs[j];
             b.start[b.n] = blocks;
             blocks += jobs[j].gx * jobs[j].gy * jobs[j].gz;
-            if (++b.n == 32) { int rc = launch(); if (rc) return rc; }
+            if (++b.n == 36) { int rc = launch(); if (rc) return rc; }
         }
         if (b.n) { int rc = launch(); if (rc) return rc; }
     }

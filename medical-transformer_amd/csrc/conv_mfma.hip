@@ -12,7 +12,8 @@
 // B[16][64] gathered from NCHW with the column's (n,ho,wo) decoded once per lane.
 // MFMA fragment maps (cdna_hip_programming.md section 3): A: lane l = A[l&15][l>>4]; B: lane l = B[l>>4][l&15];
 // D: reg r of lane l = D[(l>>4)*4 + r][l&15].
-#include "medt_kernels.h"
+#include "defer.h"
+#include <stdlib.h>
 
 namespace medt {
 
@@ -237,17 +238,17 @@ int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, fl
 // weight gradient on the matrix cores (same tiling as conv_wgrad_kernel in conv.hip)
 // --------------------------------------------------------------------------- //
 template <int K>
-__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
+__device__ __forceinline__ void conv_wgrad_mfma_body(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
-    int stride, int pad, int QS, int npg) {
+    int stride, int pad, int QS, int npg, int bx, int by, int bz) {
     constexpr int KK = K * K;
     __shared__ float A[64][65];
     __shared__ float B[64][65];
     const int Ktot = Cin * KK, HoWo = Ho * Wo;
-    const int o0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int o0 = bx * 64, k0 = by * 64;
     const long NP = (long)N * HoWo;
-    const long q_begin = (long)blockIdx.z * QS;
+    const long q_begin = (long)bz * QS;
     const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane, r0 = wv;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
         }
         __syncthreads();
     }
-    float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
+    float* out = scratch + (size_t)bz * Cout * Ktot;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -312,6 +313,59 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
             const int o = o0 + 16 * wv + (lane >> 4) * 4 + r, k = k0 + t * 16 + (lane & 15);
             if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[t][r];
         }
+}
+
+template <int K>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+    int stride, int pad, int QS, int npg) {
+    conv_wgrad_mfma_body<K>(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, blockIdx.x,
+                            blockIdx.y, blockIdx.z);
+}
+
+// The recorded weight gradients of many layers in one launch per kernel size (defer.h): 64 x 64 tiles on the matrix
+// cores for every layer -- a launch holds thousands of workgroups across the layers, so the per-layer tile sizing of the
+// immediate VALU kernel (which exists to give ONE layer enough workgroups) is not needed, and per FMA the MFMA tile
+// reads 16x fewer LDS bytes than the 4x4 register tile (profiles/r02_wgrad_ab.json).
+using WBatch = JobBatch<WJob, 36>;
+template <int K>
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(WBatch b) {
+    const int j = find_job(b, blockIdx.x);
+    const WJob& w = b.job[j];
+    const int local = blockIdx.x - b.start[j];
+    const int bx = local % w.gx, t = local / w.gx, by = t % w.gy, bz = t / w.gy;
+    conv_wgrad_mfma_body<K>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride,
+                            w.pad, w.QS, w.npg, bx, by, bz);
+}
+
+int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
+    static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
+    if (valu) return conv_wgrad_grouped_valu(jobs, n, s);            // A/B switch: the 4x4-register-tile VALU body
+    static const int KS[3] = {1, 3, 7};
+    for (int K : KS) {
+        WBatch b;
+        b.n = 0;
+        int blocks = 0;
+        auto launch = [&]() -> int {
+            b.start[b.n] = blocks;
+            if (K == 1) hipLaunchKernelGGL((conv_wgrad_mfma_grouped_kernel<1>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+            else if (K == 3) hipLaunchKernelGGL((conv_wgrad_mfma_grouped_kernel<3>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+            else hipLaunchKernelGGL((conv_wgrad_mfma_grouped_kernel<7>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+            b.n = 0;
+            blocks = 0;
+            return launch_status("conv_wgrad_mfma_grouped");
+        };
+        for (int j = 0; j < n; ++j) {
+            if (jobs[j].K != K) continue;
+            b.job[b.n] = jobs[j];
+            b.start[b.n] = blocks;
+            blocks += jobs[j].gx * jobs[j].gy * jobs[j].gz;
+            if (++b.n == 36) { int rc = launch(); if (rc) return rc; }
+        }
+        if (b.n) { int rc = launch(); if (rc) return rc; }
+    }
+    return MEDT_OK;
 }
 
 int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const float* x, float* scratch, int N, int Cin,

@@ -34,21 +34,30 @@ struct BfinJob {                     // bn_bwd_finalize
     const float* weight;
     float *coef, *dweight, *dbias;
 };
+struct SmallFinArgs {                // wopos_small_bwd_finalize: BatchNorm parameter gradients of a fused small layer
+    const float *part_ob, *part_sb, *part_qb;
+    BnStats so, ss, sq;
+    float *d_out_w, *d_out_b, *d_sim_w, *d_sim_b, *d_qkv_w, *d_qkv_b;
+    int C, G, groups, training;
+    double row_count, sim_count;
+    float dscale_out;
+};
 struct RJob { const float* src; float* dst; int P, K; };                         // reduce_rows
 struct CJob { const float* x; float* part; int N, C, HW; };                      // channel_sum, first stage
-struct WJob {                        // conv_wgrad_kernel<K, TO, TC> over a (gx, gy, gz) grid
+struct WJob {                        // conv_wgrad_body<K, 64, 64> over a (gx, gy, gz) grid of (o-tile, k-tile, position chunk)
     const float *dy, *raw, *coef, *x;
     float* scratch;
-    int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K, TO, TC;
+    int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K;
 };
 
 struct Queue {
     std::vector<FinJob> fin;
     std::vector<BfinJob> bfin;
+    std::vector<SmallFinArgs> sfin;
     std::vector<CJob> csum;
     std::vector<WJob> wgrad;
     std::vector<RJob> reduce;
-    size_t pending() const { return fin.size() + bfin.size() + csum.size() + wgrad.size() + reduce.size(); }
+    size_t pending() const { return fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + reduce.size(); }
 };
 
 Queue* queue_for(hipStream_t s);     // the queue bound to this stream, or nullptr (immediate launches)
@@ -58,9 +67,11 @@ BnFin make_fin(const float* partials, int ppg, int CH, double count, const medt_
 // grouped launchers (each may issue several launches when the job table exceeds one kernel-argument block)
 int bn_finalize_grouped(const FinJob* jobs, int n, hipStream_t s);
 int bn_bwd_finalize_grouped(const BfinJob* jobs, int n, hipStream_t s);
+int wopos_small_bwd_finalize_grouped(const SmallFinArgs* jobs, int n, hipStream_t s);
 int reduce_rows_grouped(const RJob* jobs, int n, hipStream_t s);
 int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s);
-int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);
+int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);            // MFMA tiles (conv_mfma.hip)
+int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s);       // VALU tiles (conv.hip), MEDT_WGRAD_VALU=1
 
 // Job table passed by value in the kernel arguments (< 4 KB): block b belongs to job j with start[j] <= b < start[j+1].
 template <class J, int MAXJ>

@@ -242,9 +242,9 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         // one finalisation launch then sums the per-group partials into the BatchNorm parameter gradients and writes
         // bn_qkv's backward coefficients for the conv kernels
         if ((rc = wopos_small_bwd(g, *d, *p, y, dy, qkv_raw, stacked, sv->lse, st.qkv, st.sim, st.out, w.dqkv,
-                                  w.part_ob, w.part_sb, w.part_qb, s))) return rc;
-        if ((rc = wopos_small_bwd_finalize(g, *d, *p, w.part_ob, w.part_sb, w.part_qb, st.qkv, st.sim, st.out, w.coef_qkv,
-                                           *gr, s))) return rc;
+                                  w.part_ob, w.part_sb, w.part_qb, w.coef_qkv, s))) return rc;
+        if ((rc = wopos_small_bwd_finalize(g, *d, *p, w.part_ob, w.part_sb, w.part_qb, st.qkv, st.sim, st.out, *gr, s,
+                                           queue_for(s)))) return rc;
         if ((rc = conv1x1_bwd_data(w.dqkv, qkv_raw, w.coef_qkv, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
             return rc;
         return conv2d_bwd_weight(w.dqkv, qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C,

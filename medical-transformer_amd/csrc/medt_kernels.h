@@ -4,6 +4,8 @@
 
 namespace medt {
 
+struct Queue;         // defer.h: recorded (deferred, grouped) launches
+
 // ---- pointwise.hip ----------------------------------------------------------
 // 1x1 convolution on NCHW:  y[n,o,p] = sum_c w[o,c] * x[n,c,p].
 // partials (optional): per-(n, pixel-tile) [sum, sum of squares] of every output channel,
@@ -58,7 +60,7 @@ size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, in
 // dw[o,c,kh,kw] = sum_{n,ho,wo} val * x[...], val = coef ? c0*dy + c1*raw + c2 : dy (coef [group][Cout][3]);
 // scratch: conv2d_bwd_weight_splits() * Cout*Cin*K*K floats
 int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo);
-struct Queue;      // defer.h: when given, the launch (and the reduction of its partial slabs) is recorded, not issued
+// defer.h: when given, the launch (and the reduction of its partial slabs) is recorded, not issued
 int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
                       int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s,
                       Queue* q = nullptr);
@@ -151,10 +153,11 @@ int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axi
 bool wopos_small_bwd_ok(const AxialGeom& g, const medt_axial_desc& d);
 int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* y,
                     const float* dy, const float* qkv_raw, const float* stacked, const float* lse, BnStats sq, BnStats ss,
-                    BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, hipStream_t s);
+                    BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, float* coef_qkv,
+                    hipStream_t s);
 int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p,
                              const float* part_ob, const float* part_sb, const float* part_qb, BnStats sq, BnStats ss,
-                             BnStats so, float* coef_qkv, const medt_axial_grads& gr, hipStream_t s);
+                             BnStats so, const medt_axial_grads& gr, hipStream_t s, Queue* q);
 bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernels (A/B checks)
 
 // axial_stats.hip: bn_similarity batch statistics in closed form (one read of q and k, no L x L pass).

@@ -223,7 +223,8 @@ def test_graphed_train_step_equals_eager(device):
 def test_deferred_grouped_launches_match_immediate(device):
     """medt_queue_*: recording the off-chain work (weight / bias gradients, slab reductions, statistics bookkeeping of the
     fused small-layer kernels) and issuing it as grouped launches gives the same numbers as the immediate launches --
-    same kernel bodies, same summation order -- for every gradient, running statistic and counter.  (Gradients are only
+    same kernel bodies; the weight gradients are chunked differently, so they agree to fp32 rounding -- for every gradient,
+    running statistic and counter.  (Gradients are only
     recorded when they land in FlatAdam's persistent slots, so both runs go through an adopted optimizer.)"""
     import medt_amd
     from medt_amd.defer import StepQueue
@@ -262,10 +263,10 @@ def test_deferred_grouped_launches_match_immediate(device):
     assert l0 == l1
     assert g0.keys() == g1.keys() and len(g0) > 200
     for k in g0:
-        if k.endswith("relative"):                          # LDS float atomics: summation order varies run to run
-            assert H.rel_err(g1[k], g0[k]) < 1e-5, k
+        if k.endswith("relative") or (g0[k].dim() > 1):     # LDS float atomics (run-to-run order) / the grouped weight-gradient
+            assert H.rel_err(g1[k], g0[k]) < 1e-5, k        # launch chunks the positions differently (fp32 summation order)
         else:
-            assert torch.equal(g0[k], g1[k]), k
+            assert torch.equal(g0[k], g1[k]), k              # BatchNorm / bias / gate gradients: same kernel bodies
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
 
