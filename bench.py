@@ -93,6 +93,20 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
                                                             ws.data_ptr(), ws_bytes, stream), "core_fwd"))
     t_stats = timed(lambda: ML.check(lib.medt_axial_core_stats(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
                                                                ws.data_ptr(), ws_bytes, stream), "core_stats"))
+    # backward core (10*C*e*M over its two passes): one full layer backward fills the workspace
+    # coefficients, then the two L x L passes are timed on their own
+    dy = torch.randn((N, C, H, W), generator=g).to(device)
+    dx = torch.empty_like(x)
+    gsz = [2 * C * C, 2 * C, 2 * C, 24, 24, 2 * C, 2 * C, layer.relative.numel(), 4]
+    gflat = torch.empty((sum(gsz),), device=device)
+    gparts = list(torch.split(gflat, gsz))
+    grads = ML.AxialGrads(*[t.data_ptr() for t in gparts[:8]], None)
+    ML.check(lib.medt_axial_layer_bwd(ctypes.byref(desc), ctypes.byref(params), x.data_ptr(), None, dy.data_ptr(),
+                                      ctypes.byref(saved), dx.data_ptr(), ctypes.byref(grads), ws.data_ptr(), ws_bytes,
+                                      stream), "layer_bwd")
+    torch.cuda.synchronize()
+    t_bwd = timed(lambda: ML.check(lib.medt_axial_core_bwd(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
+                                                           dy.data_ptr(), ws.data_ptr(), ws_bytes, stream), "core_bwd"))
     M = N * H * W
     bytes_main = 4 * C * e * M
     bytes_stats = C * e * M
@@ -107,7 +121,10 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "launch_ms": t_main * 1e3, "valu_tflops": flops_main / t_main / 1e12,
             "stats_kernel": {"achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
-                             "bytes_per_launch": bytes_stats}}
+                             "bytes_per_launch": bytes_stats, "frac": bytes_stats / t_stats / 1e9 / HBM_PEAK_GBPS},
+            "bwd_core": {"kernels": "attn_bwd_stats_kernel + attn_bwd_kernel", "bytes_per_launch": 10 * C * e * M,
+                         "achieved": 10 * C * e * M / t_bwd / 1e9, "frac": 10 * C * e * M / t_bwd / 1e9 / HBM_PEAK_GBPS,
+                         "launch_ms": t_bwd * 1e3}}
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tf) and (C, L) == (16, 64) and e == 4:
         try:

@@ -152,6 +152,11 @@ int medt_axial_core_stats(const medt_axial_desc*, const medt_axial_params*, cons
                           void* workspace, size_t workspace_bytes, void* stream);
 int medt_axial_core_fwd(const medt_axial_desc*, const medt_axial_params*, const medt_axial_saved*,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The two L x L backward passes (bn_similarity backward statistics; dq/dk/dv + relative-table and gate gradients) on
+ * their own, for benchmarks: call medt_axial_layer_bwd once with the same descriptor and workspace first (it leaves the
+ * bn_output / bn_similarity backward coefficients these passes read in the workspace).  Same kernels as the layer call. */
+int medt_axial_core_bwd(const medt_axial_desc*, const medt_axial_params*, const medt_axial_saved*, const float* dy,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Convolution block:  y = act( BN( conv2d(x, w) + bias ) + res )
@@ -177,11 +182,14 @@ size_t medt_conv_workspace_bytes(const medt_conv_desc*);   /* max over fwd and b
 int medt_conv_block_fwd(const medt_conv_desc*, const float* x, const float* w, const float* bias,
                         const medt_bn_ptrs* bn, const float* res, float* z, float* y, float* stats,
                         void* workspace, size_t workspace_bytes, void* stream);
-/* dx, dbias, dres may be NULL (not needed).  dw, dbn_weight, dbn_bias are written, not accumulated. */
+/* dx, dbias, dres may be NULL (not needed).  dw, dbn_weight, dbn_bias are written, not accumulated.
+ * dx_add (optional, same shape as dx): dx = conv-backward + dx_add.  The input of an AxialBlock feeds conv_down AND the
+ * residual / downsample path (axialnet.py:327,339-340) and the decoder skips (:494-500); the reference's autograd sums
+ * those gradients with separate add kernels, here the last producer adds the others in its epilogue. */
 int medt_conv_block_bwd(const medt_conv_desc*, const float* x, const float* w, const medt_bn_ptrs* bn,
                         const float* z, const float* y, const float* stats, const float* dy,
                         float* dx, float* dw, float* dbias, float* dbn_weight, float* dbn_bias, float* dres,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        const float* dx_add, void* workspace, size_t workspace_bytes, void* stream);
 
 /* y = relu(bilinear_x2(x)) + skip       F.interpolate(scale_factor=(2,2), mode='bilinear') + relu + torch.add
  * (lib/models/axialnet.py:493-501, 650-652, 690-698).  x (NC,H,W) -> y (NC,2H,2W); skip may be NULL.

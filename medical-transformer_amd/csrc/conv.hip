@@ -140,7 +140,7 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
 template <int K, int CT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int H, int W,
-    int Cout, int Ho, int Wo, int stride, int pad) {
+    int Cout, int Ho, int Wo, int stride, int pad, const float* __restrict__ add) {
     constexpr int KK = K * K;
     const int HW = H * W;
     const long q = (long)blockIdx.x * MEDT_THREADS + threadIdx.x;
@@ -178,19 +178,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
         }
     }
     if (ok) {
-        float* dp = dx + ((size_t)n * Cin + c0) * HW + p;
+        const size_t o0 = ((size_t)n * Cin + c0) * HW + p;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) dp[(size_t)c * HW] = acc[c];
+        for (int c = 0; c < CT; ++c) dx[o0 + (size_t)c * HW] = add ? acc[c] + add[o0 + (size_t)c * HW] : acc[c];
     }
 }
 
 template <int K>
 static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int Ho,
-                             int Wo, int stride, int pad, hipStream_t s) {
+                             int Wo, int stride, int pad, hipStream_t s, const float* add) {
     const unsigned gx = (unsigned)(((long)N * H * W + MEDT_THREADS - 1) / MEDT_THREADS);
 #define MEDT_LAUNCH_BWD(CT)                                                                                       \
     hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CT>), dim3(gx, Cin / CT), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin, \
-                       H, W, Cout, Ho, Wo, stride, pad)
+                       H, W, Cout, Ho, Wo, stride, pad, add)
     switch (pick_tile(Cin, K == 7 ? 4 : 16, gx)) {
         case 16: if constexpr (K != 7) { MEDT_LAUNCH_BWD(16); } break;
         case 8: if constexpr (K != 7) { MEDT_LAUNCH_BWD(8); } break;
@@ -203,16 +203,16 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
 }
 
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
-                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s) {
+                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K
-    if (wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) &&
+    // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K   (the `add` epilogue is VALU-path only)
+    if (!add && wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) &&
         (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K) == 0))
         return conv_mfma_bwd_data_s1(dy, w, wt_scratch, ksplit_scratch, dx, N, Cin, H, W, Cout, K, pad, s);
     switch (K) {
-        case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
-        case 3: return conv2d_bwd_data_k<3>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
-        case 7: return conv2d_bwd_data_k<7>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s);
+        case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s, add);
+        case 3: return conv2d_bwd_data_k<3>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s, add);
+        case 7: return conv2d_bwd_data_k<7>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s, add);
     }
     set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K);
     return MEDT_EUNSUPPORTED;

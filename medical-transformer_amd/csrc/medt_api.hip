@@ -158,6 +158,30 @@ int medt_axial_core_fwd(const medt_axial_desc* d, const medt_axial_params* p, co
                           d->training ? w.part_out : nullptr, w.flag, (hipStream_t)stream);
 }
 
+int medt_axial_core_bwd(const medt_axial_desc* d, const medt_axial_params* p, const medt_axial_saved* sv, const float* dy,
+                        void* ws, size_t ws_bytes, void* stream) {
+    AxialGeom g;
+    int rc = check_common(d, p, sv, &g);
+    if (rc) return rc;
+    float* qkv_raw = (float*)sv->qkv_raw;
+    float* stacked = (float*)sv->stacked;
+    if (!dy || !sv->lse) { set_error("core_bwd: null dy / lse"); return MEDT_EINVAL; }
+    if (d->out_relu) { set_error("core_bwd: out_relu layers are not supported by the benchmark entry"); return MEDT_EUNSUPPORTED; }
+    Carver c(ws, ws_bytes);
+    BwdWs w(c, g, d->stride, d->out_relu);
+    if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    LayerStats st(sv->stats, g);
+    GatePtrs gates;
+    if ((rc = effective_gates(d, p, w.gate_eff, s, &gates))) return rc;
+    // pass A (bn_similarity backward statistics) and pass B (dq, dk, dv, table / gate gradients): the two L x L passes;
+    // coef_out / coef_sim are whatever the preceding medt_axial_layer_bwd left in the workspace
+    if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse, dy, w.coef_out,
+                                   d->stride, w.part_sb, s))) return rc;
+    return axial_attn_bwd(g, qkv_raw, st.qkv, st.sim, w.coef_sim, p->relative, gates, stacked, sv->lse, dy, w.coef_out,
+                          d->stride, w.dqkv, w.part_qb, w.rel_part, p->f_qr ? w.gate_part : nullptr, s);
+}
+
 int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, float* y,
                          const medt_axial_saved* sv, void* ws, size_t ws_bytes, void* stream) {
     AxialGeom g;
@@ -401,7 +425,8 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
 
 int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w, const medt_bn_ptrs* bn, const float* z,
                         const float* y, const float* stats, const float* dy, float* dx, float* dw, float* dbias,
-                        float* dbn_weight, float* dbn_bias, float* dres, void* ws, size_t ws_bytes, void* stream) {
+                        float* dbn_weight, float* dbn_bias, float* dres, const float* dx_add, void* ws, size_t ws_bytes,
+                        void* stream) {
     ConvGeom g;
     int rc = conv_geom(d, &g);
     if (rc) return rc;
@@ -441,7 +466,8 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     } else {
         grad_out = dy;
     }
-    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s))) return rc;
+    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s,
+                                    dx_add))) return rc;
     Queue* q = queue_for(s);          // parameter gradients: recorded for the grouped flush when a queue is bound
     if (d->has_bias) {
         if (q) {

@@ -54,8 +54,9 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
                int y_bf16 = 0);
 size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // wt_scratch: Cout*Cin*K*K floats (used by the MFMA path for the flipped weights; may be NULL -> VALU path)
+// add (optional): dx = dgrad + add -- the other gradient contributions of a fanned-out input, summed in the epilogue
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
-                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s);
+                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add = nullptr);
 size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // dw[o,c,kh,kw] = sum_{n,ho,wo} val * x[...], val = coef ? c0*dy + c1*raw + c2 : dy (coef [group][Cout][3]);
 // scratch: conv2d_bwd_weight_splits() * Cout*Cin*K*K floats

@@ -76,13 +76,15 @@ SIGNATURES = {
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_axial_core_fwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved),
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_axial_core_bwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved), C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_conv_stats_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "medt_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "medt_conv_block_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BnPtrs),
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_conv_block_bwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(BnPtrs), C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_up2x_relu_add_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "medt_up2x_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "medt_patch_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -23,6 +23,7 @@ import os
 PATCH = 32          # hard-coded in the reference (:664)
 GRID = 4
 TWO_STREAMS = os.environ.get("MEDT_TWO_STREAMS", "1") != "0"
+SINKS = os.environ.get("MEDT_GRAD_SINKS", "1") != "0"       # gradient fan-in in dgrad epilogues (ops.GradSink)
 _side = {}
 
 
@@ -42,16 +43,20 @@ def _require_device(x):
 def axial_block_forward(blk, x, bn_groups: int = 1):
     """AxialBlock{,_dynamic,_wopos}.forward (reference :282-302, :324-344, :368-391)."""
     _require_device(x)
-    out = ops.conv_block(x, blk.conv_down, blk.bn1, relu=True, training=blk.bn1.training, bn_groups=bn_groups)
+    # x fans out to conv_down and to the residual / downsample path (and, for layer outputs, to a decoder skip): their
+    # gradients meet in conv_down's dgrad epilogue instead of autograd add kernels (ops.GradSink)
+    sink = ops.sink_of(x) if (SINKS and x.requires_grad) else None
+    out = ops.conv_block(x, blk.conv_down, blk.bn1, relu=True, training=blk.bn1.training, bn_groups=bn_groups,
+                         x_sink=sink, x_role="final")
     out = blk.hight_block.run(out, bn_groups, False)
     out = blk.width_block.run(out, bn_groups, True)             # + the block's ReLU (:333)
     if blk.downsample is not None:
         identity = ops.conv_block(x, blk.downsample[0], blk.downsample[1], relu=False,
-                                  training=blk.downsample[1].training, bn_groups=bn_groups)
-    else:
-        identity = x
-    return ops.conv_block(out, blk.conv_up, blk.bn2, res=identity, relu=True, training=blk.bn2.training,
-                          bn_groups=bn_groups)
+                                  training=blk.downsample[1].training, bn_groups=bn_groups, x_sink=sink, x_role="deposit")
+        return ops.conv_block(out, blk.conv_up, blk.bn2, res=identity, relu=True, training=blk.bn2.training,
+                              bn_groups=bn_groups)
+    return ops.conv_block(out, blk.conv_up, blk.bn2, res=x, relu=True, training=blk.bn2.training,
+                          bn_groups=bn_groups, res_sink=sink)
 
 
 def _layer(seq, x, bn_groups=1):
@@ -74,10 +79,11 @@ def _unet_body(net, x, sfx="", bn_groups=1):
     x2 = _layer(g("layer2"), x1, bn_groups)
     x3 = _layer(g("layer3"), x2, bn_groups)
     x4 = _layer(g("layer4"), x3, bn_groups)
+    sk = (lambda t: ops.sink_of(t)) if SINKS else (lambda t: None)    # x1..x3 also feed the next layer's first block
     y = ops.up2x_relu_add(ops.conv_block(x4, g("decoder1")), x4)
-    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder2")), x3)
-    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder3")), x2)
-    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder4")), x1)
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder2")), x3, sk(x3))
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder3")), x2, sk(x2))
+    y = ops.up2x_relu_add(ops.conv_block(y, g("decoder4")), x1, sk(x1))
     y = ops.up2x_relu_add(ops.conv_block(y, g("decoder5")), None)
     return y
 
@@ -105,7 +111,7 @@ def medt_forward(net, x):
     g = _stem(net, xin)
     x1 = _layer(net.layer1, g)
     x2 = _layer(net.layer2, x1)
-    y = ops.up2x_relu_add(ops.conv_block(x2, net.decoder4), x1)
+    y = ops.up2x_relu_add(ops.conv_block(x2, net.decoder4), x1, ops.sink_of(x1) if SINKS else None)
     y = ops.up2x_relu_add(ops.conv_block(y, net.decoder5), None)
     # local branch: all 16 patches at once, patch-major on the batch dim, one BatchNorm group per patch.  In eval mode
     # the grouping does not change the result (running statistics); it is kept so the small per-group slices still

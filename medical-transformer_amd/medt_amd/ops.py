@@ -25,11 +25,45 @@ def _stream():
 # --------------------------------------------------------------------------- #
 # y = act( BN( conv(x) + bias ) + res )
 # --------------------------------------------------------------------------- #
-class ConvBlockCfg:
-    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups")
+class GradSink:
+    """Gradient fan-in without add kernels.  A block input x feeds conv_down AND the residual / downsample path, the layer
+    outputs x1..x3 also feed a decoder skip: the reference's autograd sums those gradients with one add kernel per extra
+    consumer.  Consumers that share a sink hand their contribution over instead: whoever finishes its backward first
+    deposits its gradient tensor here and returns nothing to autograd; the next one adds the deposit in the epilogue of
+    its own dgrad kernel (medt_conv_block_bwd's dx_add) and either re-deposits the sum (role "deposit") or -- the
+    consumer autograd runs last, conv_down: the earliest-created node -- returns it (role "final").  If the order ever
+    differs (final already ran) a depositor simply returns its gradient the ordinary way."""
+    __slots__ = ("pending", "closed")
 
-    def __init__(self, stride, pad, bn, relu, bn_groups=1):
+    def __init__(self):
+        self.pending, self.closed = None, False
+
+    def deposit(self, t) -> bool:
+        """True: taken (the caller returns None to autograd).  False: return the gradient normally."""
+        if self.closed or self.pending is not None:
+            return False
+        self.pending = t
+        return True
+
+    def take(self):
+        t, self.pending = self.pending, None
+        return t
+
+
+def sink_of(x):
+    """The sink shared by the consumers of tensor x (created on first use)."""
+    s = getattr(x, "_medt_sink", None)
+    if s is None:
+        s = x._medt_sink = GradSink()
+    return s
+
+
+class ConvBlockCfg:
+    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink")
+
+    def __init__(self, stride, pad, bn, relu, bn_groups=1, x_sink=None, x_role=None, res_sink=None):
         self.stride, self.pad, self.bn, self.relu, self.bn_groups = stride, pad, bn, relu, bn_groups
+        self.x_sink, self.x_role, self.res_sink = x_sink, x_role, res_sink
 
 
 def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDesc:
@@ -87,6 +121,9 @@ class ConvBlockFn(torch.autograd.Function):
         Cout = w.shape[0]
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
+        # fan-in of the input's gradient (GradSink): add what the other consumers deposited in this dgrad's epilogue
+        xs = cfg.x_sink if need_dx else None
+        dx_add = xs.take() if (xs is not None and w.shape[2] == 1) else None
         present = (True, ctx.has_bias, has_bn, has_bn)
         shapes = (w.shape, (Cout,), (Cout,), (Cout,))
         dst, ret, pend = [None] * 4, [None] * 4, []
@@ -110,18 +147,27 @@ class ConvBlockFn(torch.autograd.Function):
         q = DEFER.recording(allow=not pend and all(r is None for r in ret))
         L.check(lib.medt_conv_block_bwd(C.byref(desc), x.data_ptr(), w.data_ptr(), C.byref(bnp) if has_bn else None,
                                         L.ptr(z), L.ptr(y), L.ptr(stats), dy.data_ptr(), L.ptr(dx), dst[0].data_ptr(),
-                                        L.ptr(dst[1]), L.ptr(dst[2]), L.ptr(dst[3]), L.ptr(dres), ws.data_ptr(), ws_bytes,
-                                        _stream()), "medt_conv_block_bwd")
+                                        L.ptr(dst[1]), L.ptr(dst[2]), L.ptr(dst[3]), L.ptr(dres), L.ptr(dx_add), ws.data_ptr(),
+                                        ws_bytes, _stream()), "medt_conv_block_bwd")
         if q is not None:                      # recorded weight / bias gradient jobs read these at the flush
             q.hold(ws, x, dy, stats, dres, *dst)
         for slot, tmp in pend:
             OPT.accumulate(slot, tmp)
+        if xs is not None:
+            if cfg.x_role == "final":
+                xs.closed = True
+            elif xs.deposit(dx):                       # role "deposit": hand dx to the consumer that runs after this one
+                dx = None
+        if dres is not None and cfg.res_sink is not None and cfg.res_sink.deposit(dres):
+            dres = None
         return (dx, ret[0], ret[1], ret[2], ret[3], dres, None, None)
 
 
-def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups=1):
-    """conv: nn.Conv2d holder, bn: nn.BatchNorm2d holder or None."""
-    cfg = ConvBlockCfg(conv.stride[0], conv.padding[0], bn, relu, bn_groups if bn is not None else 1)
+def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups=1, x_sink=None, x_role=None,
+               res_sink=None):
+    """conv: nn.Conv2d holder, bn: nn.BatchNorm2d holder or None.  x_sink / x_role / res_sink: see GradSink."""
+    cfg = ConvBlockCfg(conv.stride[0], conv.padding[0], bn, relu, bn_groups if bn is not None else 1, x_sink, x_role,
+                       res_sink)
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                              bn.bias if bn is not None else None, res, cfg, training)
 
@@ -131,7 +177,8 @@ def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups
 # --------------------------------------------------------------------------- #
 class UpReluAddFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, skip):
+    def forward(ctx, x, skip, skip_sink=None):
+        ctx.skip_sink = skip_sink
         _require_device(x)
         lib = L.lib()
         x = x.contiguous()
@@ -154,11 +201,14 @@ class UpReluAddFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         L.check(lib.medt_up2x_relu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N * Cc, H, W, _stream()),
                 "medt_up2x_relu_bwd")
-        return dx, (dy if ctx.has_skip else None)
+        dskip = dy if ctx.has_skip else None
+        if dskip is not None and ctx.skip_sink is not None and ctx.skip_sink.deposit(dskip):
+            dskip = None                               # the skip tensor's block adds it in its dgrad epilogue (GradSink)
+        return dx, dskip, None
 
 
-def up2x_relu_add(x, skip=None):
-    return UpReluAddFn.apply(x, skip)
+def up2x_relu_add(x, skip=None, skip_sink=None):
+    return UpReluAddFn.apply(x, skip, skip_sink)
 
 
 # --------------------------------------------------------------------------- #
