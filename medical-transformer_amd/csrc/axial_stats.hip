@@ -205,6 +205,148 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
     }
 }
 
+// --------------------------------------------------------------------------- //
+// Width layers (the sequence is the contiguous NCHW direction) without the LDS transpose: a ROW of 16 lanes owns one
+// sequence, every lane V = L/16 consecutive positions (one 16-byte load per channel at L = 64), a wave moves 4 whole
+// sequences per step with fully coalesced loads.  The table-weighted sums (qr, kr) only ever need the grand total, so
+// they stay lane-private until the end; the per-sequence sums / Grams the qk moments need are all-reduced inside the
+// 16-lane row with four DPP row rotations each (no LDS, no barrier).  Every lane of a row then holds the same
+// per-sequence products: they are accumulated on all 16 and the total is scaled by 1/16 (exact).
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+template <int V>
+__device__ __forceinline__ void load_run(const float* __restrict__ p, size_t idx, int bf, float (&out)[V]) {
+    if (bf) {
+        const unsigned short* q = reinterpret_cast<const unsigned short*>(p) + idx;
+        if constexpr (V >= 4) {
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) {
+                const uint2 r = reinterpret_cast<const uint2*>(q)[h];
+                out[4 * h] = __uint_as_float(r.x << 16); out[4 * h + 1] = __uint_as_float(r.x & 0xffff0000u);
+                out[4 * h + 2] = __uint_as_float(r.y << 16); out[4 * h + 3] = __uint_as_float(r.y & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) out[v] = bf16_bits_to_f32(q[v]);
+        }
+    } else {
+        const float* q = p + idx;
+        if constexpr (V >= 4) {
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) {
+                const float4 r = reinterpret_cast<const float4*>(q)[h];
+                out[4 * h] = r.x; out[4 * h + 1] = r.y; out[4 * h + 2] = r.z; out[4 * h + 3] = r.w;
+            }
+        } else if constexpr (V == 2) {
+            const float2 r = *reinterpret_cast<const float2*>(q);
+            out[0] = r.x; out[1] = r.y;
+        } else {
+            out[0] = q[0];
+        }
+    }
+}
+
+template <int HQ, bool POS, int V>
+__global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
+                                                                      BnStats qs, const float* __restrict__ tables,
+                                                                      GatePtrs gates, float* __restrict__ partials,
+                                                                      int sparts) {
+    constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NCH = 4 * HQ, L = 16 * V;
+    __shared__ float red[MEDT_WAVES * 8];
+    const int grp = blockIdx.x / sparts, tile = blockIdx.x - grp * sparts, hg = blockIdx.y;
+    const int seq0 = tile * 64, nseq = min(64, g.spg - seq0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, p0 = (lane & 15) * V;
+    float sc[GP], sh[GP];
+#pragma unroll
+    for (int ch = 0; ch < GP; ++ch) {
+        sc[ch] = qs.scale[grp * 2 * g.C + hg * NCH + ch];
+        sh[ch] = qs.shift[grp * 2 * g.C + hg * NCH + ch];
+    }
+    float tq[POS ? NR : 1][V], tk[POS ? NR : 1][V];         // this lane's positions of the sliding-window tables
+    if (POS) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                tq[r][v] = tables[(size_t)(p0 + v) * NR + r];
+                tk[r][v] = tables[(size_t)(L + p0 + v) * NR + r];
+            }
+    }
+    float qk1 = 0.f, qk2 = 0.f, r1q = 0.f, r2q = 0.f, r1k = 0.f, r2k = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int sl = (it * MEDT_WAVES + wave) * 4 + row;                  // sequence of the tile owned by this row
+        const bool active = sl < nseq;
+        const int b = grp * g.spg + seq0 + (active ? sl : 0);
+        const int n = b / g.Bo, sq = b - n * g.Bo;
+        const size_t base = ((size_t)n * 2 * g.C + hg * NCH) * g.HW + (size_t)sq * g.W + p0;
+        float x[GP][V];
+#pragma unroll
+        for (int ch = 0; ch < GP; ++ch) load_run<V>(qkv_raw, base + (size_t)ch * g.HW, g.bf16, x[ch]);
+        float s[2 * NR];                                                    // Sq | Gq pairs | Sk | Gk pairs of this lane's run
+#pragma unroll
+        for (int k = 0; k < 2 * NR; ++k) s[k] = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float y[GP];
+#pragma unroll
+            for (int ch = 0; ch < GP; ++ch) y[ch] = active ? fmaf(x[ch][v], sc[ch], sh[ch]) : 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                s[c] += y[c];
+                s[NR + c] += y[HQ + c];
+                if (POS) {
+                    r1q = fmaf(y[c], tq[c][v], r1q);
+                    r1k = fmaf(y[HQ + c], tk[c][v], r1k);
+                }
+            }
+            int pr = 0;
+#pragma unroll
+            for (int a = 0; a < HQ; ++a)
+#pragma unroll
+                for (int c = a; c < HQ; ++c, ++pr) {
+                    const float pq = y[a] * y[c], pk = y[HQ + a] * y[HQ + c];
+                    s[HQ + pr] += pq;
+                    s[NR + HQ + pr] += pk;
+                    if (POS) {
+                        r2q = fmaf(pq, tq[HQ + pr][v], r2q);
+                        r2k = fmaf(pk, tk[HQ + pr][v], r2k);
+                    }
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * NR; ++k) s[k] = row16_allsum(s[k]);         // per-sequence totals, in all 16 lanes
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qk1 = fmaf(s[c], s[NR + c], qk1);
+        int pr = 0;
+#pragma unroll
+        for (int a = 0; a < HQ; ++a)
+#pragma unroll
+            for (int c = a; c < HQ; ++c, ++pr) qk2 = fmaf((c > a ? 2.f : 1.f) * s[HQ + pr], s[NR + HQ + pr], qk2);
+    }
+    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
+    float acc[6] = {qk1 * 0.0625f, qk2 * 0.0625f, f_qr * r1q, f_qr * f_qr * r2q, f_kr * r1k, f_kr * f_kr * r2k};
+    constexpr int NA = POS ? 6 : 2;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const float t = wave_sum(acc[k]);
+        if (lane == 0) red[wave * 8 + k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NA) {
+        const int k = threadIdx.x;
+        const float t = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
+        partials[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = t;
+    }
+}
+
 static int stats_chunk_log(const AxialGeom& g) {
     int cap = 128 / g.gp;                 // [gp q|k channels][64][PC+1] floats <= ~33 KB
     if (cap < 4) cap = 4;
@@ -217,6 +359,22 @@ int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, con
                       const float* tables, float* partials, hipStream_t s) {
     const int sparts = sim_stats_parts(g), lg = stats_chunk_log(g);
     if (g.pos && !tables) { set_error("sim_stats: no tables"); return MEDT_EINVAL; }
+    if (g.axis == 1 && g.hq <= 2 && (g.L == 16 || g.L == 32 || g.L == 64 || g.L == 128) && (g.W & 3) == 0) {
+        // rows-of-16-lanes kernel: no LDS transpose (width layers with the model's power-of-two lengths, hq <= 2)
+        const dim3 gridr(g.groups * sparts, g.G), blockr(MEDT_THREADS);
+#define MEDT_SR(HQv, POSv, Vv) \
+    hipLaunchKernelGGL((sim_stats_rows_kernel<HQv, POSv, Vv>), gridr, blockr, 0, s, g, qkv_raw, qkv, tables, gates, partials, sparts)
+#define MEDT_SR_V(HQv, POSv)                                                                                          \
+    do {                                                                                                              \
+        if (g.L == 16) MEDT_SR(HQv, POSv, 1); else if (g.L == 32) MEDT_SR(HQv, POSv, 2);                               \
+        else if (g.L == 64) MEDT_SR(HQv, POSv, 4); else MEDT_SR(HQv, POSv, 8);                                         \
+    } while (0)
+        if (g.hq == 1) { if (g.pos) MEDT_SR_V(1, true); else MEDT_SR_V(1, false); }
+        else { if (g.pos) MEDT_SR_V(2, true); else MEDT_SR_V(2, false); }
+#undef MEDT_SR_V
+#undef MEDT_SR
+        return launch_status("sim_stats_rows_kernel");
+    }
     const size_t stage = g.axis == 1 ? (size_t)g.gp * 64 * ((1 << lg) + 1) : 0, red = 3 * 16 * 64;
     const size_t lds = (64 + (stage > red ? stage : red)) * sizeof(float);
     const dim3 grid(g.groups * sparts, g.G), block(MEDT_THREADS);

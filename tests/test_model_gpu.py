@@ -12,6 +12,7 @@ from oracle import medt_oracle as O
 pytestmark = pytest.mark.gpu
 MODEL_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(H.GOLDEN, "model_*.npz")))
 TOL = 1e-3
+KNOISE = 5.0        # training-mode gradients: product error <= KNOISE x the reference's own measured fp32 noise
 
 
 def build(name, S, device, chan=3):
@@ -25,10 +26,11 @@ def build(name, S, device, chan=3):
 def test_model_vs_reference_fixture(fn, device):
     """Tolerances.  eval / evalgrad (running statistics): 1e-3 relative, everything.
     train (batch statistics): logits 1e-3 or 3x the reference's own fp32-vs-fp64 discrepancy, whichever
-    is larger; gradients within 3x max(reference fp32 noise, 5 % of the norm) -- the whole-network
-    training-mode backward is ill-conditioned in fp32 for the reference itself (fixture 'grad_noise',
-    DESIGN.md 'parity floor'); the exact backward wiring is pinned by the evalgrad fixtures and by the
-    layer-level tests at 1e-3."""
+    is larger; every gradient tensor within KNOISE x the reference's own fp32 noise on THAT tensor (the
+    maximum over three fp32 runs of the reference with different summation orders, stored per tensor by
+    make_golden.py) -- the whole-network training-mode backward is ill-conditioned in fp32 for the
+    reference itself (DESIGN.md 'parity floor').  The ratio product-error / reference-noise is printed.
+    The exact backward wiring is pinned by the evalgrad fixtures and by the layer-level tests at 1e-3."""
     fx = H.load_golden(fn)
     name = fn.split("_")[1]
     S, N, seed, _ = [int(v) for v in fx["meta"]]
@@ -55,6 +57,9 @@ def test_model_vs_reference_fixture(fn, device):
         assert torch.equal((o >= 0.5)[safe], (want >= 0.5)[safe])
         margin = (want[:, 1] - want[:, 0]).abs() > 1e-3 * want.abs().max()
         assert torch.equal(o.argmax(1)[margin], want.argmax(1)[margin])
+        print(f"{fn}: label map (logit >= 0.5) bit-exact on {int(safe.sum())} of {safe.numel()} values "
+              f"({int((~safe).sum())} within 1e-3 of the threshold excluded); argmax bit-exact on {int(margin.sum())} of "
+              f"{margin.numel()} pixels ({int((~margin).sum())} near-ties excluded)")
     if mode == "eval":
         return
     loss = torch.nn.functional.cross_entropy(out, y.to(device))
@@ -64,22 +69,37 @@ def test_model_vs_reference_fixture(fn, device):
     params = dict(model.named_parameters())
     names, summ, noise = list(fx["grad_names"]), fx["grad_summary"], fx["grad_noise"]
     gmax = summ[:, 0].max()
-    bad = []
-    for k, (norm, dot), (nz, _) in zip(names, summ, noise):
+    bad, ratios = [], []
+    for k, (norm, dot), (nz, nzd) in zip(names, summ, noise):
         g = params[k].grad.double().cpu().reshape(-1)
         scale = max(norm, 1e-3 * gmax)
-        tol_abs = TOL * scale if mode == "evalgrad" else 3 * max(nz, 0.05 * scale)
-        if abs(g.norm().item() - norm) > tol_abs:
-            bad.append((k, "norm", g.norm().item(), norm))
         d = torch.dot(g, H.probe_vector(k, g.numel(), seed)).item()
-        if abs(d - dot) > 5 * tol_abs:
+        if mode == "evalgrad":
+            tol_n = tol_d = TOL * scale
+            tol_d *= 5
+        else:
+            # training mode: k x the reference's OWN float32 noise on this tensor (max over three fp32 runs of the
+            # reference with different summation orders, make_golden.py), never less than the fp32 bar itself
+            # (the probe has unit-variance entries: an error vector of norm e moves the dot product by ~N(0, e^2), so the
+            # dot product is held to 3 sigma of KNOISE x the noise NORM -- three samples of the reference's own probe
+            # noise are too few to use that directly)
+            floor = max(nz, TOL * scale)
+            tol_n, tol_d = KNOISE * floor, 3 * KNOISE * max(floor, nzd)
+            ratios.append(max(abs(g.norm().item() - norm) / floor, abs(d - dot) / (3 * max(floor, nzd))))
+        if abs(g.norm().item() - norm) > tol_n:
+            bad.append((k, "norm", g.norm().item(), norm))
+        if abs(d - dot) > tol_d:
             bad.append((k, "dot", d, dot))
+    if ratios:
+        r = np.sort(np.array(ratios))
+        print(f"{fn}: product error / reference fp32 noise per gradient tensor: median {np.median(r):.2f}, "
+              f"90% {r[int(0.9 * len(r))]:.2f}, max {r[-1]:.2f} (bound {KNOISE})")
     assert not bad, bad[:8]
     for k in fx:
         if k.startswith("grad/"):
             w = torch.from_numpy(fx[k])
             scale = max(w.abs().max().item(), 1e-3 * gmax)
-            tol_abs = TOL * scale if mode == "evalgrad" else 4 * max(float(fx["gradnoise/" + k[5:]][0]), 0.05 * scale)
+            tol_abs = TOL * scale if mode == "evalgrad" else KNOISE * max(float(fx["gradnoise/" + k[5:]][0]), TOL * scale)
             assert (params[k[5:]].grad.double().cpu() - w).abs().max().item() < tol_abs, k
     if mode == "train":
         sd = model.state_dict()
