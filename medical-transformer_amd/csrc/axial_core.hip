@@ -345,6 +345,25 @@ __device__ __forceinline__ void bwd_stage(const AxialGeom& g, BwdLds<GP, POS>& S
     __syncthreads();
 }
 
+// Sum over the L lanes of a sequence (L a power of two <= 64, segments aligned to L), result in every lane.
+// 16-lane rows are all-reduced with DPP row rotations; rows are combined through SGPRs (v_readlane): no LDS traffic.
+__device__ __forceinline__ float seg_allsum(float v, int L) {
+    if (L >= 16) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+        if (L == 16) return v;
+        const int vi = __float_as_int(v);
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+        if (L == 64) return (r0 + r1) + (r2 + r3);
+        return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;                                                    // L == 32
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // Everything one (i, j) pair contributes, shared by the row- and column-oriented loops.
 struct PairTerms {
     float tqk, rq, rk;      // sum_c q k ; sum_c q Rq[d] ; sum_c k Rk[d']   (ungated)
@@ -534,7 +553,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
         const float* lsep = S.g3 + ls * S.R3 + GP * L;
         const float* delp = lsep + L;
         // ---------------- row-oriented: thread owns query row i = idx ----------------
-        {
+        // (only when the wrapped-diagonal sweep below cannot run: it produces dq and the gate gradients as well)
+        if (!diag) {
             const int i = idx;
             float q[HQ], dsv[GP], dse[GP], dq[HQ];
 #pragma unroll
@@ -608,9 +628,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
             const int src_lane = (threadIdx.x & 63 & ~Lm) | ((dl - 1) & Lm);
             float tq_hi[HQ], tq_lo[HQ], tk_hi[HQ], tk_lo[HQ], tv_hi[GP], tv_lo[GP];
             float aq_hi[HQ], aq_lo[HQ], ak_hi[HQ], ak_lo[HQ], av_hi[GP], av_lo[GP];
-            float dk[HQ], dv[GP];
+            float dk[HQ], dv[GP], dq_d[HQ];
 #pragma unroll
             for (int c = 0; c < HQ; ++c) {
+                dq_d[c] = 0.f;
                 tq_hi[c] = S.tq[c * TL + d_hi]; tq_lo[c] = S.tq[c * TL + d_lo];
                 tk_hi[c] = S.tk[c * TL + d_hi]; tk_lo[c] = S.tk[c * TL + d_lo];
                 aq_hi[c] = aq_lo[c] = ak_hi[c] = ak_lo[c] = 0.f;
@@ -647,9 +668,21 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
                 }
                 const float dZ = P * (fmaf(f_sv, dPv, f_sve * dPe) - delp[i]);
                 const float dSqk = fmaf(b_qk, dZ, fmaf(u_qk, tqk, w_qk));
-                const float gq = f_qr * fmaf(b_qr, dZ, fmaf(u_qr, tqr, w_qr));
-                const float gk = f_kr * fmaf(b_kr, dZ, fmaf(u_kr, tkr, w_kr));
+                const float dSqr = fmaf(b_qr, dZ, fmaf(u_qr, tqr, w_qr)), dSkr = fmaf(b_kr, dZ, fmaf(u_kr, tkr, w_kr));
+                const float gq = f_qr * dSqr, gk = f_kr * dSkr;
                 const float gv = f_sve * P, pv = f_sv * P;
+                // gate gradients: every (i, j) pair is visited exactly once by this sweep
+                gacc[0] = fmaf(dSqr, rq, gacc[0]);
+                gacc[1] = fmaf(dSkr, rk, gacc[1]);
+                gacc[2] = fmaf(P, dPe, gacc[2]);
+                gacc[3] = fmaf(P, dPv, gacc[3]);
+                // dq of row i: every lane of the sequence holds one column's term -> sum over the L lanes, kept by lane i
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    float t = fmaf(dSqk, kj[c], gq * (hi ? tq_hi[c] : tq_lo[c]));
+                    t = seg_allsum(t, L);
+                    if (dl == i) dq_d[c] = t;
+                }
 #pragma unroll
                 for (int c = 0; c < HQ; ++c) {
                     dk[c] = fmaf(dSqk, qi[c], fmaf(gk, hi ? tk_hi[c] : tk_lo[c], dk[c]));
@@ -670,6 +703,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
                     for (int c = 0; c < GP; ++c) dv[c] = __shfl(dv[c], src_lane, 64);
                 }
             }
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) dqkv_v[c] = dq_d[c];
             // after step L-1 lane delta holds column (L-1-delta) mod L: park the values, the owner lane reads them
             const int owner = (threadIdx.x & 63 & ~Lm) | ((L - 1 - dl) & Lm);
 #pragma unroll

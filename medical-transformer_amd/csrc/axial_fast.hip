@@ -248,38 +248,16 @@ template <bool BF>
 __device__ __forceinline__ float* act_base(float* p, size_t elems) {
     return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * (BF ? 2 : 4));
 }
+// byte offsets (ES = element size of the storage type), as in ldg_u / stg_u
 template <bool BF>
-__device__ __forceinline__ float lda_u(const float* __restrict__ ubase, unsigned elemoff) {
-    if (BF) return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(ubase) + elemoff * 2u));
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + elemoff * 4u);
+__device__ __forceinline__ float lda_u(const float* __restrict__ ubase, unsigned byteoff) {
+    if (BF) return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(ubase) + byteoff));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + byteoff);
 }
 template <bool BF>
-__device__ __forceinline__ void sta_u(float* __restrict__ ubase, unsigned elemoff, float v) {
-    if (BF) *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ubase) + elemoff * 2u) = f32_to_bf16_bits(v);
-    else *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + elemoff * 4u) = v;
-}
-
-template <bool BF>
-__device__ __forceinline__ f4 lda_u4(const float* __restrict__ ubase, unsigned elemoff) {
-    if (BF) {
-        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ubase) + elemoff * 2u);
-        f4 v;
-        v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
-        v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
-        return v;
-    }
-    return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(ubase) + elemoff * 4u);
-}
-template <bool BF>
-__device__ __forceinline__ void sta_u4(float* __restrict__ ubase, unsigned elemoff, f4 v) {
-    if (BF) {
-        uint2 r;
-        r.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
-        r.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ubase) + elemoff * 2u) = r;
-    } else {
-        *reinterpret_cast<f4*>(reinterpret_cast<char*>(ubase) + elemoff * 4u) = v;
-    }
+__device__ __forceinline__ void sta_u(float* __restrict__ ubase, unsigned byteoff, float v) {
+    if (BF) *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ubase) + byteoff) = f32_to_bf16_bits(v);
+    else *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
 }
 
 // Where the elements of one super-tile live.  (n0, s0, nseq) are wave-uniform (first image, first sequence inside
@@ -316,23 +294,6 @@ struct SuperMap {
         lo = ls * F::RS + i;
         return true;
     }
-    // Quad addressing (four-rows-per-lane kernel): a thread moves the 4 CONSECUTIVE elements e = 4*(tid + 256 t) .. +3 of
-    // the contiguous NCHW direction with one 16-byte access (width axis: 4 positions of one sequence; height axis: the
-    // same position of 4 adjacent sequences).  Valid for full tiles whose rows stay 16-byte aligned and inside one image.
-    __device__ __forceinline__ bool quad_ok(const AxialGeom& g, int full) const {
-        if (nseq != full || (g.W & 3)) return false;
-        return AXIS == 1 ? true : ((nseq & 3) == 0 && (g.Bo & 3) == 0 && (s0 & 3) == 0);
-    }
-    __device__ __forceinline__ void locate_quad(const AxialGeom& g, int t, int& lo, int& dn, int& pix) const {
-        const int e = 4 * (threadIdx.x + t * MEDT_THREADS);
-        int ls, i;
-        if (AXIS == 1) { ls = e / L; i = e % L; }
-        else { i = (int)(((float)e + 0.5f) * inv_nseq); ls = e - i * nseq; }
-        int sq;
-        image_of(g, ls, dn, sq);
-        pix = AXIS == 1 ? sq * g.W + i : i * g.W + sq;
-        lo = ls * F::RS + i;
-    }
 };
 
 // Register prefetch of a super-tile: the raw global loads of tile u+1 are issued before the arithmetic of tile u and
@@ -354,53 +315,15 @@ struct SuperPrefetch {
         for (int t = 0; t < NTA; ++t) {
             int lo, dn, pix;
             if (m.locate(g, t, lo, dn, pix)) {
-                const unsigned off = (unsigned)(dn * img + pix);
+                constexpr unsigned ES = BF ? 2u : 4u;
+                const unsigned off = (unsigned)(dn * img + pix) * ES;
 #pragma unroll
-                for (int ch = 0; ch < NCHL; ++ch) v[t * NCHL + ch] = lda_u<BF>(base, off + (unsigned)(ch * g.HW));
+                for (int ch = 0; ch < NCHL; ++ch) v[t * NCHL + ch] = lda_u<BF>(base, off + (unsigned)(ch * g.HW) * ES);
             }
         }
     }
     __device__ __forceinline__ void issue(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
         issue_t<kBF>(qkv_raw, g, hg, m);
-    }
-    // quad variants (see SuperMap::locate_quad): v[(t*NCHL + ch)*4 + k] = element k of quad t, channel ch
-    static constexpr int NQ = NTA / 4;
-    __device__ __forceinline__ void issue_quad(const float* __restrict__ qkv_raw, const AxialGeom& g, int hg, const Map& m) {
-        const float* base = act_base<kBF>(qkv_raw, ((size_t)m.n0 * 2 * g.C + hg * F::NCH) * g.HW);      // uniform
-        const int img = 2 * g.C * g.HW;
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) {
-            int lo, dn, pix;
-            m.locate_quad(g, t, lo, dn, pix);
-            const unsigned off = (unsigned)(dn * img + pix);
-#pragma unroll
-            for (int ch = 0; ch < NCHL; ++ch) {
-                const f4 q = lda_u4<kBF>(base, off + (unsigned)(ch * g.HW));
-                float* d = v + (t * NCHL + ch) * 4;
-                d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-            }
-        }
-    }
-    __device__ __forceinline__ void commit_quad(float* reg, const AxialGeom& g, const Map& m, const float* __restrict__ sc,
-                                                const float* __restrict__ sh) const {
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) {
-            int lo, dn, pix;
-            m.locate_quad(g, t, lo, dn, pix);
-#pragma unroll
-            for (int ch = 0; ch < NCHL; ++ch) {
-                const float* d = v + (t * NCHL + ch) * 4;
-                const float a = sc[ch], b = sh[ch];
-                if (AXIS == 1) {
-                    f4 q;
-                    q.x = fmaf(d[0], a, b); q.y = fmaf(d[1], a, b); q.z = fmaf(d[2], a, b); q.w = fmaf(d[3], a, b);
-                    *reinterpret_cast<f4*>(reg + lo + ch * L) = q;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) reg[lo + k * F::RS + ch * L] = fmaf(d[k], a, b);
-                }
-            }
-        }
     }
     __device__ __forceinline__ void commit(float* reg, const AxialGeom& g, const Map& m, const float* __restrict__ sc,
                                            const float* __restrict__ sh) const {
@@ -426,9 +349,10 @@ __device__ __forceinline__ void store_super_t(const float* reg, int lch0, float*
     for (int t = 0; t < F::nta(AXIS) * F::EPT; ++t) {
         int lo, dn, pix;
         if (m.locate(g, t, lo, dn, pix)) {
-            const unsigned off = (unsigned)(dn * img + pix);
+            constexpr unsigned ES = BF ? 2u : 4u;
+            const unsigned off = (unsigned)(dn * img + pix) * ES;
             const float* src = reg + lo + lch0 * L;
-            for (int ch = 0; ch < nch; ++ch) sta_u<BF>(base, off + (unsigned)(ch * g.HW), src[ch * L]);
+            for (int ch = 0; ch < nch; ++ch) sta_u<BF>(base, off + (unsigned)(ch * g.HW) * ES, src[ch * L]);
         }
     }
 }
@@ -438,28 +362,6 @@ __device__ __forceinline__ void store_super(const float* reg, int lch0, float* _
                                             const AxialGeom& g, const SuperMap<F, AXIS>& m, int bf16 = 0) {
     if (kBF && bf16) store_super_t<F, AXIS, true>(reg, lch0, dst, CH, ch0, nch, g, m);
     else store_super_t<F, AXIS, false>(reg, lch0, dst, CH, ch0, nch, g, m);
-}
-
-// Quad store (four-rows-per-lane kernel, SuperMap::locate_quad); BF: dst stored as bfloat16
-template <class F, int AXIS, bool BF>
-__device__ __forceinline__ void store_super_quad(const float* reg, int lch0, float* __restrict__ dst, int CH, int ch0, int nch,
-                                                 const AxialGeom& g, const SuperMap<F, AXIS>& m) {
-    constexpr int L = F::LEN;
-    float* base = act_base<BF>(dst, ((size_t)m.n0 * CH + ch0) * g.HW);                      // uniform
-    const int img = CH * g.HW;
-#pragma unroll
-    for (int t = 0; t < F::nta(AXIS) * F::EPT / 4; ++t) {
-        int lo, dn, pix;
-        m.locate_quad(g, t, lo, dn, pix);
-        const unsigned off = (unsigned)(dn * img + pix);
-        const float* src = reg + lo + lch0 * L;
-        for (int ch = 0; ch < nch; ++ch) {
-            f4 q;
-            if (AXIS == 1) q = *reinterpret_cast<const f4*>(src + ch * L);
-            else { q.x = src[ch * L]; q.y = src[F::RS + ch * L]; q.z = src[2 * F::RS + ch * L]; q.w = src[3 * F::RS + ch * L]; }
-            sta_u4<BF>(base, off + (unsigned)(ch * g.HW), q);
-        }
-    }
 }
 
 // EXACT = true : online softmax (running max, one rescale per 4-column chunk); if `flag` is given the kernel only
@@ -692,11 +594,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                     int dn, sq;
                     cur.image_of(g, ls, dn, sq);
                     const int pix = sq * g.W + i;
-                    const unsigned off = (unsigned)(dn * g.OC * g.HW + pix);
+                    constexpr unsigned ES = kBF ? 2u : 4u;
+                    const unsigned off = (unsigned)(dn * g.OC * g.HW + pix) * ES;
                     float* bo = act_base<kBF>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);      // uniform
 #pragma unroll
                     for (int k = 0; k < OCG; ++k) {
-                        sta_u<kBF>(bo, off + (unsigned)(k * g.HW), outv[k]);
+                        sta_u<kBF>(bo, off + (unsigned)(k * g.HW) * ES, outv[k]);
                         st_sum[k] += outv[k];
                         st_sq[k] = fmaf(outv[k], outv[k], st_sq[k]);
                     }
@@ -836,26 +739,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
         nxt.set(g, grp * g.npg + dn, q0 - dn * g.Bo, min(SSr, g.spg - (int)q0));
     }
     PF pf;
-    // full, aligned super-tiles move 16 bytes per access (quad path); ragged ones fall back to the element-wise movers
-    bool nq = false;
-    if (part < nsup) {
-        nq = g.nt4 == F::nta(AXIS) && nxt.quad_ok(g, SSr);
-        if (nq) pf.issue_quad(qkv_raw, g, hg, nxt); else pf.issue(qkv_raw, g, hg, nxt);
-    }
+    if (part < nsup) pf.issue(qkv_raw, g, hg, nxt);
     for (int u = part; u < nsup; u += g.oparts) {
         cur = nxt;
-        const bool cq = nq;
         const int nseq = cur.nseq;
         __syncthreads();                                       // previous super-tile fully stored / tables staged
-        if (cq) pf.commit_quad(reg, g, cur, sc, sh); else pf.commit(reg, g, cur, sc, sh);
+        pf.commit(reg, g, cur, sc, sh);
         {
             const int un = u + g.oparts;
             int s0 = cur.s0 + ds_step, n0 = cur.n0 + dn_step;
             if (s0 >= g.Bo) { s0 -= g.Bo; ++n0; }
             if (un < nsup) {
                 nxt.set(g, n0, s0, min(SSr, g.spg - un * SSr));
-                nq = g.nt4 == F::nta(AXIS) && nxt.quad_ok(g, SSr);
-                if (nq) pf.issue_quad(qkv_raw, g, hg, nxt); else pf.issue(qkv_raw, g, hg, nxt);
+                pf.issue(qkv_raw, g, hg, nxt);
             }
         }
         __syncthreads();
@@ -958,13 +854,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
             }
         }
         __syncthreads();
-        if (cq) {
-            store_super_quad<F, AXIS, kBF>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur);
-            if (lse_out) store_super_quad<F, AXIS, false>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
-        } else {
-            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, 1);
-            if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
-        }
+        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, 1);
+        if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
     }
     if (!EXACT && bad) atomicOr(flag, 1u);
     if (out_partials) {
