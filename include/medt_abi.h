@@ -85,7 +85,11 @@ typedef struct medt_axial_desc {
     int32_t out_relu;       /* 1: fuse the block's ReLU after the width layer (:333) into the output pass */
     int32_t gate_mode;      /* 0: f_* multiply as stored (axialnet.py:163-164,175-176);
                                1: sigmoid(f_*) multiplies -- AxialAttention_gated_sig, lib/models/model_codes.py:279-280,
-                                  292-293; the gate gradients returned are then wrt the stored (pre-sigmoid) values */
+                                  292-293; the gate gradients returned are then wrt the stored (pre-sigmoid) values;
+                               2: one set of gates PER SEQUENCE -- AxialAttention_gated_data, model_codes.py:406-407,420-421:
+                                  params.f_qr points to a (B*, 4) tensor with columns (qr, kr, sv, sve), B* = N*W (axis 0) or
+                                  N*H (axis 1), sequence b = n*Bo + s; f_kr / f_sve / f_sv are ignored; grads.gates receives the
+                                  (B*, 4) gradient in the same layout; the generic (not the bandwidth-tuned) kernels run */
     int32_t act_dtype;      /* storage type of saved->qkv_raw and saved->stacked: 0 float32 (the reference's arithmetic and
                                storage), 1 bfloat16 (BASELINE.json configs[1]: half the attention path's HBM bytes;
                                accumulation, statistics, x / y / dx and every gradient stay float32).  has_pos only. */
@@ -190,6 +194,16 @@ int medt_conv_block_bwd(const medt_conv_desc*, const float* x, const float* w, c
                         const float* z, const float* y, const float* stats, const float* dy,
                         float* dx, float* dw, float* dbias, float* dbn_weight, float* dbn_bias, float* dres,
                         const float* dx_add, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The gate network of AxialAttention_gated_data (lib/models/model_codes.py:371-380):
+ *   xn = mean over the sequence of x (B*, C);  h = relu(fcn1(xn));  o = relu(fcn2(h));  gates = sigmoid(o)   (B*, 4)
+ * xn, h (B*, C) and o (B*, 4) are kept for the backward.  bwd: scratch = B* * (4 + 2C) floats; dw1 (C,C), db1 (C), dw2 (4,C),
+ * db2 (4) and dx (N,C,H,W: the gradient that reaches x THROUGH the gates) are written, not accumulated. */
+int medt_gate_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* xn, float* h,
+                      float* o, float* gates, int N, int C, int H, int W, int axis, void* stream);
+int medt_gate_mlp_bwd(const float* dgates, const float* gates, const float* o, const float* h, const float* xn,
+                      const float* w1, const float* w2, float* scratch, float* dw1, float* db1, float* dw2, float* db2,
+                      float* dx, int N, int C, int H, int W, int axis, void* stream);
 
 /* y = relu(bilinear_x2(x)) + skip       F.interpolate(scale_factor=(2,2), mode='bilinear') + relu + torch.add
  * (lib/models/axialnet.py:493-501, 650-652, 690-698).  x (NC,H,W) -> y (NC,2H,2W); skip may be NULL.

@@ -77,7 +77,8 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
         static const float shift = [] { const char* e = getenv("MEDT_DEBUG_BOUND_SHIFT"); return e ? (float)atof(e) : 0.f; }();
         g->bound_shift = shift;
     }
-    if (g->pos && fast_path_enabled()) {
+    if (d.gate_mode < 0 || d.gate_mode > 2) { set_error("axial: gate_mode %d unsupported (0 raw, 1 sigmoid, 2 per sequence)", d.gate_mode); return MEDT_EUNSUPPORTED; }
+    if (g->pos && fast_path_enabled() && d.gate_mode != 2) {       // per-sequence gates: generic kernels
         int nt = fast3_max_subtiles(gp, g->L, g->axis);
         if (nt > 0) {
             // Persistent workgroups over super-tiles of nt*S_T sequences.  Small problems (the model's own
@@ -153,10 +154,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, con
     const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
     tile_load<AXIS>(reg, RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, g.bf16);
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const int gseq = t.seq0 + min((int)threadIdx.x / L, t.nseq - 1);              // this thread's sequence (per-sequence gates)
+    const float f_qr = gate_at(gates.f_qr, gates.stride, gseq), f_kr = gate_at(gates.f_kr, gates.stride, gseq);
+    const float f_sve = gate_at(gates.f_sve, gates.stride, gseq), f_sv = gate_at(gates.f_sv, gates.stride, gseq);
     const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
     const float a_qr = POS ? ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E : 0.f;
-    const float a_kr = POS ? ss.scale[grp * g.SC + 2 * g.G + hg] * f_kr * MEDT_LOG2E : 0.f;
+    // the staged Rk table carries bn_similarity's scale (and the gate, when it is one scalar for the whole tile);
+    // per-sequence gates multiply the key on use instead
+    const float kmul = gates.stride ? f_kr : 1.f;
+    const float a_kr = POS ? ss.scale[grp * g.SC + 2 * g.G + hg] * (gates.stride ? 1.f : f_kr) * MEDT_LOG2E : 0.f;
     if (POS) {
         for (int e = threadIdx.x; e < HQ * TL; e += MEDT_THREADS) {
             const int c = e / TL, d = e - c * TL;
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, con
                 z = fmaf(qa[c], kc, z);
                 if (POS) {
                     z = fmaf(qb[c], tq[c * TL + d], z);
-                    z = fmaf(kc, tk[c * TL + d], z);
+                    z = fmaf(kc * kmul, tk[c * TL + d], z);
                 }
             }
             m = fmaxf(m, z);
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, con
                 z = fmaf(qa[c], kc, z);
                 if (POS) {
                     z = fmaf(qb[c], tq[c * TL + d], z);
-                    z = fmaf(kc, tk[c * TL + d], z);
+                    z = fmaf(kc * kmul, tk[c * TL + d], z);
                 }
             }
             const float p = __builtin_amdgcn_exp2f(z - m);
@@ -386,7 +392,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_stats_kernel(
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
     float rawv[NCH];
     bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv);
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const int gseq = t.seq0 + min((int)threadIdx.x / L, t.nseq - 1);              // this thread's sequence (per-sequence gates)
+    const float f_qr = gate_at(gates.f_qr, gates.stride, gseq), f_kr = gate_at(gates.f_kr, gates.stride, gseq);
+    const float f_sve = gate_at(gates.f_sve, gates.stride, gseq), f_sv = gate_at(gates.f_sv, gates.stride, gseq);
     const float e_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
     const float e_qr = POS ? ss.scale[grp * g.SC + g.G + hg] * MEDT_LOG2E : 0.f;
     const float e_kr = POS ? ss.scale[grp * g.SC + 2 * g.G + hg] * MEDT_LOG2E : 0.f;
@@ -528,7 +536,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
         for (int e = threadIdx.x; e < NCH * TL; e += MEDT_THREADS) S.dtq[e] = 0.f;      // dtq|dtk|dtv contiguous
     float rawv[NCH];
     bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv);
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
+    const int gseq = t.seq0 + min((int)threadIdx.x / L, t.nseq - 1);              // this thread's sequence (per-sequence gates)
+    const float f_qr = gate_at(gates.f_qr, gates.stride, gseq), f_kr = gate_at(gates.f_kr, gates.stride, gseq);
+    const float f_sve = gate_at(gates.f_sve, gates.stride, gseq), f_sv = gate_at(gates.f_sv, gates.stride, gseq);
     const float* cq = sim_coef + ((size_t)grp * g.SC + hg) * 3;
     const float* cr = sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
     const float* ck = sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
@@ -790,7 +800,22 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
             rp[(HQ + c) * TL + d] = S.dtk[c * TL + (TL - 1 - d)];
         }
         for (int e = threadIdx.x; e < GP * TL; e += MEDT_THREADS) rp[GP * TL + e] = S.dtv[e];
-        if (gate_partials) block_sum<4>(gacc, S.red, gate_partials + blk * 4);
+        if (gate_partials) {
+            if (gates.stride == 0) {
+                block_sum<4>(gacc, S.red, gate_partials + blk * 4);
+            } else {                                 // per-sequence gates: one row of 4 per (sequence, head)
+                __syncthreads();
+                for (int e = threadIdx.x; e < g.S_T * 4; e += MEDT_THREADS) S.red[e] = 0.f;
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicAdd(&S.red[ls * 4 + k], gacc[k]);
+                }
+                __syncthreads();
+                for (int e = threadIdx.x; e < t.nseq * 4; e += MEDT_THREADS)
+                    gate_partials[((size_t)(t.seq0 + (e >> 2)) * g.G + hg) * 4 + (e & 3)] = S.red[e];
+            }
+        }
     }
     // bn_qkv backward statistics: sum d, sum d * xhat  per channel of this head
     {
@@ -837,7 +862,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
 
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                    GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
-    if (fast_path_enabled()) {
+    if (fast_path_enabled() && gates.stride == 0) {            // (per-sequence gates: generic kernel)
         const int rc = g.bf16 ? axial_attn_fwd_fast_bf16(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s)
                               : axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s);
         if (rc <= 0) return rc;

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
             }
         }
     }
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
+    const int gseq = grp * g.spg + seq0 + min(lane, nseq - 1);
+    const float f_qr = gate_at(gates.f_qr, gates.stride, gseq), f_kr = gate_at(gates.f_kr, gates.stride, gseq);
     acc[2] = f_qr * r1q;
     acc[3] = f_qr * f_qr * r2q;
     acc[4] = f_kr * r1k;
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom 
                 tk[r][v] = tables[(size_t)(L + p0 + v) * NR + r];
             }
     }
-    float qk1 = 0.f, qk2 = 0.f, r1q = 0.f, r2q = 0.f, r1k = 0.f, r2k = 0.f;
+    float qk1 = 0.f, qk2 = 0.f, g1q = 0.f, g2q = 0.f, g1k = 0.f, g2k = 0.f;
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
+        float r1q = 0.f, r2q = 0.f, r1k = 0.f, r2k = 0.f;
         const int sl = (it * MEDT_WAVES + wave) * 4 + row;                  // sequence of the tile owned by this row
         const bool active = sl < nseq;
         const int b = grp * g.spg + seq0 + (active ? sl : 0);
@@ -330,9 +332,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom 
         for (int a = 0; a < HQ; ++a)
 #pragma unroll
             for (int c = a; c < HQ; ++c, ++pr) qk2 = fmaf((c > a ? 2.f : 1.f) * s[HQ + pr], s[NR + HQ + pr], qk2);
+        if (POS) {                                                          // the sequence's gates scale its qr / kr moments
+            const float f_qr = gate_at(gates.f_qr, gates.stride, b), f_kr = gate_at(gates.f_kr, gates.stride, b);
+            g1q = fmaf(f_qr, r1q, g1q);
+            g2q = fmaf(f_qr * f_qr, r2q, g2q);
+            g1k = fmaf(f_kr, r1k, g1k);
+            g2k = fmaf(f_kr * f_kr, r2k, g2k);
+        }
     }
-    const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr);
-    float acc[6] = {qk1 * 0.0625f, qk2 * 0.0625f, f_qr * r1q, f_qr * f_qr * r2q, f_kr * r1k, f_kr * f_kr * r2k};
+    float acc[6] = {qk1 * 0.0625f, qk2 * 0.0625f, g1q, g2q, g1k, g2k};
     constexpr int NA = POS ? 6 : 2;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {

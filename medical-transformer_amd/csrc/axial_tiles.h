@@ -57,6 +57,8 @@ __device__ __forceinline__ void tile_load_pooled(float* lds, int stride, int lch
 }
 
 __device__ __forceinline__ float gate(const float* p) { return p ? *p : 1.f; }
+// gate of sequence `seq` (GatePtrs::stride == 0: the shared scalar)
+__device__ __forceinline__ float gate_at(const float* p, int stride, int seq) { return p ? p[(size_t)stride * seq] : 1.f; }
 
 
 }  // namespace medt

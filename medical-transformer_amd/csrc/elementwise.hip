@@ -379,6 +379,149 @@ int gate_sigmoid_bwd(const float* d_eff, const float* eff, float* dgate, hipStre
 }
 
 // --------------------------------------------------------------------------- //
+// AxialAttention_gated_data (reference lib/models/model_codes.py:316-443): four gates PER SEQUENCE from a two-layer MLP
+// on the sequence-averaged input (:371-380):  xn = mean_L x;  h = relu(W1 xn + b1);  o = relu(W2 h + b2);  s = sigmoid(o);
+// gate columns (qr, kr, sv, sve) = s[:, 0..3] (:376-379, 406-407, 420-421).  One wave per sequence.
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(64) void gate_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* __restrict__ xn,
+                                                          float* __restrict__ h, float* __restrict__ o,
+                                                          float* __restrict__ gates, int C, int H, int W, int axis) {
+    extern __shared__ float sm[];                      // xn[C] | h[C]
+    const int b = blockIdx.x, Bo = axis ? H : W, L = axis ? W : H, n = b / Bo, sq = b - n * Bo, HW = H * W;
+    const int pstride = axis ? 1 : W;
+    for (int c = threadIdx.x; c < C; c += 64) {
+        const float* p = x + ((size_t)n * C + c) * HW + (axis ? sq * W : sq);
+        float a = 0.f;
+        for (int i = 0; i < L; ++i) a += p[(size_t)i * pstride];
+        a *= 1.f / (float)L;
+        sm[c] = a;
+        xn[(size_t)b * C + c] = a;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 64) {
+        float a = b1[c];
+        for (int k = 0; k < C; ++k) a = fmaf(w1[(size_t)c * C + k], sm[k], a);
+        a = fmaxf(a, 0.f);
+        sm[C + c] = a;
+        h[(size_t)b * C + c] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float a = b2[threadIdx.x];
+        for (int k = 0; k < C; ++k) a = fmaf(w2[threadIdx.x * C + k], sm[C + k], a);
+        a = fmaxf(a, 0.f);
+        o[b * 4 + threadIdx.x] = a;
+        gates[b * 4 + threadIdx.x] = 1.f / (1.f + expf(-a));
+    }
+}
+
+int gate_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* xn, float* h,
+                 float* o, float* gates, int N, int C, int H, int W, int axis, hipStream_t s) {
+    const int nseq = N * (axis ? H : W);
+    hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3(nseq), dim3(64), 2 * C * sizeof(float), s, x, w1, b1, w2, b2, xn, h, o, gates,
+                       C, H, W, axis);
+    return launch_status("gate_mlp_fwd");
+}
+
+// per sequence: d_o = dgates * s(1-s) * [o > 0];  dh = (W2^T d_o) * [h > 0];  dxn = W1^T dh
+__global__ __launch_bounds__(64) void gate_mlp_bwd_seq_kernel(const float* __restrict__ dgates, const float* __restrict__ gates,
+                                                              const float* __restrict__ o, const float* __restrict__ h,
+                                                              const float* __restrict__ w1, const float* __restrict__ w2,
+                                                              float* __restrict__ d_o, float* __restrict__ dh,
+                                                              float* __restrict__ dxn, int C) {
+    extern __shared__ float sm[];                      // d_o[4] | dh[C]
+    const int b = blockIdx.x;
+    if (threadIdx.x < 4) {
+        const float sg = gates[b * 4 + threadIdx.x];
+        const float v = o[b * 4 + threadIdx.x] > 0.f ? dgates[b * 4 + threadIdx.x] * sg * (1.f - sg) : 0.f;
+        sm[threadIdx.x] = v;
+        d_o[b * 4 + threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a = fmaf(w2[k * C + c], sm[k], a);
+        a = h[(size_t)b * C + c] > 0.f ? a : 0.f;
+        sm[4 + c] = a;
+        dh[(size_t)b * C + c] = a;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 64) {
+        float a = 0.f;
+        for (int k = 0; k < C; ++k) a = fmaf(w1[(size_t)k * C + c], sm[4 + k], a);
+        dxn[(size_t)b * C + c] = a;
+    }
+}
+
+// parameter gradients (sums over the sequences): block r < C: row r of dW1 and db1[r]; block C + k: row k of dW2, db2[k]
+__global__ __launch_bounds__(64) void gate_mlp_bwd_param_kernel(const float* __restrict__ d_o, const float* __restrict__ dh,
+                                                                const float* __restrict__ h, const float* __restrict__ xn,
+                                                                float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2, int C,
+                                                                int nseq) {
+    const int r = blockIdx.x;
+    const bool first = r < C;
+    const int row = first ? r : r - C, stride = first ? C : 4;
+    const float* lhs = first ? dh : d_o;                 // [b][row]
+    const float* rhs = first ? xn : h;                   // [b][c]
+    for (int c = threadIdx.x; c < C; c += 64) {
+        float a = 0.f;
+        for (int b = 0; b < nseq; ++b) a = fmaf(lhs[(size_t)b * stride + row], rhs[(size_t)b * C + c], a);
+        (first ? dw1 : dw2)[(size_t)row * C + c] = a;
+    }
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int b = 0; b < nseq; ++b) a += lhs[(size_t)b * stride + row];
+        (first ? db1 : db2)[row] = a;
+    }
+}
+
+// dx[n, c, pos] = dxn[b(n, pos), c] / L   (backward of the sequence mean)
+__global__ __launch_bounds__(MEDT_THREADS) void gate_mlp_bwd_dx_kernel(const float* __restrict__ dxn, float* __restrict__ dx,
+                                                                       int C, int H, int W, int axis, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % W), hh = (int)((idx / W) % H), c = (int)((idx / ((size_t)W * H)) % C);
+    const int n = (int)(idx / ((size_t)W * H * C));
+    const int Bo = axis ? H : W, L = axis ? W : H, sq = axis ? hh : w;
+    dx[idx] = dxn[((size_t)n * Bo + sq) * C + c] * (1.f / (float)L);
+}
+
+int gate_mlp_bwd(const float* dgates, const float* gates, const float* o, const float* h, const float* xn, const float* w1,
+                 const float* w2, float* d_o, float* dh, float* dxn, float* dw1, float* db1, float* dw2, float* db2,
+                 float* dx, int N, int C, int H, int W, int axis, hipStream_t s) {
+    const int nseq = N * (axis ? H : W);
+    hipLaunchKernelGGL(gate_mlp_bwd_seq_kernel, dim3(nseq), dim3(64), (4 + C) * sizeof(float), s, dgates, gates, o, h, w1, w2,
+                       d_o, dh, dxn, C);
+    int rc = launch_status("gate_mlp_bwd_seq");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gate_mlp_bwd_param_kernel, dim3(C + 4), dim3(64), 0, s, d_o, dh, h, xn, dw1, db1, dw2, db2, C, nseq);
+    if ((rc = launch_status("gate_mlp_bwd_param"))) return rc;
+    const size_t total = (size_t)N * C * H * W;
+    hipLaunchKernelGGL(gate_mlp_bwd_dx_kernel, dim3(grid1d(total)), dim3(MEDT_THREADS), 0, s, dxn, dx, C, H, W, axis, total);
+    return launch_status("gate_mlp_bwd_dx");
+}
+
+// per-sequence gate gradients: sum over the heads, reorder (f_qr, f_kr, f_sve, f_sv) -> gate-tensor columns (qr, kr, sv, sve)
+__global__ __launch_bounds__(MEDT_THREADS) void gate_seq_reduce_kernel(const float* __restrict__ partials,
+                                                                       float* __restrict__ dgates, int nseq, int G) {
+    const int idx = blockIdx.x * MEDT_THREADS + threadIdx.x;
+    if (idx >= nseq * 4) return;
+    const int b = idx >> 2, col = idx & 3, k = col == 2 ? 3 : (col == 3 ? 2 : col);
+    float a = 0.f;
+    for (int g = 0; g < G; ++g) a += partials[((size_t)b * G + g) * 4 + k];
+    dgates[idx] = a;
+}
+
+int gate_seq_reduce(const float* partials, float* dgates, int nseq, int G, hipStream_t s) {
+    hipLaunchKernelGGL(gate_seq_reduce_kernel, dim3(grid1d((size_t)nseq * 4)), dim3(MEDT_THREADS), 0, s, partials, dgates, nseq, G);
+    return launch_status("gate_seq_reduce");
+}
+
+// --------------------------------------------------------------------------- //
 // Adam (torch.optim.Adam semantics, coupled L2 weight decay).  The step counter lives on the device so a
 // captured hipGraph replays correctly: adam_tick advances it and derives the bias corrections.
 //   state[0] = step, state[1] = 1 - b1^step, state[2] = 1 - b2^step

@@ -67,7 +67,8 @@ struct BwdWs {
         part_qb = c.take<float>((size_t)g.groups * g.tpg * 2 * g.C * 2);
         coef_qkv = c.take<float>((size_t)g.groups * 2 * g.C * 3);
         rel_part = c.take<float>(g.pos ? nblocks * 2 * g.gp * TL : 0);
-        gate_part = c.take<float>(g.pos ? nblocks * 4 : 0);
+        const size_t nseqh = (size_t)g.groups * g.spg * g.G;          // per-sequence gates: one row per (sequence, head)
+        gate_part = c.take<float>(g.pos ? (nblocks > nseqh ? nblocks : nseqh) * 4 : 0);
         dw_scratch = c.take<float>((size_t)conv2d_bwd_weight_splits(g.N, g.C, 2 * g.C, 1, g.H, g.W) * 2 * g.C * g.C);
         dy_masked = c.take<float>(out_relu ? (size_t)g.N * g.C * (g.H / stride) * (g.W / stride) : 0);
     }
@@ -75,13 +76,17 @@ struct BwdWs {
 
 // The gates the kernels multiply with: the stored scalars, or (gate_mode 1) their sigmoids computed into `eff`.
 static int effective_gates(const medt_axial_desc* d, const medt_axial_params* p, float* eff, hipStream_t s, GatePtrs* out) {
-    *out = GatePtrs{p->f_qr, p->f_kr, p->f_sve, p->f_sv};
+    *out = GatePtrs{p->f_qr, p->f_kr, p->f_sve, p->f_sv, 0};
     if (d->gate_mode == 0 || !p->f_qr) return MEDT_OK;
-    if (d->gate_mode != 1) { set_error("axial: gate_mode %d unsupported (0: raw, 1: sigmoid)", d->gate_mode); return MEDT_EUNSUPPORTED; }
+    if (d->gate_mode == 2) {      // f_qr = the (B*, 4) gate tensor, columns (qr, kr, sv, sve); the other pointers are ignored
+        *out = GatePtrs{p->f_qr, p->f_qr + 1, p->f_qr + 3, p->f_qr + 2, 4};
+        return MEDT_OK;
+    }
+    if (d->gate_mode != 1) { set_error("axial: gate_mode %d unsupported (0: raw, 1: sigmoid, 2: per sequence)", d->gate_mode); return MEDT_EUNSUPPORTED; }
     if (!p->f_kr || !p->f_sve || !p->f_sv) { set_error("axial: gate_mode 1 needs all four gates"); return MEDT_EINVAL; }
     int rc = gate_sigmoid_fwd(p->f_qr, p->f_kr, p->f_sve, p->f_sv, eff, s);
     if (rc) return rc;
-    *out = GatePtrs{eff, eff + 1, eff + 2, eff + 3};
+    *out = GatePtrs{eff, eff + 1, eff + 2, eff + 3, 0};
     return MEDT_OK;
 }
 
@@ -309,7 +314,9 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if (g.pos) {
         if (q) q->reduce.push_back(RJob{w.rel_part, gr->relative, (int)w.nblocks, 2 * g.gp * TL});
         else if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
-        if (gr->gates) {
+        if (gr->gates && d->gate_mode == 2) {
+            if ((rc = gate_seq_reduce(w.gate_part, gr->gates, g.groups * g.spg, g.G, s))) return rc;
+        } else if (gr->gates) {
             const bool sig = d->gate_mode == 1 && p->f_qr;
             if (q && !sig) q->reduce.push_back(RJob{w.gate_part, gr->gates, (int)w.nblocks, 4});
             else {
@@ -477,6 +484,25 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     }
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,
                              d->pad, 1, s, q);
+}
+
+int medt_gate_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* xn, float* h,
+                      float* o, float* gates, int N, int C, int H, int W, int axis, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !xn || !h || !o || !gates || N < 1 || C < 1 || C > 4096 || H < 1 || W < 1) {
+        set_error("gate_mlp fwd: bad arguments"); return MEDT_EINVAL;
+    }
+    return gate_mlp_fwd(x, w1, b1, w2, b2, xn, h, o, gates, N, C, H, W, axis ? 1 : 0, (hipStream_t)stream);
+}
+int medt_gate_mlp_bwd(const float* dgates, const float* gates, const float* o, const float* h, const float* xn,
+                      const float* w1, const float* w2, float* scratch, float* dw1, float* db1, float* dw2, float* db2,
+                      float* dx, int N, int C, int H, int W, int axis, void* stream) {
+    if (!dgates || !gates || !o || !h || !xn || !w1 || !w2 || !scratch || !dw1 || !db1 || !dw2 || !db2 || !dx) {
+        set_error("gate_mlp bwd: null pointer"); return MEDT_EINVAL;
+    }
+    const size_t nseq = (size_t)N * (axis ? H : W);
+    float *d_o = scratch, *dh = d_o + nseq * 4, *dxn = dh + nseq * C;        // scratch: nseq * (4 + 2C) floats
+    return gate_mlp_bwd(dgates, gates, o, h, xn, w1, w2, d_o, dh, dxn, dw1, db1, dw2, db2, dx, N, C, H, W, axis ? 1 : 0,
+                        (hipStream_t)stream);
 }
 
 int medt_up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, void* stream) {

@@ -104,6 +104,15 @@ int ce_bwd(const float* logits, const int64_t* target, const float* loss_out, co
 // gated_sig: eff[k] = sigmoid(*f[k]) (k: f_qr, f_kr, f_sve, f_sv);  dgate[k] = d_eff[k] * eff[k] * (1 - eff[k])
 int gate_sigmoid_fwd(const float* f_qr, const float* f_kr, const float* f_sve, const float* f_sv, float* eff, hipStream_t s);
 int gate_sigmoid_bwd(const float* d_eff, const float* eff, float* dgate, hipStream_t s);
+// gate_mode 2: per-sequence gate gradients [B*][G][4] (f_qr, f_kr, f_sve, f_sv) -> dgates [B*][4] in the (qr, kr, sv, sve)
+// column order of the gate tensor
+int gate_seq_reduce(const float* partials, float* dgates, int nseq, int G, hipStream_t s);
+// AxialAttention_gated_data's gate MLP (reference lib/models/model_codes.py:371-380) and its backward
+int gate_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* xn, float* h,
+                 float* o, float* gates, int N, int C, int H, int W, int axis, hipStream_t s);
+int gate_mlp_bwd(const float* dgates, const float* gates, const float* o, const float* h, const float* xn, const float* w1,
+                 const float* w2, float* d_o, float* dh, float* dxn, float* dw1, float* db1, float* dw2, float* db2,
+                 float* dx, int N, int C, int H, int W, int axis, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float b1, float b2,
               float eps, float wd, float gscale, hipStream_t s);
 
@@ -128,7 +137,8 @@ struct AxialGeom {
 int  axial_geom(const medt_axial_desc& d, AxialGeom* g);   // validates, returns MEDT_E*
 size_t axial_core_lds_bytes(const AxialGeom& g, bool backward);
 
-struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; };
+// stride 0: one scalar per gate; stride 4 (gate_mode 2, AxialAttention_gated_data): element [b*stride] belongs to sequence b
+struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; int stride; };
 
 // axial_fast.hip: 16-byte-LDS-read variants for has_pos && L % 4 == 0; return 1 when not applicable
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,

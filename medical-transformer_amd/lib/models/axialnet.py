@@ -58,6 +58,7 @@ class _AxialAttentionBase(nn.Module):
         if self._gated:
             for name, val in zip(("f_qr", "f_kr", "f_sve", "f_sv"), self._gate_init):
                 setattr(self, name, nn.Parameter(torch.tensor(val), requires_grad=False))
+        self._gate_modules(in_planes)         # (model_codes.AxialAttention_gated_data registers its gate MLP here)
         if pos:
             self.relative = nn.Parameter(torch.randn(self.group_planes * 2, kernel_size * 2 - 1), requires_grad=True)
             rows = torch.arange(kernel_size).unsqueeze(1)
@@ -66,6 +67,13 @@ class _AxialAttentionBase(nn.Module):
         if stride > 1:
             self.pooling = nn.AvgPool2d(stride, stride=stride)     # kept for module-tree parity; fused in the kernel
         self.reset_parameters()
+
+    def _gate_modules(self, in_planes):
+        pass
+
+    def _gates(self, x):
+        """(f_qr, f_kr, f_sve, f_sv) for medt_amd.axial_attention, or None."""
+        return (self.f_qr, self.f_kr, self.f_sve, self.f_sv) if self._gated else None
 
     def reset_parameters(self):
         self.qkv_transform.weight.data.normal_(0, math.sqrt(1. / self.in_planes))
@@ -80,7 +88,7 @@ class _AxialAttentionBase(nn.Module):
         if self._has_pos and L != self.kernel_size:
             # same failure class as the reference's einsum shape error (e.g. `logo` at 256)
             raise RuntimeError(f"axial attention built for sequence length {self.kernel_size}, got {L}")
-        gates = (self.f_qr, self.f_kr, self.f_sve, self.f_sv) if self._gated else None
+        gates = self._gates(x)
         return medt_amd.axial_attention(
             x, self.qkv_transform.weight, self.bn_qkv, self.bn_similarity, self.bn_output,
             self.relative if self._has_pos else None, gates, self.groups, self.width, self.stride,

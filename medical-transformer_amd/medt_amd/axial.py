@@ -154,7 +154,8 @@ class AxialAttentionFn(torch.autograd.Function):
                 need_tmp.append(k)
         want_gates = ctx.has_gates and any(ctx.needs_input_grad[9:13])
         gate_direct = False
-        if want_gates:
+        n_gate = f_qr.numel() if (ctx.has_gates and cfg.gate_mode == 2) else 4     # per-sequence gates: a (B*, 4) tensor
+        if want_gates and cfg.gate_mode != 2:
             gs = ctx.gate_slots
             if all(g_ is not None for g_ in gs) and all(ctx.needs_input_grad[9:13]) and \
                     all(gs[i + 1].view.data_ptr() == gs[i].view.data_ptr() + 4 for i in range(3)) and \
@@ -162,7 +163,7 @@ class AxialAttentionFn(torch.autograd.Function):
                 for g_ in gs:                                   # four adjacent 0-d slots == the ABI's float[4]
                     OPT.claim(g_)
                 gate_direct = True
-        tmp_sizes = [sizes[k] for k in need_tmp] + ([4] if (want_gates and not gate_direct) else [])
+        tmp_sizes = [sizes[k] for k in need_tmp] + ([n_gate] if (want_gates and not gate_direct) else [])
         if tmp_sizes:
             parts = list(torch.split(torch.empty((sum(tmp_sizes),), device=dev, dtype=torch.float32), tmp_sizes))
             for k, part in zip(need_tmp, parts):
@@ -190,7 +191,9 @@ class AxialAttentionFn(torch.autograd.Function):
                 q.hold(*parts)
         for slot, tmp in pend:
             OPT.accumulate(slot, tmp)
-        if want_gates and not gate_direct:
+        if want_gates and cfg.gate_mode == 2:
+            dg = [parts[-1].view_as(f_qr), None, None, None]
+        elif want_gates and not gate_direct:
             gg = parts[-1]
             dg = [gg[i].reshape(()) if ctx.needs_input_grad[9 + i] else None for i in range(4)]
         else:
@@ -206,6 +209,8 @@ def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: O
 
     gates = (f_qr, f_kr, f_sve, f_sv) 0-d tensors or None (ungated: all ones).
     gate_mode 1: sigmoid(f) multiplies (AxialAttention_gated_sig, reference lib/models/model_codes.py:215-313).
+    gate_mode 2: gates = (G, None, None, None) with G a (B*, 4) tensor of per-sequence gates, columns (qr, kr, sv, sve)
+    (AxialAttention_gated_data, :316-443; G comes from medt_amd.ops.gate_mlp).
     """
     cfg = AxialConfig(groups, 1 if width else 0, relative is not None, stride, bn_qkv, bn_similarity, bn_output,
                       bn_groups, bn_qkv.eps, _momentum(bn_qkv), out_relu, gate_mode)

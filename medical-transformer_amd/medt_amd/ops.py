@@ -212,6 +212,55 @@ def up2x_relu_add(x, skip=None, skip_sink=None):
 
 
 # --------------------------------------------------------------------------- #
+# gate network of AxialAttention_gated_data
+# --------------------------------------------------------------------------- #
+class GateMlpFn(torch.autograd.Function):
+    """(N,C,H,W) -> (B*, 4) per-sequence gates: sigmoid(relu(fcn2(relu(fcn1(mean over the sequence of x)))))
+    (reference lib/models/model_codes.py:371-380)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, axis):
+        _require_device(x)
+        lib = L.lib()
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        nseq = N * (H if axis else W)
+        dev = x.device
+        xn = torch.empty((nseq, Cc), device=dev, dtype=torch.float32)
+        h = torch.empty_like(xn)
+        o = torch.empty((nseq, 4), device=dev, dtype=torch.float32)
+        gates = torch.empty_like(o)
+        L.check(lib.medt_gate_mlp_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                      xn.data_ptr(), h.data_ptr(), o.data_ptr(), gates.data_ptr(), N, Cc, H, W, axis,
+                                      _stream()), "medt_gate_mlp_fwd")
+        ctx.save_for_backward(w1, w2, xn, h, o, gates)
+        ctx.geom = (N, Cc, H, W, axis)
+        return gates
+
+    @staticmethod
+    def backward(ctx, dgates):
+        lib = L.lib()
+        w1, w2, xn, h, o, gates = ctx.saved_tensors
+        N, Cc, H, W, axis = ctx.geom
+        dev = dgates.device
+        nseq = gates.shape[0]
+        dgates = dgates.contiguous()
+        scratch = torch.empty((nseq * (4 + 2 * Cc),), device=dev, dtype=torch.float32)
+        dw1, db1 = torch.empty_like(w1), torch.empty((Cc,), device=dev, dtype=torch.float32)
+        dw2, db2 = torch.empty_like(w2), torch.empty((4,), device=dev, dtype=torch.float32)
+        dx = torch.empty((N, Cc, H, W), device=dev, dtype=torch.float32)
+        L.check(lib.medt_gate_mlp_bwd(dgates.data_ptr(), gates.data_ptr(), o.data_ptr(), h.data_ptr(), xn.data_ptr(),
+                                      w1.data_ptr(), w2.data_ptr(), scratch.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                                      dw2.data_ptr(), db2.data_ptr(), dx.data_ptr(), N, Cc, H, W, axis, _stream()),
+                "medt_gate_mlp_bwd")
+        return dx, dw1, db1, dw2, db2, None
+
+
+def gate_mlp(x, fcn1, fcn2, width: bool):
+    return GateMlpFn.apply(x, fcn1.weight, fcn1.bias, fcn2.weight, fcn2.bias, 1 if width else 0)
+
+
+# --------------------------------------------------------------------------- #
 # LoGo patches
 # --------------------------------------------------------------------------- #
 def patch_gather(x, P=32, G=4):

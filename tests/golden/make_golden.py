@@ -145,6 +145,8 @@ def layer_fixture(kind, C, L, width, stride, N, seed):
     ax = ref_loader.load()
     if kind == "gatedsig":                           # experimental zoo, lib/models/model_codes.py:215-313
         cls = ref_loader.load_model_codes().AxialAttention_gated_sig
+    elif kind == "gateddata":                        # :316-443
+        cls = ref_loader.load_model_codes().AxialAttention_gated_data
     else:
         cls = {"dynamic": ax.AxialAttention_dynamic, "plain": ax.AxialAttention, "wopos": ax.AxialAttention_wopos}[kind]
     torch.manual_seed(seed)
@@ -207,6 +209,8 @@ def main():
     layer_cases = [
         ("gatedsig", 32, 16, True, 2, 2, 17),
         ("gatedsig", 16, 32, False, 1, 2, 18),
+        ("gateddata", 32, 16, True, 2, 2, 19),
+        ("gateddata", 16, 32, False, 1, 2, 20),
         ("dynamic", 16, 16, False, 1, 2, 11),
         ("dynamic", 32, 8, True, 2, 2, 12),
         ("plain", 16, 8, True, 1, 2, 13),

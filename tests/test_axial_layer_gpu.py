@@ -21,9 +21,9 @@ LAYER_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(H.GOLDE
 def make_layer(kind, C, L, width, stride, device):
     import lib as droplib
     ax = droplib.models.axialnet
-    if kind == "gatedsig":
+    if kind in ("gatedsig", "gateddata"):
         from lib.models import model_codes
-        cls = model_codes.AxialAttention_gated_sig
+        cls = model_codes.AxialAttention_gated_sig if kind == "gatedsig" else model_codes.AxialAttention_gated_data
     else:
         cls = {"dynamic": ax.AxialAttention_dynamic, "plain": ax.AxialAttention, "wopos": ax.AxialAttention_wopos}[kind]
     return cls(C, C, groups=8, kernel_size=L, stride=stride, width=width).to(device)
@@ -51,7 +51,7 @@ def run_case(layer, st, x, dout, kind, width, stride, device, training=True, bn_
     ost = O.clone_state({("m." + k): v for k, v in st.items()}, torch.float64, requires_grad=True)
     xo = x.double().requires_grad_(True)
     yo = O.axial_attention(xo, ost, "m", width, stride, training, bn_groups,
-                           gate_mode="sigmoid" if kind == "gatedsig" else "raw")
+                           gate_mode={"gatedsig": "sigmoid", "gateddata": "data"}.get(kind, "raw"))
     (yo * dout.double()).sum().backward()
     want = {"y": yo.detach(), "dx": xo.grad}
     for k, _ in layer.named_parameters():
@@ -94,6 +94,9 @@ CASES = [
     ("wopos", 128, 2, True, 2, 4, 2),
     ("gatedsig", 16, 64, True, 1, 2, 8),        # model_codes.AxialAttention_gated_sig: sigmoid(f) gates
     ("gatedsig", 64, 16, False, 2, 2, 16),
+    ("gateddata", 16, 64, True, 1, 2, 8),       # model_codes.AxialAttention_gated_data: per-sequence gates from an MLP
+    ("gateddata", 32, 32, False, 2, 2, 32),
+    ("gateddata", 128, 8, True, 1, 2, 8),
     ("dynamic", 16, 24, True, 1, 2, 5),         # non power-of-two length, ragged tile
     ("wopos", 16, 12, False, 1, 3, 7),
 ]

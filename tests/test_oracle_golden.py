@@ -40,7 +40,7 @@ def test_layer_oracle_matches_reference_fixture(fn):
     x = torch.from_numpy(fx["x"]).double()
     # eval
     st_e = O.clone_state(st, torch.float64)
-    gm = "sigmoid" if fn.split("_")[1] == "gatedsig" else "raw"
+    gm = {"gatedsig": "sigmoid", "gateddata": "data"}.get(fn.split("_")[1], "raw")
     out = O.axial_attention(x, st_e, "m", bool(width), stride, training=False, gate_mode=gm)
     assert H.rel_err(out, fx["out_eval"]) < 1e-10
     # train: forward, backward, running stats

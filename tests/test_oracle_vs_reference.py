@@ -88,5 +88,14 @@ def test_gated_sig_module_surface_matches_reference():
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k                # same registration order -> same RNG stream -> same init
     assert [(k, p.requires_grad) for k, p in a.named_parameters()] == [(k, p.requires_grad) for k, p in b.named_parameters()]
-    with pytest.raises(NotImplementedError):
-        model_codes.AxialAttention_gated_data(32, 32)
+    torch.manual_seed(10)
+    c = mc.AxialAttention_gated_data(32, 32, groups=8, kernel_size=16, stride=1, width=False)
+    torch.manual_seed(10)
+    d = model_codes.AxialAttention_gated_data(32, 32, groups=8, kernel_size=16, stride=1, width=False)
+    sc, sd = c.state_dict(), d.state_dict()
+    assert list(sc.keys()) == list(sd.keys())              # fcn1 / fcn2 sit between bn_output and relative, as in the reference
+    for k in sc:
+        assert torch.equal(sc[k], sd[k]), k
+    blk = model_codes.AxialBlock_gated_data(32, 16, kernel_size=16)
+    ref_blk = mc.AxialBlock_gated_data(32, 16, kernel_size=16)
+    assert list(blk.state_dict().keys()) == list(ref_blk.state_dict().keys())
