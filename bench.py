@@ -142,10 +142,10 @@ def cpu_baseline_leg(steps=8):
     import lib as droplib
     O.set_fast_bn(True)                                  # aten's fused BatchNorm, like the reference's nn.BatchNorm
     torch.manual_seed(3000)
-    # Host threads: MEDT_CPU_THREADS, default 8 -- the fastest setting measured on the 256-core MI355X host
-    # (s/step at 8/16/32/64 threads: 1.68 / 1.96 / 2.79 / 6.37; all 256 cores did not finish in 20 minutes):
-    # the reference's tensors are a few MB, more OpenMP threads only add synchronisation.
-    cores = min(os.cpu_count() or 1, int(os.environ.get("MEDT_CPU_THREADS", "8")))
+    # Host threads: MEDT_CPU_THREADS, default 16 -- the fastest setting in the sweeps on the 256-core MI355X hosts
+    # (profiles/r02_cpu_thread_sweep.json, s/step at 8/16/32/64 threads: 2.04 / 1.89 / 2.73 / 5.95; round 1's box:
+    # 1.68 / 1.96 / 2.79 / 6.37): the reference's tensors are a few MB, more OpenMP threads only add synchronisation.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("MEDT_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     log(f"cpu baseline: {cores} threads of {os.cpu_count()} cores")
     sd = droplib.models.axialnet.MedT(img_size=IMG, imgchan=3).state_dict()

@@ -25,6 +25,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (<= 16 tiles) it is 2-4x slower, and for 1x1 convolutions it ties.  Hence:
 bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions) {
     static const bool off = [] { const char* e = getenv("MEDT_DISABLE_MFMA"); return e && e[0] == '1'; }();
+    // A/B switch (scripts/conv_ab.py -> profiles/r02_conv_ab.json): the matrix-core tile kernel wherever it is legal
+    static const bool force = [] { const char* e = getenv("MEDT_FORCE_MFMA"); return e && e[0] == '1'; }();
+    if (force && !off) return (K == 1 || K == 3) && (stride == 1 || stride == 2);
     const long tiles = ((positions + 63) / 64) * ((Cout + 63) / 64);
     if (off || Cout < 32 || Cin * K * K < 256 || (stride != 1 && stride != 2)) return false;
     if (K == 3 && tiles >= 128) return true;

@@ -1,16 +1,42 @@
 #!/bin/bash
-# Runs ON the GPU box (gpurun): the bench line, rocprofv3 kernel statistics of the same commands, and the PMC passes
-# behind profiles/roofline_traffic.json and profiles/r01_attn_fwd_pmc.json.  Outputs land in gpurun_out/profiles_raw/.
+# Runs ON the GPU box (gpurun): the bench lines, rocprofv3 kernel statistics of the same commands, the PMC passes behind
+# profiles/roofline_traffic.json and profiles/rNN_attn_pmc.json, the grouped weight-gradient MFMA/VALU A/B, the host
+# thread sweep of the CPU baseline and the parity report.  Outputs land in gpurun_out/profiles_raw/.
+# (counter passes: --pmc with --kernel-trace only, one counter group per run -- MI355X_MICROARCH.md)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_raw
 rm -rf $O && mkdir -p $O
-timeout 400 python bench.py 2>$O/bench.err | tail -1 > $O/bench_line.json
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python bench.py --no-cpu-baseline > $O/bench_prof.log 2>&1
+timeout 500 python bench.py 2>$O/bench.err | tail -1 > $O/bench_line.json
+timeout 300 python bench.py --model gatedaxialunet --batch 8 --dtype bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_gated_bf16.json
+timeout 300 python bench.py --model gatedaxialunet --batch 8 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/bench_line_gated_f32.json
+timeout 300 python bench.py --model MedT --imgsize 256 --batch 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/bench_line_medt256.json
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python bench.py --no-cpu-baseline --no-roofline > $O/bench_prof.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -- python bench.py --roofline-only > $O/roofline_prof.log 2>&1
+MEDT_ROOF_AXIS=h timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline_h -- python bench.py --roofline-only > $O/roofline_h_prof.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline_bf16 -- python bench.py --roofline-only --dtype bf16 > $O/roofline_bf16_prof.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --roofline-only > $O/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --roofline-only > $O/pmc_write.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -- python bench.py --roofline-only > $O/pmc_sq1.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2 -- python bench.py --roofline-only > $O/pmc_sq2.log 2>&1
+# grouped weight gradients: MFMA 64x64 tiles (default) vs the 4x4-register-tile VALU body, and the deferral itself
+for v in "MFMA:" "VALU:MEDT_WGRAD_VALU=1" "IMMEDIATE:MEDT_DEFER=0" "ONE_STREAM:MEDT_TWO_STREAMS=0" "NO_SINKS:MEDT_GRAD_SINKS=0"; do
+  name=${v%%:*}; envs=${v#*:}
+  echo -n "$name " >> $O/ab.txt
+  env $envs timeout 200 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $O/ab.txt
+done
+timeout 600 python scripts/conv_ab.py > $O/conv_ab.json 2>$O/conv_ab.err
+# host threads of the CPU baseline (the oracle on this box's cores): s/step at 8 / 16 / 32 / 64 threads
+for t in 8 16 32 64; do
+  echo -n "$t " >> $O/cpu_threads.txt
+  MEDT_CPU_THREADS=$t MEDT_CPU_STEPS=3 timeout 300 python -c "
+import json, sys
+sys.argv = ['bench.py']
+import bench
+print(json.dumps(bench.cpu_baseline_leg(steps=3)))" 2>/dev/null | tail -1 >> $O/cpu_threads.txt
+done
+# parity report (product error / reference fp32 noise per gradient tensor, excluded-pixel counts, bf16 errors)
+timeout 600 python -m pytest tests/test_model_gpu.py tests/test_dist_gpu.py -m gpu -q -s 2>&1 | grep -E "product error|label map|rel err|worst gradient|passed|failed" > $O/parity_report.txt
+cp gpurun_out/dist_forced_rccl.log $O/ 2>/dev/null
 find $O -name "*kernel_trace.csv" -path "*pmc*" -delete
 find $O -name "*kernel_trace.csv" -size +20M -delete
-ls -R $O | head -40
+ls -R $O | head -60
