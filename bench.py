@@ -120,8 +120,13 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "launch_ms": t_main * 1e3, "valu_tflops": flops_main / t_main / 1e12,
-            "stats_kernel": {"achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
+            "stats_kernel": {"kernel": "sim_stats_rows_kernel" if width else "sim_stats_kernel",
+                             "achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
                              "bytes_per_launch": bytes_stats, "frac": bytes_stats / t_stats / 1e9 / HBM_PEAK_GBPS},
+            # SURVEY.md 8(d) "train fwd" = statistics pass + main pass: 6*C*e*M over both launches
+            "train_fwd_core": {"bytes_per_launch": bytes_main + 2 * bytes_stats,
+                               "achieved": (bytes_main + 2 * bytes_stats) / (t_main + t_stats) / 1e9,
+                               "frac": (bytes_main + 2 * bytes_stats) / (t_main + t_stats) / 1e9 / HBM_PEAK_GBPS},
             "bwd_core": {"kernels": "attn_bwd_stats_kernel + attn_bwd_kernel", "bytes_per_launch": 10 * C * e * M,
                          "achieved": 10 * C * e * M / t_bwd / 1e9, "frac": 10 * C * e * M / t_bwd / 1e9 / HBM_PEAK_GBPS,
                          "launch_ms": t_bwd * 1e3}}

@@ -149,9 +149,10 @@ int medt_axial_layer_bwd(const medt_axial_desc*, const medt_axial_params*, const
                          void* workspace, size_t workspace_bytes, void* stream);
 /* y: forward output, needed iff out_relu. */
 
-/* The two L x L stages on their own, for benchmarks / profiling (bench.py's roofline leg).
- * qkv_raw -> [logit statistics partials] and qkv_raw -> stacked, lse, given the BN
- * scale/shift already in saved->stats.  Same kernels the layer entry points launch. */
+/* The stages of the attention core on their own, for benchmarks / profiling (bench.py's roofline legs): the bn_similarity
+ * statistics pass (closed form: one read of q,k) and the fused logits + softmax + sv|sve pass, given the BN scale/shift
+ * already in saved->stats.  Same kernels the layer entry points launch.  Call medt_axial_layer_fwd once with the same
+ * descriptor and workspace first: it leaves the sliding-window tables the statistics kernel reads in the workspace. */
 int medt_axial_core_stats(const medt_axial_desc*, const medt_axial_params*, const medt_axial_saved*,
                           void* workspace, size_t workspace_bytes, void* stream);
 int medt_axial_core_fwd(const medt_axial_desc*, const medt_axial_params*, const medt_axial_saved*,

@@ -33,18 +33,6 @@ int sim_stats_parts(const AxialGeom& g) { return cdiv(g.spg, 64); }
 // carry the factor 2 of the symmetric double sum.  side 0 = q rows of `relative`, 1 = k rows.
 int sim_tables_blocks(const AxialGeom& g) { return g.pos ? 2 * (g.hq + npairs(g.hq)) : 0; }
 
-__global__ __launch_bounds__(64) void sim_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
-                                                        int HQ, int L) {
-    __shared__ float lds[512];
-    sim_tables_block(blockIdx.x, relative, tables, HQ, L, lds);
-}
-
-int sim_tables(const AxialGeom& g, const float* relative, float* tables, hipStream_t s) {
-    if (!g.pos) return MEDT_OK;
-    hipLaunchKernelGGL(sim_tables_kernel, dim3(sim_tables_blocks(g)), dim3(64), 0, s, relative, tables, g.hq, g.L);
-    return launch_status("sim_tables");
-}
-
 template <int HQ, bool POS, int AXIS>
 __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
                                                                  BnStats qs, const float* __restrict__ tables,

@@ -142,7 +142,7 @@ int medt_axial_core_stats(const medt_axial_desc* d, const medt_axial_params* p, 
     LayerStats st(sv->stats, g);
     GatePtrs gates;
     if ((rc = effective_gates(d, p, w.gate_eff, (hipStream_t)stream, &gates))) return rc;
-    if ((rc = sim_tables(g, p->relative, w.tables, (hipStream_t)stream))) return rc;
+    // (the sliding-window tables are the ones the preceding medt_axial_layer_fwd left in this workspace)
     return axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, (hipStream_t)stream);
 }
 

@@ -173,12 +173,11 @@ bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernel
 
 // axial_stats.hip: bn_similarity batch statistics in closed form (one read of q and k, no L x L pass).
 // partials [group][sim_stats_parts()][SC][2]; tables: sim_tables_floats() floats, the sliding-window sums of the
-// relative table.  They are built by sim_tables(), or by sim_tables_blocks() extra blocks appended to the bn_qkv
-// bn_finalize launch that precedes the statistics kernel in the layer (no launch of their own).
+// relative table, built by sim_tables_blocks() extra blocks appended to the bn_qkv bn_finalize launch that precedes the
+// statistics kernel in the layer (no launch of their own).
 size_t sim_tables_floats(const AxialGeom& g);
 int sim_tables_blocks(const AxialGeom& g);
 int sim_stats_parts(const AxialGeom& g);
-int sim_tables(const AxialGeom& g, const float* relative, float* tables, hipStream_t s);
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
                       const float* tables, float* partials, hipStream_t s);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)

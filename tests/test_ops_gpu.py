@@ -260,3 +260,14 @@ def test_batchnorm_momentum_none_is_refused(device):
     bn = nn.BatchNorm2d(4, momentum=None).to(device)
     with pytest.raises(medt_amd.MedtError):
         ops.conv_block(torch.randn(2, 3, 4, 4, device=device), conv, bn, training=True)
+
+
+def test_single_value_training_batchnorm_is_refused(device):
+    """nn.BatchNorm raises "Expected more than 1 value per channel when training"; so does the conv + BN block."""
+    import medt_amd
+    from medt_amd import ops
+    conv = nn.Conv2d(3, 4, 1, bias=False).to(device)
+    bn = nn.BatchNorm2d(4).to(device)
+    with pytest.raises(medt_amd.MedtError):
+        ops.conv_block(torch.randn(1, 3, 1, 1, device=device), conv, bn, training=True)
+    ops.conv_block(torch.randn(1, 3, 1, 1, device=device), conv, bn, training=False)      # eval: fine
