@@ -279,8 +279,7 @@ struct BwdLds {
     static constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = POS ? 2 * GP : GP;
     float *reg, *red, *tq, *tk, *tv, *dtq, *dtk, *dtv, *g2, *g3;
     int RS, R2, R3, TL;
-    __device__ BwdLds(float* smem, const AxialGeom& g) {
-        const int L = g.L;
+    __device__ BwdLds(float* smem, const AxialGeom& g, int L) {
         TL = 2 * L - 1;
         RS = (NCH + 1) * L + 1;
         R2 = NCH * L + 1;
@@ -305,9 +304,9 @@ __device__ __forceinline__ void bwd_stage(const AxialGeom& g, BwdLds<GP, POS>& S
                                           const float* __restrict__ qkv_raw, const BnStats& qs,
                                           const float* __restrict__ relative, const float* __restrict__ stacked,
                                           const float* __restrict__ lse, const float* __restrict__ dy,
-                                          const float* __restrict__ out_coef, int pool, float (&rawv)[2 * GP]) {
+                                          const float* __restrict__ out_coef, int pool, float (&rawv)[2 * GP], int L) {
     constexpr int HQ = GP / 2, NCH = 2 * GP, OCG = POS ? 2 * GP : GP;
-    const int L = g.L, TL = S.TL;
+    const int TL = S.TL;
     tile_load<AXIS>(S.reg, S.RS, 0, qkv_raw, 2 * g.C, hg * NCH, NCH, t, g.bf16);
     tile_load<AXIS>(S.g2, S.R2, 0, stacked, g.OC, hg * OCG, OCG, t, g.bf16);
     tile_load_pooled<AXIS>(S.g3, S.R3, 0, dy, g.C, hg * GP, GP, g.H, pool, t);
@@ -379,19 +378,21 @@ struct PairTerms {
 // --------------------------------------------------------------------------- //
 // backward pass A: sum over (b,i,j) of dZ * {1, S_qk, S_qr, S_kr} per head
 // --------------------------------------------------------------------------- //
-template <int GP, bool POS, int AXIS>
+// LC: compile-time sequence length (0 = runtime g.L): index arithmetic folds into immediates and the sweeps unroll
+template <int GP, bool POS, int AXIS, int LC = 0>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_stats_kernel(
     AxialGeom g, const float* __restrict__ qkv_raw, BnStats qs, BnStats ss, const float* __restrict__ relative,
     GatePtrs gates, const float* __restrict__ stacked, const float* __restrict__ lse, const float* __restrict__ dy,
     const float* __restrict__ out_coef, int pool, float* __restrict__ partials) {
     constexpr int HQ = GP / 2, NCH = 2 * GP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    BwdLds<GP, POS> S(smem, g);
-    const int L = g.L, TL = S.TL;
+    const int L = LC ? LC : g.L;
+    BwdLds<GP, POS> S(smem, g, L);
+    const int TL = S.TL;
     const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
     float rawv[NCH];
-    bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv);
+    bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv, L);
     const int gseq = t.seq0 + min((int)threadIdx.x / L, t.nseq - 1);              // this thread's sequence (per-sequence gates)
     const float f_qr = gate_at(gates.f_qr, gates.stride, gseq), f_kr = gate_at(gates.f_kr, gates.stride, gseq);
     const float f_sve = gate_at(gates.f_sve, gates.stride, gseq), f_sv = gate_at(gates.f_sv, gates.stride, gseq);
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_stats_kernel(
         const float lse_i = S.g3[ls * S.R3 + GP * L + i], delta = S.g3[ls * S.R3 + (GP + 1) * L + i];
         const float* kp = S.reg + ls * S.RS + HQ * L;
         const float* vp = S.reg + ls * S.RS + GP * L;
+#pragma unroll 4
         for (int j = 0; j < L; ++j) {
             const int d = i - j + L - 1;
             float tqk = 0.f, rq = 0.f, rk = 0.f;
@@ -519,7 +521,7 @@ int axial_sim_bwd_finalize(const AxialGeom& g, const float* partials, BnStats si
 // --------------------------------------------------------------------------- //
 // backward pass B: dq (row-oriented), dk / dv (column-oriented), table and gate gradients
 // --------------------------------------------------------------------------- //
-template <int GP, bool POS, int AXIS>
+template <int GP, bool POS, int AXIS, int LC = 0>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
     AxialGeom g, const float* __restrict__ qkv_raw, BnStats qs, BnStats ss, const float* __restrict__ sim_coef,
     const float* __restrict__ relative, GatePtrs gates, const float* __restrict__ stacked,
@@ -528,14 +530,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
     float* __restrict__ gate_partials) {
     constexpr int HQ = GP / 2, NCH = 2 * GP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    BwdLds<GP, POS> S(smem, g);
-    const int L = g.L, TL = S.TL;
+    const int L = LC ? LC : g.L;
+    BwdLds<GP, POS> S(smem, g, L);
+    const int TL = S.TL;
     const int grp = blockIdx.x / g.tpg, tile = blockIdx.x - grp * g.tpg, hg = blockIdx.y;
     TileCtx t{L, g.Bo, g.W, g.HW, grp * g.spg + tile * g.S_T, min(g.S_T, g.spg - tile * g.S_T)};
     if (POS)
         for (int e = threadIdx.x; e < NCH * TL; e += MEDT_THREADS) S.dtq[e] = 0.f;      // dtq|dtk|dtv contiguous
     float rawv[NCH];
-    bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv);
+    bwd_stage<GP, POS, AXIS>(g, S, t, grp, hg, qkv_raw, qs, relative, stacked, lse, dy, out_coef, pool, rawv, L);
     const int gseq = t.seq0 + min((int)threadIdx.x / L, t.nseq - 1);              // this thread's sequence (per-sequence gates)
     const float f_qr = gate_at(gates.f_qr, gates.stride, gseq), f_kr = gate_at(gates.f_kr, gates.stride, gseq);
     const float f_sve = gate_at(gates.f_sve, gates.stride, gseq), f_sv = gate_at(gates.f_sv, gates.stride, gseq);
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
                 av_hi[c] = av_lo[c] = 0.f;
                 dv[c] = 0.f;
             }
+#pragma unroll 2
             for (int i = 0; i < L; ++i) {
                 const int j = (i - dl) & Lm;
                 const bool hi = i >= dl;
@@ -871,10 +875,32 @@ int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStat
     MEDT_DISPATCH(attn_fwd_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials);
 }
 
+// compile-time-L instantiations of the two backward passes (position-encoded layers, L = 16 / 32 / 64)
+#define MEDT_LC_CASE(KERNEL, GPv, AXv, LCv, ...) \
+    case (GPv * 2 + AXv) * 256 + LCv: hipLaunchKernelGGL((KERNEL<GPv, true, AXv, LCv>), grid, block, lds, s, __VA_ARGS__); break;
+#define MEDT_LC_L(KERNEL, GPv, AXv, ...) \
+    MEDT_LC_CASE(KERNEL, GPv, AXv, 16, __VA_ARGS__) MEDT_LC_CASE(KERNEL, GPv, AXv, 32, __VA_ARGS__) MEDT_LC_CASE(KERNEL, GPv, AXv, 64, __VA_ARGS__)
+#define MEDT_DISPATCH_LC(KERNEL, ...)                                                                        \
+    do {                                                                                                     \
+        if (g.pos && (g.L == 16 || g.L == 32 || g.L == 64) && lds <= 160 * 1024) {                          \
+            const dim3 grid(g.groups * g.tpg, g.G), block(MEDT_THREADS);                                    \
+            switch ((g.gp * 2 + g.axis) * 256 + g.L) {                                                      \
+                MEDT_LC_L(KERNEL, 2, 0, __VA_ARGS__) MEDT_LC_L(KERNEL, 2, 1, __VA_ARGS__)                    \
+                MEDT_LC_L(KERNEL, 4, 0, __VA_ARGS__) MEDT_LC_L(KERNEL, 4, 1, __VA_ARGS__)                    \
+                MEDT_LC_L(KERNEL, 8, 0, __VA_ARGS__) MEDT_LC_L(KERNEL, 8, 1, __VA_ARGS__)                    \
+                MEDT_LC_L(KERNEL, 16, 0, __VA_ARGS__) MEDT_LC_L(KERNEL, 16, 1, __VA_ARGS__)                  \
+                default: set_error(#KERNEL ": no compile-time-L instantiation"); return MEDT_EUNSUPPORTED;   \
+            }                                                                                                \
+            return launch_status(#KERNEL);                                                                   \
+        }                                                                                                    \
+    } while (0)
+
 int axial_attn_bwd_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                          GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* partials, hipStream_t s) {
     const size_t lds = axial_core_lds_bytes(g, true);
+    MEDT_DISPATCH_LC(attn_bwd_stats_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, dy, out_coef, stride,
+                     partials);
     MEDT_DISPATCH(attn_bwd_stats_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, dy, out_coef, stride,
                   partials);
 }
@@ -884,6 +910,8 @@ int axial_attn_bwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStat
                    const float* out_coef, int stride, float* dqkv, float* qkv_partials, float* rel_partials,
                    float* gate_partials, hipStream_t s) {
     const size_t lds = axial_core_lds_bytes(g, true);
+    MEDT_DISPATCH_LC(attn_bwd_kernel, g, qkv_raw, qkv, sim, sim_coef, relative, gates, stacked, lse, dy, out_coef, stride,
+                     dqkv, qkv_partials, rel_partials, gate_partials);
     MEDT_DISPATCH(attn_bwd_kernel, g, qkv_raw, qkv, sim, sim_coef, relative, gates, stacked, lse, dy, out_coef, stride,
                   dqkv, qkv_partials, rel_partials, gate_partials);
 }
