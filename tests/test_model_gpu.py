@@ -194,6 +194,51 @@ def test_baseline_batch_sizes_evalgrad_vs_oracle(name, S, N, bf16, device):
     print(f"  worst gradient rel err {worst:.2e}")
 
 
+def test_training_trajectory_vs_oracle(device):
+    """Three optimisation steps of the reference's loop (train.py:140,156-161: forward, LogNLLLoss, backward, Adam with
+    lr 1e-3 / weight_decay 1e-5) through the hipGraph-replayed product step against the fp64 oracle driving
+    oracle.adam_step: the loss of every step and the BatchNorm running statistics after the last one.  (Weights are not
+    compared element-wise: Adam turns the rounding noise of a near-zero gradient into a +-lr step.)"""
+    import medt_amd
+    from medt_amd.optim import FlatAdam
+    from medt_amd.trainer import TrainStep
+    name, S, N, STEPS = "gatedaxialunet", 64, 2, 3
+    model = build(name, S, device)
+    model.train()
+    st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}        # the factory's own initialisation
+    x, y = H.seeded_input(81, N, 3, S)
+    opt = FlatAdam(list(model.parameters()), lr=1e-3, weight_decay=1e-5)
+    step = TrainStep(model, opt, medt_amd.cross_entropy, use_graph=True, warmup=2)
+    losses = [step(x.to(device), y.to(device)).item() for _ in range(STEPS)]
+    # oracle: same loop in float64; parameters that receive a gradient are updated, the frozen gates are not
+    ost = O.clone_state(st, torch.float64)
+    train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
+    mom = {}
+    want = []
+    for t in range(1, STEPS + 1):
+        leaf = {k: (v.clone().requires_grad_(True) if k in train_keys else v) for k, v in ost.items()}
+        out = O.forward(name, x.double(), leaf, True)
+        loss = O.log_nll_loss(out, y)
+        loss.backward()
+        want.append(loss.item())
+        for k in ost:
+            if k in train_keys and leaf[k].grad is not None:
+                m, v = mom.get(k, (torch.zeros_like(ost[k]), torch.zeros_like(ost[k])))
+                pnew, m, v = O.adam_step(ost[k], leaf[k].grad, m, v, t)
+                ost[k], mom[k] = pnew.detach(), (m, v)
+            else:
+                ost[k] = leaf[k].detach()                    # buffers (running statistics) as updated by the forward
+    for a, b in zip(losses, want):
+        assert abs(a - b) <= 2e-3 * abs(b), (losses, want)
+    sd = model.state_dict()
+    # (shallow layers only: the deep ones normalise over 32-value populations whose statistics follow every rounding)
+    for k in ("bn1.running_mean", "bn2.running_var", "layer1.0.hight_block.bn_similarity.running_var",
+              "layer1.0.hight_block.bn_qkv.running_mean"):
+        assert H.rel_err(sd[k], ost[k]) < 3e-2, k          # (weights have moved by up to 3 lr-sized Adam steps)
+    assert int(sd["bn1.num_batches_tracked"].item()) == STEPS
+    print(f"trajectory: product losses {losses} vs oracle {want}")
+
+
 def test_graphed_train_step_equals_eager(device):
     """The hipGraph-replayed step (trainer.TrainStep) IS the eager step: the warm-up steps before capture are rolled back
     (weights, Adam state, BatchNorm running statistics, num_batches_tracked), so capture + N replays perform exactly N
