@@ -184,9 +184,105 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
     }
 }
 
+// Few positions, many channels (the 4x4 / 2x2 maps of the deep LoGo layers, decoder1_p): the lanes of the kernel above
+// would each walk all Cout output channels serially -- a chain of Cout/4 dependent global round trips (round 2: 78 us
+// for decoder1_p's 67 MFLOP).  Here a workgroup owns 64 positions, its four waves split the o-contraction and combine
+// through LDS (fixed order), and the loop keeps 8-16 channels' loads in flight.
+template <int K, int CT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
+    const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int H, int W,
+    int Cout, int Ho, int Wo, int stride, int pad, const float* __restrict__ add) {
+    constexpr int KK = K * K;
+    __shared__ float red[3][CT][64];
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CT][KK]: this workgroup's weight slice
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int HW = H * W;
+    const long q = (long)blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.y * CT;
+    for (int e = threadIdx.x; e < Cout * CT * KK; e += MEDT_THREADS) {
+        const int o = e / (CT * KK), r = e - o * (CT * KK);
+        wl[e] = w[((size_t)o * Cin + c0) * KK + r];
+    }
+    const bool ok = q < (long)N * HW;
+    const int n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
+    const int h = p / W, ww = p - h * W;
+    int off[KK];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int hh = h + pad - kh, wq = ww + pad - kw;
+            int o = -1;
+            if (ok && hh >= 0 && wq >= 0 && hh % stride == 0 && wq % stride == 0) {
+                const int ho = hh / stride, wo = wq / stride;
+                if (ho < Ho && wo < Wo) o = ho * Wo + wo;
+            }
+            off[kh * K + kw] = o;
+        }
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
+    const int ob = (Cout * wv) / 4, oe = (Cout * (wv + 1)) / 4;
+    __syncthreads();
+#pragma unroll K == 1 ? 16 : 4
+    for (int o = ob; o < oe; ++o) {
+        float dv[KK];
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {                               // unconditional load, then select: no branch per tap
+            const float v = dyn[(size_t)o * Ho * Wo + max(off[t], 0)];
+            dv[t] = off[t] >= 0 ? v : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float* wp = wl + (o * CT + c) * KK;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) red[wv - 1][c][lane] = acc[c];
+    }
+    __syncthreads();
+    if (wv == 0 && ok) {
+        const size_t o0 = ((size_t)n * Cin + c0) * HW + p;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float v = acc[c] + (red[0][c][lane] + red[1][c][lane]) + red[2][c][lane];
+            dx[o0 + (size_t)c * HW] = add ? v + add[o0 + (size_t)c * HW] : v;
+        }
+    }
+}
+
+static bool conv_bwd_data_ws_enabled() {
+    static const bool on = [] { const char* e = getenv("MEDT_DGRAD_WS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int K>
 static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int Ho,
                              int Wo, int stride, int pad, hipStream_t s, const float* add) {
+    if constexpr (K != 7) {
+        if ((long)N * H * W <= 4096 && Cout >= 64 && conv_bwd_data_ws_enabled()) {
+            const unsigned g64 = (unsigned)(((long)N * H * W + 63) / 64);
+#define MEDT_LAUNCH_WS(CT)                                                                                           \
+    hipLaunchKernelGGL((conv2d_bwd_data_ws_kernel<K, CT>), dim3(g64, Cin / CT), dim3(MEDT_THREADS),                   \
+                       (size_t)Cout * CT * K * K * sizeof(float), s, dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, add)
+            int ct = pick_tile(Cin, K == 1 ? 8 : 4, g64);
+            while (ct > 1 && (size_t)Cout * ct * K * K * sizeof(float) > 48 * 1024) ct >>= 1;
+            if ((size_t)Cout * ct * K * K * sizeof(float) > 48 * 1024) ct = 0;          // does not fit: the kernel below
+            switch (ct) {
+                case 0: break;
+                case 8: if constexpr (K == 1) { MEDT_LAUNCH_WS(8); } break;
+                case 4: MEDT_LAUNCH_WS(4); break;
+                case 2: MEDT_LAUNCH_WS(2); break;
+                default: MEDT_LAUNCH_WS(1); break;
+            }
+#undef MEDT_LAUNCH_WS
+            if (ct) return launch_status("conv2d_bwd_data_ws");
+        }
+    }
     const unsigned gx = (unsigned)(((long)N * H * W + MEDT_THREADS - 1) / MEDT_THREADS);
 #define MEDT_LAUNCH_BWD(CT)                                                                                       \
     hipLaunchKernelGGL((conv2d_bwd_data_kernel<K, CT>), dim3(gx, Cin / CT), dim3(MEDT_THREADS), 0, s, dy, w, dx, N, Cin, \

@@ -150,6 +150,222 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     }
 }
 
+// --------------------------------------------------------------------------- //
+// 3x3 / stride 1 / pad 1 on 16-wide maps: MedT's local stem (conv2_p 64->128, conv3_p 128->64 on the 16x16 maps of the
+// 32-px patches -- 53 % of the model's FLOPs), forward, backward-data (flipped weights) and weight gradient.
+// The generic tile kernel above makes one global round trip per 16-deep K slice (16 MFMAs per wave) and decodes
+// (c,kh,kw) per gathered element; one workgroup per CU cannot hide that latency (round 2: 58 / 86 us for 2.4 GFLOP
+// = 27 / 18 % of the fp32 MFMA peak).  Here a workgroup owns 4 full rows of one image (64 positions) and walks the
+// input channels in chunks of 16: the chunk's 6 x 18 halo patch and its 64 x 144 weight slab are staged in LDS once
+// and all 9 taps run from them -- 144 MFMAs per wave per global round trip, no index arithmetic in the loop, each
+// input element fetched once instead of 9 times.  LDS strides are chosen so that every fragment read is conflict-free:
+//   weights  As[o][148]: bank = 20 (l&15) + 9 (l>>4) + const  -- 16 multiples of 4 plus residues 0..3 mod 4
+//   patch    Ps[c][112]: bank = 48 (l>>4) + (l&15) + const    -- four 16-bank windows
+// --------------------------------------------------------------------------- //
+constexpr int R16_AST = 148, R16_CST = 112, R16_RST = 18;
+constexpr int R16_DST = 68, R16_WCST = 132;
+
+bool conv_rows16_ok(int Cin, int H, int W, int K, int stride, int pad) {
+    static const bool off = [] { const char* e = getenv("MEDT_CONV_ROWS16"); return e && e[0] == '0'; }();
+    return !off && K == 3 && stride == 1 && pad == 1 && W == 16 && H % 4 == 0 && Cin % 16 == 0;
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ partials, int Cin, int H, int Cout, int relu) {
+    __shared__ float As[64 * R16_AST];
+    __shared__ float Ps[16 * R16_CST];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tpi = H >> 2;                                        // 4-row tiles per image
+    const int n = blockIdx.x / tpi, r0 = (blockIdx.x - n * tpi) * 4, o0 = blockIdx.y * 64;
+    const int Ktot = Cin * 9, HW = H * 16;
+    if (tid < 192) {                                               // the padding columns (-1 and 16) stay zero
+        const int c = tid / 12, rem = tid - c * 12;
+        Ps[c * R16_CST + (rem >> 1) * R16_RST + (rem & 1) * 17] = 0.f;
+    }
+    const int ar = tid >> 4, ae = tid & 15;                        // weight slab: rows ar + 16 j, columns ae + 16 m
+    const float* xn = x + (size_t)n * Cin * HW;
+    int poff[6], goff[6];                                          // patch element u = tid + 256 i: (c, row, col)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + MEDT_THREADS * i, c = u / 96, rem = u - c * 96, row = rem >> 4, col = rem & 15;
+        const int gr = r0 - 1 + row;
+        poff[i] = c * R16_CST + row * R16_RST + 1 + col;
+        goff[i] = (gr >= 0 && gr < H) ? c * HW + gr * 16 + col : -1;       // rows above / below the image stay zero
+    }
+    float ra[36], rp[6];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = min(o0 + ar + 16 * j, Cout - 1);          // rows past Cout: their accumulators are never stored
+            const float* wr = w + (size_t)o * Ktot + c0 * 9 + ae;
+#pragma unroll
+            for (int m = 0; m < 9; ++m) ra[j * 9 + m] = wr[16 * m];
+        }
+        const float* xc = xn + (size_t)c0 * HW;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                               // unconditional loads (no branch per element), then select
+            const float v = xc[max(goff[i], 0)];
+            rp[i] = goff[i] >= 0 ? v : 0.f;
+        }
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
+    const float* arow = As + (16 * wv + (lane & 15)) * R16_AST + (lane >> 4) * 9;
+    const float* prow = Ps + (lane >> 4) * R16_CST + (lane & 15);
+    const int nch = Cin >> 4;
+    fetch(0);
+    for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 9; ++m) As[(ar + 16 * j) * R16_AST + ae + 16 * m] = ra[j * 9 + m];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ps[poff[i]] = rp[i];
+        __syncthreads();
+        if (ch + 1 < nch) fetch((ch + 1) * 16);                    // flies during the 144 MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[9], b[6][3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a[t] = arow[ks * 36 + t];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) b[r][kw] = prow[ks * 4 * R16_CST + r * R16_RST + kw];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq)
+                        acc[tq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kh * 3 + kw], b[tq + kh][kw], acc[tq], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[(lane>>4)*4 + r][lane&15] of tile tq  ->  o = o0 + 16 wv + (lane>>4)*4 + r,  position (r0 + tq, lane&15)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+        if (o < Cout) {
+            const float bo = bias ? bias[o] : 0.f;
+            float* yo = y + ((size_t)n * Cout + o) * HW + r0 * 16 + (lane & 15);
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const float v = acc[tq][r] + bo;
+                s1[r] += v;
+                s2[r] = fmaf(v, v, s2[r]);
+                yo[tq * 16] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+    if (partials) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
+            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+            if ((lane & 15) == 0 && o < Cout) {
+                float* dst = partials + ((size_t)blockIdx.x * Cout + o) * 2;
+                dst[0] = a;
+                dst[1] = b;
+            }
+        }
+    }
+}
+
+// Weight gradient of the same layers: dW[o][c][t] = sum_q dY[o][q] * X[c][q + t].  A workgroup owns 64 output channels x
+// one 16-channel chunk x all 9 taps (9 accumulator tiles per wave) over a chunk of 64-position tiles: the dY tile and the
+// halo patch are staged once per position tile and the 9 taps read shifted windows of the patch -- 144 MFMAs per wave per
+// round trip.  Both operands have the channel on the fragment's row index and the position on k:
+//   dY  Ds[o][68]:  bank = 4 (l&15) + (l>>4) + const;   patch Ps[c][132]: bank = 4 (l&15) + (l>>4) + const.
+// grid (Cout/64, Cin/16, splits); slab bz of `scratch` receives the partial sum over its position tiles.
+__global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int Cin, int H, int Cout, int tiles_per_split, int ptiles,
+    int npg) {
+    __shared__ float Ds[64 * R16_DST];
+    __shared__ float Ps[16 * R16_WCST];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int o0 = blockIdx.x * 64, c0 = blockIdx.y * 16;
+    const int Ktot = Cin * 9, HW = H * 16, tpi = H >> 2;
+    const int pt_begin = blockIdx.z * tiles_per_split;
+    const int pt_end = min(ptiles, pt_begin + tiles_per_split);
+    if (tid < 192) {
+        const int c = tid / 12, rem = tid - c * 12;
+        Ps[c * R16_WCST + (rem >> 1) * R16_RST + (rem & 1) * 17] = 0.f;
+    }
+    int poff[6], pc[6], prw[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + MEDT_THREADS * i, c = u / 96, rem = u - c * 96, row = rem >> 4, col = rem & 15;
+        poff[i] = c * R16_WCST + row * R16_RST + 1 + col;
+        pc[i] = (c0 + c) * HW + col;
+        prw[i] = row - 1;
+    }
+    float rd[16], rp[6];
+    auto fetch = [&](int pt) {
+        const int n = pt / tpi, r0 = (pt - n * tpi) * 4;
+        const size_t base = (size_t)n * Cout * HW + r0 * 16 + lane;
+        const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)                                // rows past Cout: their accumulators are never stored
+            rd[j] = dy[base + (size_t)min(o0 + wv + 4 * j, Cout - 1) * HW];
+        if (cf) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int o = min(o0 + wv + 4 * j, Cout - 1);
+                rd[j] = fmaf(cf[o * 3], rd[j], fmaf(cf[o * 3 + 1], raw[base + (size_t)o * HW], cf[o * 3 + 2]));
+            }
+        }
+        const float* xn = x + (size_t)n * Cin * HW;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                               // unconditional loads (no branch per element), then select
+            const int gr = r0 + prw[i];
+            const float v = xn[pc[i] + min(max(gr, 0), H - 1) * 16];
+            rp[i] = (unsigned)gr < (unsigned)H ? v : 0.f;
+        }
+    };
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4)(0.f);
+    const float* drow = Ds + (16 * wv + (lane & 15)) * R16_DST + (lane >> 4);
+    const float* prow = Ps + (lane & 15) * R16_WCST + (lane >> 4);
+    if (pt_begin < pt_end) fetch(pt_begin);
+    for (int pt = pt_begin; pt < pt_end; ++pt) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Ds[(wv + 4 * j) * R16_DST + lane] = rd[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ps[poff[i]] = rp[i];
+        __syncthreads();
+        if (pt + 1 < pt_end) fetch(pt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {                          // k = position (row ks>>2, column 4 (ks&3) + (lane>>4))
+            const float a = drow[ks * 4];
+            const float* pk = prow + (ks >> 2) * R16_RST + (ks & 3) * 4;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pk[kh * R16_RST + kw], acc[kh * 3 + kw], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+        if (o < Cout) {
+            float* dst = out + (size_t)o * Ktot + (c0 + (lane & 15)) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
+        }
+    }
+}
+
 // y[n,o,p] = bias[o] + sum over K slices; optional ReLU and BatchNorm partials ([group][256-position part][Cout][2]).
 // grid (groups*ppg256, Cout): lanes over the positions of one group, one channel per blockIdx.y.
 __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
@@ -199,6 +415,11 @@ int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, f
         ks = cdiv(Ktot, kchunk);
     }
     const dim3 grid((unsigned)qt, cdiv(Cout, 64), ks), block(MEDT_THREADS);
+    if (ks == 1 && (N / groups) * Ho * Wo % 64 == 0 && conv_rows16_ok(Cin, H, W, K, stride, pad)) {
+        hipLaunchKernelGGL(conv3x3_rows16_fwd_kernel, dim3((unsigned)qt, cdiv(Cout, 64)), block, 0, s, x, w, bias, y,
+                           partials, Cin, H, Cout, relu);
+        return launch_status("conv3x3_rows16_fwd");
+    }
     float* kout = ks > 1 ? scratch : nullptr;
     if (K == 1)
         hipLaunchKernelGGL(conv_mfma_fwd_kernel<1>, grid, block, 0, s, x, w, bias, y, partials, Cin, H, W, Cout, Ho, Wo,
@@ -375,6 +596,11 @@ int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const 
                     int H, int W, int Cout, int Ho, int Wo, int K, int stride, int pad, int QS, int splits, int npg,
                     hipStream_t s) {
     const dim3 grid(cdiv(Cout, 64), cdiv(Cin * K * K, 64), splits), block(MEDT_THREADS);
+    if (QS % 64 == 0 && Ho == H && Wo == W && conv_rows16_ok(Cin, H, W, K, stride, pad)) {
+        hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel, dim3(cdiv(Cout, 64), Cin / 16, splits), block, 0, s, dy, raw, coef,
+                           x, scratch, Cin, H, Cout, QS / 64, N * H / 4, npg);
+        return launch_status("conv3x3_rows16_wgrad");
+    }
     if (K == 1)
         hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho,
                            Wo, stride, pad, QS, npg);

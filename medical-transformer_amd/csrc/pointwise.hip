@@ -105,9 +105,11 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int Cout, int HW, int npg) {
     __shared__ float red[3][CT][64];
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CT]: this workgroup's weight slice
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long q = (long)blockIdx.x * 64 + lane;
     const int  c0 = blockIdx.y * CT;
+    for (int e = threadIdx.x; e < Cout * CT; e += MEDT_THREADS) wl[e] = w[(e / CT) * Cin + c0 + (e % CT)];
     const bool ok = q < (long)N * HW;
     const int  n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
     const size_t base = (size_t)n * Cout * HW + p;
@@ -116,7 +118,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
     float acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
-#pragma unroll 4
+    // the weights come from LDS, so the only global loads in the loop are dy / raw / coef: 16 channels' worth in flight
+    // per round trip (the loop is a chain of round trips, nothing else: <= 4k positions)
+    __syncthreads();
+#pragma unroll 16
     for (int o = ob; o < oe; ++o) {
         float v = ok ? dy[base + (size_t)o * HW] : 0.f;
         if (cf) {
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
             v = fmaf(cf[o * 3 + 0], v, fmaf(cf[o * 3 + 1], r, cf[o * 3 + 2]));
         }
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = fmaf(w[o * Cin + c0 + c], v, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = fmaf(wl[o * CT + c], v, acc[c]);
     }
     if (wv > 0) {
 #pragma unroll
@@ -142,14 +147,14 @@ int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const
                      int Cout, int HW, int groups, hipStream_t s) {
     const int npg = N / groups;
     const unsigned gx = (unsigned)(((long)N * HW + MEDT_THREADS - 1) / MEDT_THREADS);
-    if ((long)N * HW <= 4096 && Cout >= 64 && Cin % 8 == 0) {         // small, deep: wave-split contraction
+    if ((long)N * HW <= 4096 && Cout >= 64 && Cout <= 768 && Cin % 8 == 0) {   // small, deep: wave-split contraction
         const unsigned g64 = (unsigned)(((long)N * HW + 63) / 64);
         if (Cin % 16 == 0 && g64 * (Cin / 16) >= 64)
-            hipLaunchKernelGGL(conv1x1_bwd_data_ws_kernel<16>, dim3(g64, Cin / 16), dim3(MEDT_THREADS), 0, s, dy, raw, coef,
-                               w, dx, N, Cin, Cout, HW, npg);
+            hipLaunchKernelGGL(conv1x1_bwd_data_ws_kernel<16>, dim3(g64, Cin / 16), dim3(MEDT_THREADS),
+                               (size_t)Cout * 16 * sizeof(float), s, dy, raw, coef, w, dx, N, Cin, Cout, HW, npg);
         else
-            hipLaunchKernelGGL(conv1x1_bwd_data_ws_kernel<8>, dim3(g64, Cin / 8), dim3(MEDT_THREADS), 0, s, dy, raw, coef, w,
-                               dx, N, Cin, Cout, HW, npg);
+            hipLaunchKernelGGL(conv1x1_bwd_data_ws_kernel<8>, dim3(g64, Cin / 8), dim3(MEDT_THREADS),
+                               (size_t)Cout * 8 * sizeof(float), s, dy, raw, coef, w, dx, N, Cin, Cout, HW, npg);
         return launch_status("conv1x1_bwd_data_ws");
     }
     int CT = 16;                                   // fewer channels per lane when the grid would not fill the chip

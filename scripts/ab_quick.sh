@@ -1,0 +1,13 @@
+# A/B of the round-2 late kernels ON the GPU box (gpurun): conv tests, bench with each switch off, kernel statistics
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/ab_quick
+rm -rf $O && mkdir -p $O
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -15 > $O/tests.txt
+for v in "DEFAULT:" "NO_ROWS16:MEDT_CONV_ROWS16=0" "NO_DGRAD_WS:MEDT_DGRAD_WS=0" $EXTRA_AB; do
+  name=${v%%:*}; envs=${v#*:}
+  echo -n "$name " >> $O/ab.txt
+  env $envs timeout 200 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $O/ab.txt
+done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python bench.py --no-cpu-baseline --no-roofline > $O/bench_prof.log 2>&1
+find $O -name "*kernel_trace.csv" -size +30M -delete
+cat $O/tests.txt; cat $O/ab.txt

@@ -53,6 +53,7 @@ CONV_CASES = [
     (128, 64, 3, 1, 1, True, False, False, True, 32, 16, 1),    # conv3_p-shaped, bias + relu, no BN
     (32, 64, 3, 2, 1, True, False, False, False, 16, 64, 1),    # stride 2 (forward + weight gradient on MFMA)
     (40, 72, 3, 1, 1, False, True, True, True, 36, 15, 2),      # ragged tiles: Cout % 64 != 0, positions % 64 != 0
+    (48, 80, 3, 1, 1, False, True, True, True, 32, 16, 2),      # 16-wide-map kernels with a partial channel tile (fwd / dgrad / wgrad)
 ]
 
 
