@@ -16,37 +16,62 @@ import torch
 from . import _lib as L
 
 ENABLED = os.environ.get("MEDT_DEFER", "1") != "0"
+# one queue per recording stream: the stream whose pass ends first (MedT's global branch) issues its own grouped
+# launches right there, under the other branch's latency-bound chain, instead of after the join (net.medt_forward)
+SPLIT = os.environ.get("MEDT_SPLIT_FLUSH", "1") != "0"
 _current = None
 
 
 class StepQueue:
     def __init__(self):
-        self._h = L.lib().medt_queue_create()
-        self._keep = []
+        self._handles = {}             # stream -> queue handle (one shared handle under key None when not SPLIT)
+        self._keep = {}                # handle -> tensors the recorded jobs point into
         self._bound = set()
 
     def __del__(self):
         try:
-            L.lib().medt_queue_destroy(self._h)
+            for h in self._handles.values():
+                L.lib().medt_queue_destroy(h)
         except Exception:
             pass
+
+    def _handle(self, s):
+        key = s if SPLIT else None
+        h = self._handles.get(key)
+        if h is None:
+            h = self._handles[key] = L.lib().medt_queue_create()
+            self._keep[h] = []
+        return h
 
     def bind_current_stream(self):
         s = torch.cuda.current_stream().cuda_stream
         if s not in self._bound:
-            L.check(L.lib().medt_queue_bind(self._h, s), "medt_queue_bind")
+            L.check(L.lib().medt_queue_bind(self._handle(s), s), "medt_queue_bind")
             self._bound.add(s)
 
     def hold(self, *tensors):
-        self._keep.extend(t for t in tensors if t is not None)
+        h = self._handle(torch.cuda.current_stream().cuda_stream)
+        self._keep[h].extend(t for t in tensors if t is not None)
 
     def pending(self) -> int:
-        return int(L.lib().medt_queue_pending(self._h))
+        return sum(int(L.lib().medt_queue_pending(h)) for h in self._handles.values())
 
     def flush(self):
         """Issue everything recorded so far on the current stream (all recording streams must have been joined into it)."""
-        L.check(L.lib().medt_queue_flush(self._h, torch.cuda.current_stream().cuda_stream), "medt_queue_flush")
-        self._keep.clear()
+        cur = torch.cuda.current_stream().cuda_stream
+        for h in self._handles.values():
+            L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
+            self._keep[h].clear()
+
+    def flush_current_stream(self):
+        """Issue what was recorded ON the current stream, on it (no other stream's work is waited for)."""
+        if not SPLIT:
+            return
+        cur = torch.cuda.current_stream().cuda_stream
+        h = self._handles.get(cur)
+        if h is not None:
+            L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
+            self._keep[h].clear()
 
     def _unbind_all(self):
         lib = L.lib()
@@ -67,7 +92,14 @@ class StepQueue:
         finally:
             _current = None
             self._unbind_all()
-            self._keep.clear()
+            for k in self._keep.values():
+                k.clear()
+
+
+def flush_current_stream():
+    """Called where one branch's backward pass ends (ops.ConvBlockFn, cfg.last_of_branch)."""
+    if _current is not None:
+        _current.flush_current_stream()
 
 
 def recording(allow: bool = True):

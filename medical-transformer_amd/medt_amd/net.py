@@ -65,11 +65,12 @@ def _layer(seq, x, bn_groups=1):
     return x
 
 
-def _stem(net, x, sfx="", bn_groups=1):
+def _stem(net, x, sfx="", bn_groups=1, first_of_branch=False):
     g = lambda n: getattr(net, n + sfx)
     for i in ("1", "2", "3"):
         bn = g("bn" + i)
-        x = ops.conv_block(x, g("conv" + i), bn, relu=True, training=bn.training, bn_groups=bn_groups)
+        x = ops.conv_block(x, g("conv" + i), bn, relu=True, training=bn.training, bn_groups=bn_groups,
+                           last_of_branch=first_of_branch and i == "1")     # first forward op = last backward op
     return x
 
 
@@ -108,7 +109,9 @@ def medt_forward(net, x):
     side = _side_stream(xin.device) if TWO_STREAMS else None
     if side is not None:
         side.wait_stream(main)
-    g = _stem(net, xin)
+    # (the global branch's backward ends well before the local one's: its recorded weight-gradient jobs are issued on
+    # its own stream as soon as its stem's backward has run, under the local chain -- defer.flush_current_stream)
+    g = _stem(net, xin, first_of_branch=side is not None)
     x1 = _layer(net.layer1, g)
     x2 = _layer(net.layer2, x1)
     y = ops.up2x_relu_add(ops.conv_block(x2, net.decoder4), x1, ops.sink_of(x1) if SINKS else None)

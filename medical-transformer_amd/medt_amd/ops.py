@@ -59,11 +59,12 @@ def sink_of(x):
 
 
 class ConvBlockCfg:
-    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink")
+    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink", "last_of_branch")
 
-    def __init__(self, stride, pad, bn, relu, bn_groups=1, x_sink=None, x_role=None, res_sink=None):
+    def __init__(self, stride, pad, bn, relu, bn_groups=1, x_sink=None, x_role=None, res_sink=None, last_of_branch=False):
         self.stride, self.pad, self.bn, self.relu, self.bn_groups = stride, pad, bn, relu, bn_groups
         self.x_sink, self.x_role, self.res_sink = x_sink, x_role, res_sink
+        self.last_of_branch = last_of_branch       # this block's backward is the last work of its stream's backward pass
 
 
 def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDesc:
@@ -160,14 +161,16 @@ class ConvBlockFn(torch.autograd.Function):
                 dx = None
         if dres is not None and cfg.res_sink is not None and cfg.res_sink.deposit(dres):
             dres = None
+        if cfg.last_of_branch:                         # nothing else of this branch follows: its recorded jobs go out now
+            DEFER.flush_current_stream()
         return (dx, ret[0], ret[1], ret[2], ret[3], dres, None, None)
 
 
 def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups=1, x_sink=None, x_role=None,
-               res_sink=None):
+               res_sink=None, last_of_branch=False):
     """conv: nn.Conv2d holder, bn: nn.BatchNorm2d holder or None.  x_sink / x_role / res_sink: see GradSink."""
     cfg = ConvBlockCfg(conv.stride[0], conv.padding[0], bn, relu, bn_groups if bn is not None else 1, x_sink, x_role,
-                       res_sink)
+                       res_sink, last_of_branch)
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                              bn.bias if bn is not None else None, res, cfg, training)
 

@@ -2,8 +2,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/ab_quick
 rm -rf $O && mkdir -p $O
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -15 > $O/tests.txt
-for v in "DEFAULT:" "NO_ROWS16:MEDT_CONV_ROWS16=0" "NO_DGRAD_WS:MEDT_DGRAD_WS=0" $EXTRA_AB; do
+timeout 900 python -m pytest ${AB_TESTS:-tests/test_ops_gpu.py tests/test_model_gpu.py} -m gpu -x -q 2>&1 | tail -15 > $O/tests.txt
+for v in "DEFAULT:" $EXTRA_AB; do
   name=${v%%:*}; envs=${v#*:}
   echo -n "$name " >> $O/ab.txt
   env $envs timeout 200 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $O/ab.txt
