@@ -7,6 +7,7 @@
 // channels in registers, the K*K taps of one input channel are loaded once per lane and the weights
 // arrive through the scalar path (wave-uniform addresses, K*K contiguous floats per (o,c) pair).
 #include "defer.h"
+#include <type_traits>
 
 namespace medt {
 
@@ -35,23 +36,45 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
 #pragma unroll
     for (int o = 0; o < OT; ++o) acc[o] = bias ? bias[o0 + o] : 0.f;
     const float* xn = x + (size_t)n * Cin * H * W;
-#pragma unroll K == 1 ? 4 : (K == 3 ? 2 : 1)
-    for (int c = 0; c < Cin; ++c) {
-        float xv[KK];
+    // tap offsets inside one channel plane, decoded once (-1: padding or a lane past the end).  The loads in the channel
+    // loop are unconditional (clamped offset, then a select): a branch per tap would keep one load in flight at a time.
+    int off[KK];
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh)
+    for (int kh = 0; kh < K; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int h = h0 + kh, ww = w0 + kw;
-                xv[kh * K + kw] = (ok && h >= 0 && h < H && ww >= 0 && ww < W) ? xn[((size_t)c * H + h) * W + ww] : 0.f;
-            }
-#pragma unroll
-        for (int o = 0; o < OT; ++o) {
-            const float* wp = w + ((size_t)(o0 + o) * Cin + c) * KK;
-#pragma unroll
-            for (int t = 0; t < KK; ++t) acc[o] = fmaf(wp[t], xv[t], acc[o]);
+        for (int kw = 0; kw < K; ++kw) {
+            const int h = h0 + kh, ww = w0 + kw;
+            off[kh * K + kw] = (ok && (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W) ? h * W + ww : -1;
         }
-    }
+    const int HWi = H * W;
+    // U channels' taps are loaded as one batch (U*K*K loads in flight), then consumed: MEDT_SCHED_FENCE keeps the
+    // scheduler from interleaving load / use pairs, which would make the loop one global round trip per tap.
+    constexpr int U = K == 1 ? 8 : (K == 3 ? 4 : 1);
+    auto taps = [&](auto u_tag, int c) {
+        constexpr int UU = decltype(u_tag)::value;
+        float xr[UU][KK];
+#pragma unroll
+        for (int u = 0; u < UU; ++u)
+#pragma unroll
+            for (int t = 0; t < KK; ++t) xr[u][t] = xn[(size_t)(c + u) * HWi + max(off[t], 0)];
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float xv[KK];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) xv[t] = off[t] >= 0 ? xr[u][t] : 0.f;
+#pragma unroll
+            for (int o = 0; o < OT; ++o) {
+                const float* wp = w + ((size_t)(o0 + o) * Cin + c + u) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) acc[o] = fmaf(wp[t], xv[t], acc[o]);
+            }
+        }
+        MEDT_SCHED_FENCE();
+    };
+    int c = 0;
+    for (; c + U <= Cin; c += U) taps(std::integral_constant<int, U>{}, c);
+    for (; c < Cin; ++c) taps(std::integral_constant<int, 1>{}, c);
     if (ok) {
         const size_t yo = ((size_t)n * Cout + o0) * HoWo + p;
 #pragma unroll
@@ -165,18 +188,33 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
     const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
-#pragma unroll K == 1 ? 4 : (K == 3 ? 4 : 1)
-    for (int o = 0; o < Cout; ++o) {
-        float dv[KK];
+    constexpr int U = K == 1 ? 8 : (K == 3 ? 4 : 1);               // output channels per batch of loads (see conv2d_fwd_kernel)
+    const int HoWo = Ho * Wo;
+    auto taps = [&](auto u_tag, int o) {
+        constexpr int UU = decltype(u_tag)::value;
+        float dr[UU][KK];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) dv[t] = off[t] >= 0 ? dyn[(size_t)o * Ho * Wo + off[t]] : 0.f;
+        for (int u = 0; u < UU; ++u)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const float* wp = w + ((size_t)o * Cin + c0 + c) * KK;
+            for (int t = 0; t < KK; ++t) dr[u][t] = dyn[(size_t)(o + u) * HoWo + max(off[t], 0)];
+        MEDT_SCHED_FENCE();
 #pragma unroll
-            for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
+        for (int u = 0; u < UU; ++u) {
+            float dv[KK];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) dv[t] = off[t] >= 0 ? dr[u][t] : 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float* wp = w + ((size_t)(o + u) * Cin + c0 + c) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
+            }
         }
-    }
+        MEDT_SCHED_FENCE();
+    };
+    int o = 0;
+    for (; o + U <= Cout; o += U) taps(std::integral_constant<int, U>{}, o);
+    for (; o < Cout; ++o) taps(std::integral_constant<int, 1>{}, o);
     if (ok) {
         const size_t o0 = ((size_t)n * Cin + c0) * HW + p;
 #pragma unroll
@@ -225,21 +263,33 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     const float* dyn = dy + (size_t)n * Cout * Ho * Wo;
     const int ob = (Cout * wv) / 4, oe = (Cout * (wv + 1)) / 4;
     __syncthreads();
-#pragma unroll K == 1 ? 16 : 4
-    for (int o = ob; o < oe; ++o) {
-        float dv[KK];
+    constexpr int U = K == 1 ? 16 : 4;                             // output channels per batch of loads
+    const int HoWo = Ho * Wo;
+    auto taps = [&](auto u_tag, int o) {
+        constexpr int UU = decltype(u_tag)::value;
+        float dr[UU][KK];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) {                               // unconditional load, then select: no branch per tap
-            const float v = dyn[(size_t)o * Ho * Wo + max(off[t], 0)];
-            dv[t] = off[t] >= 0 ? v : 0.f;
+        for (int u = 0; u < UU; ++u)
+#pragma unroll
+            for (int t = 0; t < KK; ++t) dr[u][t] = dyn[(size_t)(o + u) * HoWo + max(off[t], 0)];
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float dv[KK];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) dv[t] = off[t] >= 0 ? dr[u][t] : 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float* wp = wl + ((o + u) * CT + c) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
+            }
         }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const float* wp = wl + (o * CT + c) * KK;
-#pragma unroll
-            for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
-        }
-    }
+        MEDT_SCHED_FENCE();
+    };
+    int o = ob;
+    for (; o + U <= oe; o += U) taps(std::integral_constant<int, U>{}, o);
+    for (; o < oe; ++o) taps(std::integral_constant<int, 1>{}, o);
     if (wv > 0) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) red[wv - 1][c][lane] = acc[c];

@@ -8,6 +8,9 @@
 
 #define MEDT_THREADS 256            // 4 wave64 per workgroup everywhere
 #define MEDT_WAVES (MEDT_THREADS / 64)
+// nothing is scheduled across this point: separates a batch of independent global loads from the arithmetic that
+// consumes them, so the loads are all in flight before the first wait (latency-bound small kernels)
+#define MEDT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MEDT_LOG2E 1.4426950408889634f
 
 namespace medt {

@@ -6,6 +6,7 @@
 // per-channel constants come through the scalar path (wave-uniform addresses).
 #include "defer.h"
 #include "sim_tables.h"
+#include <type_traits>
 
 namespace medt {
 
@@ -25,10 +26,24 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_fwd_kernel(
     float acc[OT];
 #pragma unroll
     for (int o = 0; o < OT; ++o) acc[o] = 0.f;
-    for (int c = 0; c < Cin; ++c) {
-        const float xv = ok ? xp[(size_t)c * HW] : 0.f;
+    {
+        int c = 0;                                      // lanes past HW read pixel 0 (never stored): no branch around the loads
+        for (; c + 8 <= Cin; c += 8) {
+            float xr[8];
 #pragma unroll
-        for (int o = 0; o < OT; ++o) acc[o] = fmaf(w[(o0 + o) * Cin + c], xv, acc[o]);
+            for (int u = 0; u < 8; ++u) xr[u] = xp[(size_t)(c + u) * HW];
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int o = 0; o < OT; ++o) acc[o] = fmaf(w[(o0 + o) * Cin + c + u], xr[u], acc[o]);
+            MEDT_SCHED_FENCE();
+        }
+        for (; c < Cin; ++c) {
+            const float xv = xp[(size_t)c * HW];
+#pragma unroll
+            for (int o = 0; o < OT; ++o) acc[o] = fmaf(w[(o0 + o) * Cin + c], xv, acc[o]);
+        }
     }
     if (ok) {
         float* yp = y + ((size_t)n * Cout + o0) * HW + p;
@@ -80,15 +95,41 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_kernel(
     float acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
-#pragma unroll 4
-    for (int o = 0; o < Cout; ++o) {
-        float v = ok ? dy[base + (size_t)o * HW] : 0.f;
-        if (cf) {
-            const float r = ok ? raw[base + (size_t)o * HW] : 0.f;
-            v = fmaf(cf[o * 3 + 0], v, fmaf(cf[o * 3 + 1], r, cf[o * 3 + 2]));
-        }
+    // Batches of 8 output channels: all their loads in flight, then the FMAs (MEDT_SCHED_FENCE keeps load / use pairs from
+    // being interleaved into one global round trip per channel).  Lanes past the end read position 0 (never stored).
+    auto batch = [&](auto u_tag, auto cf_tag, int o) {
+        constexpr int UU = decltype(u_tag)::value;
+        constexpr bool CF = decltype(cf_tag)::value;
+        float dv[UU], rv[UU], k0[UU], k1[UU], k2[UU];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = fmaf(w[o * Cin + c0 + c], v, acc[c]);
+        for (int u = 0; u < UU; ++u) {
+            dv[u] = dy[base + (size_t)(o + u) * HW];
+            if constexpr (CF) {
+                rv[u] = raw[base + (size_t)(o + u) * HW];
+                k0[u] = cf[(o + u) * 3 + 0];
+                k1[u] = cf[(o + u) * 3 + 1];
+                k2[u] = cf[(o + u) * 3 + 2];
+            }
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float v = dv[u];
+            if constexpr (CF) v = fmaf(k0[u], v, fmaf(k1[u], rv[u], k2[u]));
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = fmaf(w[(o + u) * Cin + c0 + c], v, acc[c]);
+        }
+        MEDT_SCHED_FENCE();
+    };
+    {
+        int o = 0;
+        if (cf) {
+            for (; o + 8 <= Cout; o += 8) batch(std::integral_constant<int, 8>{}, std::true_type{}, o);
+            for (; o < Cout; ++o) batch(std::integral_constant<int, 1>{}, std::true_type{}, o);
+        } else {
+            for (; o + 8 <= Cout; o += 8) batch(std::integral_constant<int, 8>{}, std::false_type{}, o);
+            for (; o < Cout; ++o) batch(std::integral_constant<int, 1>{}, std::false_type{}, o);
+        }
     }
     if (ok) {
         float* dp = dx + ((size_t)n * Cin + c0) * HW + p;
@@ -121,15 +162,40 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
     // the weights come from LDS, so the only global loads in the loop are dy / raw / coef: 16 channels' worth in flight
     // per round trip (the loop is a chain of round trips, nothing else: <= 4k positions)
     __syncthreads();
-#pragma unroll 16
-    for (int o = ob; o < oe; ++o) {
-        float v = ok ? dy[base + (size_t)o * HW] : 0.f;
-        if (cf) {
-            const float r = ok ? raw[base + (size_t)o * HW] : 0.f;
-            v = fmaf(cf[o * 3 + 0], v, fmaf(cf[o * 3 + 1], r, cf[o * 3 + 2]));
-        }
+    // (batches of 16 output channels, loads first: see conv1x1_bwd_data_kernel)
+    auto batch = [&](auto u_tag, auto cf_tag, int o) {
+        constexpr int UU = decltype(u_tag)::value;
+        constexpr bool CF = decltype(cf_tag)::value;
+        float dv[UU], rv[UU], k0[UU], k1[UU], k2[UU];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = fmaf(wl[o * CT + c], v, acc[c]);
+        for (int u = 0; u < UU; ++u) {
+            dv[u] = dy[base + (size_t)(o + u) * HW];
+            if constexpr (CF) {
+                rv[u] = raw[base + (size_t)(o + u) * HW];
+                k0[u] = cf[(o + u) * 3 + 0];
+                k1[u] = cf[(o + u) * 3 + 1];
+                k2[u] = cf[(o + u) * 3 + 2];
+            }
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float v = dv[u];
+            if constexpr (CF) v = fmaf(k0[u], v, fmaf(k1[u], rv[u], k2[u]));
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = fmaf(wl[(o + u) * CT + c], v, acc[c]);
+        }
+        MEDT_SCHED_FENCE();
+    };
+    {
+        int o = ob;
+        if (cf) {
+            for (; o + 16 <= oe; o += 16) batch(std::integral_constant<int, 16>{}, std::true_type{}, o);
+            for (; o < oe; ++o) batch(std::integral_constant<int, 1>{}, std::true_type{}, o);
+        } else {
+            for (; o + 16 <= oe; o += 16) batch(std::integral_constant<int, 16>{}, std::false_type{}, o);
+            for (; o < oe; ++o) batch(std::integral_constant<int, 1>{}, std::false_type{}, o);
+        }
     }
     if (wv > 0) {
 #pragma unroll
