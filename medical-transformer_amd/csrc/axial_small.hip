@@ -45,6 +45,26 @@ __device__ __forceinline__ void small_scale_shift(float s, float ss, double coun
     }
 }
 
+// The same from per-channel parameters that were prefetched into LDS at kernel start (prm[4]: weight, bias, running mean,
+// running variance): the lane that finalises a BatchNorm does not start a dependent global round trip in mid-kernel.
+__device__ __forceinline__ void small_scale_shift_p(float s, float ss, double count, const float* prm, float eps, int training,
+                                                    float& scale, float& shift) {
+    const float g = prm[0], b = prm[1];
+    if (training) {
+        const double mean = (double)s / count;
+        double var = (double)ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        scale = (float)(g * rstd);
+        shift = (float)(b - mean * g * rstd);
+    } else {
+        const float mean = prm[2];
+        const float rstd = (float)(1.0 / sqrt((double)prm[3] + (double)eps));
+        scale = g * rstd;
+        shift = b - mean * g * rstd;
+    }
+}
+
 // block_sum for workgroups of NW waves (256 or 512 threads)
 template <int K>
 __device__ __forceinline__ void small_block_sum(float (&v)[K], float* red, float* dst, int NW) {
@@ -76,6 +96,17 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     float* sh = sc + 32;                // [32] shift
     float* red = sh + 32;               // [64] reduction scratch
     float* Wl = red + 64;               // [C][NCH] qkv_transform rows of this head, transposed
+    float* prm = Wl + C * NCH;          // [NCH + 1 + GP][4] BatchNorm parameters of this head's channels (bn_qkv | sim | out)
+    if (tid < NCH + 1 + GP) {
+        const medt_bn_ptrs& bn = tid < NCH ? a.bq : (tid == NCH ? a.bs : a.bo);
+        const int ch = tid < NCH ? hg * NCH + tid : (tid == NCH ? hg : hg * GP + (tid - NCH - 1));
+        prm[tid * 4] = bn.weight[ch];
+        prm[tid * 4 + 1] = bn.bias[ch];
+        if (!a.training) {
+            prm[tid * 4 + 2] = bn.running_mean[ch];
+            prm[tid * 4 + 3] = bn.running_var[ch];
+        }
+    }
 
     // 1. qkv_transform rows hg*2gp .. +2gp                                               (axialnet.py:228)
     //    A work item is a position and a chunk of NOC <= 16 output channels: x is loaded once per item (16 loads in
@@ -142,7 +173,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         ss = wave_sum(ss);
         if (lane == 0) {
             const int ch = hg * NCH + oc;
-            small_scale_shift(s, ss, (double)P, a.bq, ch, a.eps, a.training, sc[oc], sh[oc]);
+            small_scale_shift_p(s, ss, (double)P, prm + oc * 4, a.eps, a.training, sc[oc], sh[oc]);
             if (a.training) {
                 a.part_q[((size_t)grp * 2 * C + ch) * 2] = s;
                 a.part_q[((size_t)grp * 2 * C + ch) * 2 + 1] = ss;
@@ -185,7 +216,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     small_block_sum<2>(v, red, red + 32, NW);
     if (tid == 0) {
         float scale, shift;
-        small_scale_shift(red[32], red[33], (double)P * L, a.bs, hg, a.eps, a.training, scale, shift);
+        small_scale_shift_p(red[32], red[33], (double)P * L, prm + NCH * 4, a.eps, a.training, scale, shift);
         red[40] = scale;
         if (a.training) {
             a.part_s[((size_t)grp * a.G + hg) * 2] = red[32];
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         ss = wave_sum(ss);
         if (lane == 0) {
             const int ch = hg * GP + c;
-            small_scale_shift(s, ss, (double)P, a.bo, ch, a.eps, a.training, sc[c], sh[c]);
+            small_scale_shift_p(s, ss, (double)P, prm + (NCH + 1 + c) * 4, a.eps, a.training, sc[c], sh[c]);
             if (a.training) {
                 a.part_o[((size_t)grp * C + ch) * 2] = s;
                 a.part_o[((size_t)grp * C + ch) * 2 + 1] = ss;
@@ -259,7 +290,9 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     }
 }
 
-static size_t small_lds_bytes(int gp, int P, int C) { return ((size_t)3 * gp * P + 32 + 32 + 64 + 2 * gp * C) * sizeof(float); }
+static size_t small_lds_bytes(int gp, int P, int C) {
+    return ((size_t)3 * gp * P + 32 + 32 + 64 + 2 * gp * C + 4 * (3 * gp + 1)) * sizeof(float);
+}
 
 static bool small_enabled() {
     static const bool on = [] { const char* e = getenv("MEDT_DISABLE_SMALL"); return !(e && e[0] == '1'); }();
@@ -343,8 +376,28 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
     float* dlt = lse + P;               // [P]      Delta_i = sum_c dsv[c,i] sv[c,i]
     float* red = dlt + P;               // [576]    reduction scratch (8 waves x 32 values + 64 results)
     float* cf = red + 576;              // [3*GP] bn_output coefficients, then [8] bn_similarity (e, u, w)
+    float* prm = cf + 80;               // saved statistics / weights the later phases need, prefetched now:
+    float* p_out = prm;                 //   [GP][3]  bn_output mean, rstd, weight
+    float* p_sim = p_out + 3 * GP;      //   [4]      bn_similarity scale, mean, rstd, weight
+    float* p_qkv = p_sim + 4;           //   [NCH][3] bn_qkv mean, rstd, weight
     const int st = a.stride, Ho = a.H / st, Wo = a.W / st;
     const double cnt = (double)P;
+    if (tid < GP) {
+        const int ch = hg * GP + tid;
+        p_out[tid * 3] = a.so.mean[grp * C + ch];
+        p_out[tid * 3 + 1] = a.so.rstd[grp * C + ch];
+        p_out[tid * 3 + 2] = a.w_out[ch];
+    } else if (tid == GP) {
+        p_sim[0] = a.ss.scale[grp * G + hg];
+        p_sim[1] = a.ss.mean[grp * G + hg];
+        p_sim[2] = a.ss.rstd[grp * G + hg];
+        p_sim[3] = a.w_sim[hg];
+    } else if (tid >= 64 && tid < 64 + NCH) {
+        const int ch = hg * NCH + (tid - 64);
+        p_qkv[(tid - 64) * 3] = a.sq.mean[grp * 2 * C + ch];
+        p_qkv[(tid - 64) * 3 + 1] = a.sq.rstd[grp * 2 * C + ch];
+        p_qkv[(tid - 64) * 3 + 2] = a.w_qkv_bn[ch];
+    }
 
     // normalised q|k|v of this head and the row log-sum-exps
     for (int item = tid; item < NCH * P; item += T) {
@@ -391,7 +444,7 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
             a.part_ob[((size_t)grp * C + ch) * 2 + 1] = r2;
             // same arithmetic as bn_bwd_finalize_kernel (pointwise.hip)
             const double s1 = (double)r1 * dscale, s2 = (double)r2 * dscale;
-            const double mean = a.so.mean[grp * C + ch], rstd = a.so.rstd[grp * C + ch], A = (double)a.w_out[ch] * rstd;
+            const double mean = p_out[3 * tid], rstd = p_out[3 * tid + 1], A = (double)p_out[3 * tid + 2] * rstd;
             cf[3 * tid] = (float)(A * dscale);
             if (a.training) {
                 const double m1 = s1 / cnt, m2 = s2 / cnt;
@@ -420,7 +473,7 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
     }
     __syncthreads();
     const int sj = AXIS == 1 ? 1 : W;
-    const float a_qk = a.ss.scale[grp * G + hg] * MEDT_LOG2E;
+    const float a_qk = p_sim[0] * MEDT_LOG2E;
     // everything one (i, j) pair contributes; qi/kj: positions of query i and key j
     auto pair = [&](int qi, int kj, float& S, float& Pij, float& dZ) {
         S = 0.f;
@@ -456,8 +509,8 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
             ps[0] = a0f; ps[1] = axf; ps[2] = 0.f; ps[3] = 0.f;
             // same arithmetic as sim_bwd_finalize_kernel / sim_coef (axial_core.hip)
             const double a0 = a0f, ax = axf, count = cnt * L;
-            const double mean = a.ss.mean[grp * G + hg], rstd = a.ss.rstd[grp * G + hg];
-            const double sxh = rstd * (ax - mean * a0), e = (double)a.w_sim[hg] * rstd;
+            const double mean = p_sim[1], rstd = p_sim[2];
+            const double sxh = rstd * (ax - mean * a0), e = (double)p_sim[3] * rstd;
             cf[64] = (float)e;
             if (a.training) {
                 const double m1 = a0 / count, m2 = sxh / count, u = -e * rstd * m2;
@@ -514,7 +567,7 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
     __syncthreads();
     for (int oc = wave; oc < NCH; oc += NW) {
         const int ch = hg * NCH + oc;
-        const float mean = a.sq.mean[grp * 2 * C + ch], rstd = a.sq.rstd[grp * 2 * C + ch];
+        const float mean = p_qkv[3 * oc], rstd = p_qkv[3 * oc + 1];
         float s1 = 0.f, s2 = 0.f;
         for (int q = lane; q < P; q += 64) {
             const int ni = q / HW, p = q - ni * HW;
@@ -530,7 +583,7 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
             a.part_qb[((size_t)grp * 2 * C + ch) * 2 + 1] = s2;
             // bn_qkv's backward coefficients of this (group, channel) only need this workgroup's own sums: written here
             // so the 1x1 dgrad behind does not wait for the finalisation launch (which is left with parameter gradients)
-            const double A = (double)a.w_qkv_bn[ch] * (double)rstd;
+            const double A = (double)p_qkv[3 * oc + 2] * (double)rstd;
             float* cf = a.coef_qkv + ((size_t)grp * 2 * C + ch) * 3;
             cf[0] = (float)A;
             if (a.training) {
@@ -545,7 +598,7 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
     }
 }
 
-static size_t small_bwd_lds_bytes(int gp, int P) { return ((size_t)3 * gp * P + 2 * P + 576 + 80) * sizeof(float); }
+static size_t small_bwd_lds_bytes(int gp, int P) { return ((size_t)3 * gp * P + 2 * P + 576 + 80 + 9 * gp + 4) * sizeof(float); }
 
 bool wopos_small_bwd_ok(const AxialGeom& g, const medt_axial_desc& d) {
     if (!wopos_small_ok(g, d)) return false;

@@ -41,6 +41,25 @@ __device__ __forceinline__ void conv_small_scale_shift(float s, float ss, double
     }
 }
 
+// The same from parameters prefetched into LDS at kernel start (prm[4]: weight, bias, running mean, running variance)
+__device__ __forceinline__ void conv_small_scale_shift_p(float s, float ss, double count, const float* prm, float eps,
+                                                         int training, float& scale, float& shift) {
+    const float g = prm[0], b = prm[1];
+    if (training) {
+        const double mean = (double)s / count;
+        double var = (double)ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        scale = (float)(g * rstd);
+        shift = (float)(b - mean * g * rstd);
+    } else {
+        const float mean = prm[2];
+        const float rstd = (float)(1.0 / sqrt((double)prm[3] + (double)eps));
+        scale = g * rstd;
+        shift = b - mean * g * rstd;
+    }
+}
+
 constexpr int SC_NOC = 16;              // output channels per workgroup
 
 __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a) {
@@ -53,6 +72,16 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
     float* Wl = Z + SC_NOC * P;         // [Cin][SC_NOC]
     float* sc = Wl + Cin * SC_NOC;      // [SC_NOC]
     float* sh = sc + SC_NOC;            // [SC_NOC]
+    float* prm = sh + SC_NOC;           // [SC_NOC][4] BatchNorm parameters, prefetched (no dependent round trip in mid-kernel)
+    if (tid < SC_NOC) {
+        const int ch = oc0 + tid;
+        prm[tid * 4] = a.bn.weight[ch];
+        prm[tid * 4 + 1] = a.bn.bias[ch];
+        if (!a.training) {
+            prm[tid * 4 + 2] = a.bn.running_mean[ch];
+            prm[tid * 4 + 3] = a.bn.running_var[ch];
+        }
+    }
     for (int e = tid; e < SC_NOC * Cin; e += T) {
         const int oc = e / Cin, c = e - oc * Cin;
         Wl[c * SC_NOC + oc] = a.w[(size_t)(oc0 + oc) * Cin + c];
@@ -102,6 +131,17 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
         if ((Cin & 31) == 0) project(std::integral_constant<int, 32>{});
         else project(std::integral_constant<int, 16>{});
     }
+    // the residual of this thread's outputs is fetched now and lands while the statistics are reduced
+    constexpr int RI = 16;                                          // SC_NOC * P / T <= 16 for every launch shape
+    float rv[RI];
+    if (a.res) {
+#pragma unroll
+        for (int k = 0; k < RI; ++k) {
+            const int item = min(tid + k * T, SC_NOC * P - 1);
+            const int oc = item / P, q = item - oc * P, ni = q / HoWo, po = q - ni * HoWo;
+            rv[k] = a.res[((size_t)(n0 + ni) * a.Cout + oc0 + oc) * HoWo + po];
+        }
+    }
     __syncthreads();
     for (int oc = wave; oc < SC_NOC; oc += NW) {
         float s = 0.f, ss = 0.f;
@@ -114,7 +154,7 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
         ss = wave_sum(ss);
         if (lane == 0) {
             const int ch = oc0 + oc;
-            conv_small_scale_shift(s, ss, (double)P, a.bn, ch, a.eps, a.training, sc[oc], sh[oc]);
+            conv_small_scale_shift_p(s, ss, (double)P, prm + oc * 4, a.eps, a.training, sc[oc], sh[oc]);
             if (a.training) {
                 a.partials[((size_t)grp * a.Cout + ch) * 2] = s;
                 a.partials[((size_t)grp * a.Cout + ch) * 2 + 1] = ss;
@@ -122,17 +162,21 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
         }
     }
     __syncthreads();
-    for (int item = tid; item < SC_NOC * P; item += T) {
-        const int oc = item / P, q = item - oc * P, ni = q / HoWo, po = q - ni * HoWo;
-        const size_t idx = ((size_t)(n0 + ni) * a.Cout + oc0 + oc) * HoWo + po;
-        float v = fmaf(Z[item], sc[oc], sh[oc]);
-        if (a.res) v += a.res[idx];
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.y[idx] = v;
+#pragma unroll
+    for (int k = 0; k < RI; ++k) {
+        const int item = tid + k * T;
+        if (item < SC_NOC * P) {
+            const int oc = item / P, q = item - oc * P, ni = q / HoWo, po = q - ni * HoWo;
+            const size_t idx = ((size_t)(n0 + ni) * a.Cout + oc0 + oc) * HoWo + po;
+            float v = fmaf(Z[item], sc[oc], sh[oc]);
+            if (a.res) v += rv[k];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.y[idx] = v;
+        }
     }
 }
 
-static size_t conv_small_lds(int P, int Cin) { return ((size_t)SC_NOC * P + (size_t)Cin * SC_NOC + 2 * SC_NOC) * sizeof(float); }
+static size_t conv_small_lds(int P, int Cin) { return ((size_t)SC_NOC * P + (size_t)Cin * SC_NOC + 6 * SC_NOC) * sizeof(float); }
 
 static bool conv_small_enabled() {
     static const bool on = [] { const char* e = getenv("MEDT_DISABLE_SMALL"); return !(e && e[0] == '1'); }();
