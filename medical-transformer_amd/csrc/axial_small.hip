@@ -83,6 +83,13 @@ __device__ __forceinline__ void small_block_sum(float (&v)[K], float* red, float
     __syncthreads();
 }
 
+// input-channel split of the projection phase: P * KS <= threads, slices of a multiple of 8 channels
+static __host__ __device__ inline int small_ksplit(int P, int T, int C) {
+    int ks = 1;
+    while (ks * 2 <= 16 && ks * 2 * P <= T && C % (ks * 2 * 8) == 0) ks *= 2;
+    return ks;
+}
+
 template <int AXIS, int L, int GP>
 __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     constexpr int HQ = GP / 2, NCH = 2 * GP, RMAX = 2;          // up to 2 rows (positions) per thread: P <= 2 * blockDim.x
@@ -109,56 +116,106 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     }
 
     // 1. qkv_transform rows hg*2gp .. +2gp                                               (axialnet.py:228)
-    //    A work item is a position and a chunk of NOC <= 16 output channels: x is loaded once per item (16 loads in
-    //    flight: one workgroup per CU has nothing else to hide the L2 latency) and the 256 threads stay busy when
-    //    the group has fewer than 256 positions.
-    for (int e = tid; e < NCH * C; e += T) {
-        const int oc = e / C, c = e - oc * C;
-        Wl[c * NCH + oc] = a.w[(size_t)(hg * NCH + oc) * C + c];
-    }
-    __syncthreads();
+    //    The whole kernel is a chain of dependent global round trips, so this phase is built to need one: the weight rows
+    //    and the first 32 input channels of the thread's position are requested together, and when the group has fewer
+    //    positions than the workgroup has threads the input channels are split KS ways over the threads (partial sums
+    //    combined through LDS in a fixed order), so one batch of loads per thread covers its slice.
     {
-        constexpr int NOC_MAX = NCH < 16 ? NCH : 16;
-        int chunks = P >= T ? 1 : T / P;
-        if (chunks > NCH / 4) chunks = NCH / 4;
-        if (chunks < NCH / NOC_MAX) chunks = NCH / NOC_MAX;
-        const int noc = NCH / chunks;                           // 4, 8 or 16
-        auto project = [&](auto cb_tag) {
-            constexpr int CB = decltype(cb_tag)::value;         // x values in flight per thread
-            for (int item = tid; item < P * chunks; item += T) {
-                const int chunk = item / P, q = item - chunk * P, ni = q / HW, p = q - ni * HW, oc0 = chunk * noc;
-                const float* xp = a.x + ((size_t)(n0 + ni) * C) * HW + p;
-                float acc[NOC_MAX];
+        const int KS = small_ksplit(P, T, C), cpk = C / KS;
+        float* Zp = prm + 4 * (NCH + 1 + GP);                   // [KS][NCH][P] partial sums (KS > 1)
+        constexpr int WB = 8, XB = GP >= 16 ? 16 : 32;          // (32 accumulators per position when gp = 16)
+        const int nW = NCH * C;
+        float wr[WB], xv[XB];
+        auto load_w = [&](int base) {
 #pragma unroll
-                for (int o = 0; o < NOC_MAX; ++o) acc[o] = 0.f;
-                for (int c0 = 0; c0 < C; c0 += CB) {
-                    float xv[CB];
+            for (int k = 0; k < WB; ++k) {
+                const int e = min(base + tid + k * T, nW - 1), oc = e / C;
+                wr[k] = a.w[(size_t)(hg * NCH + oc) * C + (e - oc * C)];
+            }
+        };
+        auto store_w = [&](int base) {
 #pragma unroll
-                    for (int k = 0; k < CB; ++k) xv[k] = xp[(size_t)(c0 + k) * HW];
+            for (int k = 0; k < WB; ++k) {
+                const int e = base + tid + k * T;
+                if (e < nW) { const int oc = e / C; Wl[(e - oc * C) * NCH + oc] = wr[k]; }
+            }
+        };
+        const int nitems = KS > 1 ? 1 : (P + T - 1) / T;         // KS > 1: P * KS <= T, one (position, slice) per thread
+        auto locate = [&](int r, bool& act, int& ks, int& q, const float*& xp) {
+            const int item = tid + r * T;
+            act = item < P * KS;
+            ks = act ? item / P : 0;
+            q = act ? item - ks * P : 0;
+            const int ni = q / HW, p = q - ni * HW;
+            xp = a.x + ((size_t)(n0 + ni) * C + (size_t)ks * cpk) * HW + p;
+        };
+        auto load_x = [&](const float* xp, int c0) {
 #pragma unroll
-                    for (int k = 0; k < CB; ++k) {
-                        const float* wr = Wl + (c0 + k) * NCH + oc0;
+            for (int k = 0; k < XB; ++k) xv[k] = xp[(size_t)min(c0 + k, cpk - 1) * HW];
+        };
+        bool act; int ks, q; const float* xp;
+        locate(0, act, ks, q, xp);
+        load_w(0);
+        load_x(xp, 0);                                          // both batches in flight together
+        MEDT_SCHED_FENCE();
+        store_w(0);
+        for (int base = WB * T; base < nW; base += WB * T) {
+            load_w(base);
+            MEDT_SCHED_FENCE();
+            store_w(base);
+        }
+        __syncthreads();
+        for (int r = 0; r < nitems; ++r) {
+            if (r) locate(r, act, ks, q, xp);
+            float acc[NCH];
 #pragma unroll
-                        for (int o = 0; o < NOC_MAX; o += 4)
-                            if (o < noc) {
-                                const float4 w4 = *reinterpret_cast<const float4*>(wr + o);
+            for (int o = 0; o < NCH; ++o) acc[o] = 0.f;
+            for (int c0 = 0; c0 < cpk; c0 += XB) {
+                if (r || c0) {
+                    load_x(xp, c0);
+                    MEDT_SCHED_FENCE();
+                }
+#pragma unroll
+                for (int k8 = 0; k8 < XB; k8 += 8)
+                    if (c0 + k8 < cpk) {                         // slices are multiples of 8 channels
+#pragma unroll
+                        for (int k = k8; k < k8 + 8; ++k) {
+                            const float* wrow = Wl + (ks * cpk + c0 + k) * NCH;
+#pragma unroll
+                            for (int o = 0; o < NCH; o += 4) {
+                                const float4 w4 = *reinterpret_cast<const float4*>(wrow + o);
                                 acc[o] = fmaf(w4.x, xv[k], acc[o]);
                                 acc[o + 1] = fmaf(w4.y, xv[k], acc[o + 1]);
                                 acc[o + 2] = fmaf(w4.z, xv[k], acc[o + 2]);
                                 acc[o + 3] = fmaf(w4.w, xv[k], acc[o + 3]);
                             }
-                    }
-                }
-#pragma unroll
-                for (int o = 0; o < NOC_MAX; ++o)
-                    if (o < noc) {
-                        Q[(oc0 + o) * P + q] = acc[o];
-                        a.qkv_raw[((size_t)(n0 + ni) * 2 * C + hg * NCH + oc0 + o) * HW + p] = acc[o];
+                        }
                     }
             }
-        };
-        if ((C & 31) == 0) project(std::integral_constant<int, 32>{});
-        else project(std::integral_constant<int, 16>{});
+            if (act) {
+                if (KS == 1) {
+                    const int ni = q / HW, p = q - ni * HW;
+#pragma unroll
+                    for (int o = 0; o < NCH; ++o) {
+                        Q[o * P + q] = acc[o];
+                        a.qkv_raw[((size_t)(n0 + ni) * 2 * C + hg * NCH + o) * HW + p] = acc[o];
+                    }
+                } else {
+#pragma unroll
+                    for (int o = 0; o < NCH; ++o) Zp[(ks * NCH + o) * P + q] = acc[o];
+                }
+            }
+        }
+        if (KS > 1) {
+            __syncthreads();
+            for (int item = tid; item < NCH * P; item += T) {
+                const int oc = item / P, qq = item - oc * P, ni = qq / HW, p = qq - ni * HW;
+                float v = Zp[item];
+                for (int k = 1; k < KS; ++k) v += Zp[k * NCH * P + item];
+                Q[item] = v;
+                a.qkv_raw[((size_t)(n0 + ni) * 2 * C + hg * NCH + oc) * HW + p] = v;
+            }
+        }
     }
     __syncthreads();
     // 2. bn_qkv: batch statistics over the group's positions (one wave per channel)      (:228)
@@ -291,7 +348,9 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
 }
 
 static size_t small_lds_bytes(int gp, int P, int C) {
-    return ((size_t)3 * gp * P + 32 + 32 + 64 + 2 * gp * C + 4 * (3 * gp + 1)) * sizeof(float);
+    const int ks = small_ksplit(P, P > 512 ? 512 : 256, C);
+    return ((size_t)3 * gp * P + 32 + 32 + 64 + 2 * gp * C + 4 * (3 * gp + 1) + (ks > 1 ? (size_t)ks * 2 * gp * P : 0)) *
+           sizeof(float);
 }
 
 static bool small_enabled() {

@@ -62,17 +62,33 @@ __device__ __forceinline__ void conv_small_scale_shift_p(float s, float ss, doub
 
 constexpr int SC_NOC = 16;              // output channels per workgroup
 
-__global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a) {
+// Everything in this kernel is a chain of dependent global round trips (one workgroup, a few thousand floats), so the
+// structure minimises them: the weight slab and the input values of the first 32 channels are requested together, and
+// when the group has fewer positions than the workgroup has threads the input channels are split KS ways over the
+// threads (partial sums combined through LDS in a fixed order) so that every thread's loads fit one batch.
+static __host__ __device__ inline int conv_small_threads(int P) { return P <= 256 ? 256 : (P <= 512 ? 512 : 1024); }
+static __host__ __device__ inline int conv_small_ksplit(int P, int Cin) {
+    int ks = 1;
+    const int T = conv_small_threads(P);
+    while (ks * 2 <= 16 && ks * 2 * P <= T && Cin % (ks * 2 * 8) == 0) ks *= 2;      // slices of a multiple of 8 channels
+    return ks;
+}
+
+template <int T>                                    // 256 ... 1024 threads: one position per thread when the group has 1024
+__global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = blockIdx.x, oc0 = blockIdx.y * SC_NOC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int T = blockDim.x, NW = T >> 6;           // 256 ... 1024 threads: one position per thread when the group has 1024
+    constexpr int NW = T >> 6;
     const int Cin = a.Cin, W = a.W, HW = a.H * a.W, st = a.stride, Ho = a.H / st, Wo = a.W / st, HoWo = Ho * Wo;
     const int P = a.npg * HoWo, n0 = grp * a.npg;
+    const int KS = conv_small_ksplit(P, Cin), cpk = Cin / KS;
     float* Z = smem;                    // [SC_NOC][P]
     float* Wl = Z + SC_NOC * P;         // [Cin][SC_NOC]
     float* sc = Wl + Cin * SC_NOC;      // [SC_NOC]
     float* sh = sc + SC_NOC;            // [SC_NOC]
     float* prm = sh + SC_NOC;           // [SC_NOC][4] BatchNorm parameters, prefetched (no dependent round trip in mid-kernel)
+    float* sums = prm + 4 * SC_NOC;     // [SC_NOC][2]
+    float* Zp = sums + 2 * SC_NOC;      // [KS][SC_NOC][P] partial sums of the channel slices (KS > 1)
     if (tid < SC_NOC) {
         const int ch = oc0 + tid;
         prm[tid * 4] = a.bn.weight[ch];
@@ -82,54 +98,88 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
             prm[tid * 4 + 3] = a.bn.running_var[ch];
         }
     }
-    for (int e = tid; e < SC_NOC * Cin; e += T) {
-        const int oc = e / Cin, c = e - oc * Cin;
-        Wl[c * SC_NOC + oc] = a.w[(size_t)(oc0 + oc) * Cin + c];
+    // this thread's work item: position q, channel slice ks
+    const bool act = tid < P * KS;
+    const int ks = act ? tid / P : 0, q = act ? tid - ks * P : 0, ni = q / HoWo, po = q - ni * HoWo;
+    const int ho = po / Wo, wo = po - ho * Wo;
+    const float* xp = a.x + ((size_t)(n0 + ni) * Cin + (size_t)ks * cpk) * HW + (ho * st) * W + wo * st;
+    constexpr int WB = 8, XB = T == 1024 ? 16 : 32;   // (1024 threads: 128 VGPRs per lane)
+    const int nW = SC_NOC * Cin;
+    float wr[WB], xv[XB];
+    auto load_w = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int e = min(base + tid + k * T, nW - 1), oc = e / Cin;
+            wr[k] = a.w[(size_t)(oc0 + oc) * Cin + (e - oc * Cin)];
+        }
+    };
+    auto store_w = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int e = base + tid + k * T;
+            if (e < nW) { const int oc = e / Cin; Wl[(e - oc * Cin) * SC_NOC + oc] = wr[k]; }
+        }
+    };
+    auto load_x = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < XB; ++k) xv[k] = xp[(size_t)min(c0 + k, cpk - 1) * HW];
+    };
+    load_w(0);
+    load_x(0);                                        // both batches in flight together
+    MEDT_SCHED_FENCE();
+    store_w(0);
+    for (int base = WB * T; base < nW; base += WB * T) {
+        load_w(base);
+        MEDT_SCHED_FENCE();
+        store_w(base);
     }
     __syncthreads();
-    {
-        // a work item = one output position x NOC_T channels; groups with few positions split the 16 channels over
-        // more threads
-        int chunks = P >= T ? 1 : T / P;
-        if (chunks > SC_NOC / 4) chunks = SC_NOC / 4;
-        const int noc = SC_NOC / chunks;                            // 16, 8 or 4
-        auto project = [&](auto cb_tag) {
-            constexpr int CB = decltype(cb_tag)::value;
-            for (int item = tid; item < P * chunks; item += T) {
-                const int chunk = item / P, q = item - chunk * P, ni = q / HoWo, po = q - ni * HoWo, c0o = chunk * noc;
-                const int ho = po / Wo, wo = po - ho * Wo;
-                const float* xp = a.x + ((size_t)(n0 + ni) * Cin) * HW + (ho * st) * W + wo * st;
-                float acc[SC_NOC];
+    float acc[SC_NOC];
 #pragma unroll
-                for (int o = 0; o < SC_NOC; ++o) acc[o] = 0.f;
-                for (int c0 = 0; c0 < Cin; c0 += CB) {
-                    float xv[CB];
+    for (int o = 0; o < SC_NOC; ++o) acc[o] = 0.f;
+    for (int c0 = 0; c0 < cpk; c0 += XB) {
+        if (c0) {
+            load_x(c0);
+            MEDT_SCHED_FENCE();
+        }
 #pragma unroll
-                    for (int k = 0; k < CB; ++k) xv[k] = xp[(size_t)(c0 + k) * HW];
+        for (int k8 = 0; k8 < XB; k8 += 8)
+            if (c0 + k8 < cpk) {                     // slices are multiples of 8 channels
 #pragma unroll
-                    for (int k = 0; k < CB; ++k) {
-                        const float* wr = Wl + (c0 + k) * SC_NOC + c0o;
+                for (int k = k8; k < k8 + 8; ++k) {
+                    const float* wrow = Wl + (ks * cpk + c0 + k) * SC_NOC;
 #pragma unroll
-                        for (int o = 0; o < SC_NOC; o += 4)
-                            if (o < noc) {
-                                const float4 w4 = *reinterpret_cast<const float4*>(wr + o);
-                                acc[o] = fmaf(w4.x, xv[k], acc[o]);
-                                acc[o + 1] = fmaf(w4.y, xv[k], acc[o + 1]);
-                                acc[o + 2] = fmaf(w4.z, xv[k], acc[o + 2]);
-                                acc[o + 3] = fmaf(w4.w, xv[k], acc[o + 3]);
-                            }
+                    for (int o = 0; o < SC_NOC; o += 4) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(wrow + o);
+                        acc[o] = fmaf(w4.x, xv[k], acc[o]);
+                        acc[o + 1] = fmaf(w4.y, xv[k], acc[o + 1]);
+                        acc[o + 2] = fmaf(w4.z, xv[k], acc[o + 2]);
+                        acc[o + 3] = fmaf(w4.w, xv[k], acc[o + 3]);
                     }
                 }
-#pragma unroll
-                for (int o = 0; o < SC_NOC; ++o)
-                    if (o < noc) {
-                        Z[(c0o + o) * P + q] = acc[o];
-                        a.z[((size_t)(n0 + ni) * a.Cout + oc0 + c0o + o) * HoWo + po] = acc[o];
-                    }
             }
-        };
-        if ((Cin & 31) == 0) project(std::integral_constant<int, 32>{});
-        else project(std::integral_constant<int, 16>{});
+    }
+    if (KS == 1) {
+        if (act) {
+#pragma unroll
+            for (int o = 0; o < SC_NOC; ++o) {
+                Z[o * P + q] = acc[o];
+                a.z[((size_t)(n0 + ni) * a.Cout + oc0 + o) * HoWo + po] = acc[o];
+            }
+        }
+    } else {
+        if (act) {
+#pragma unroll
+            for (int o = 0; o < SC_NOC; ++o) Zp[(ks * SC_NOC + o) * P + q] = acc[o];
+        }
+        __syncthreads();
+        for (int item = tid; item < SC_NOC * P; item += T) {
+            const int oc = item / P, qq = item - oc * P, n2 = qq / HoWo, p2 = qq - n2 * HoWo;
+            float v = Zp[item];
+            for (int k = 1; k < KS; ++k) v += Zp[k * SC_NOC * P + item];
+            Z[item] = v;
+            a.z[((size_t)(n0 + n2) * a.Cout + oc0 + oc) * HoWo + p2] = v;
+        }
     }
     // the residual of this thread's outputs is fetched now and lands while the statistics are reduced
     constexpr int RI = 16;                                          // SC_NOC * P / T <= 16 for every launch shape
@@ -138,27 +188,33 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
 #pragma unroll
         for (int k = 0; k < RI; ++k) {
             const int item = min(tid + k * T, SC_NOC * P - 1);
-            const int oc = item / P, q = item - oc * P, ni = q / HoWo, po = q - ni * HoWo;
-            rv[k] = a.res[((size_t)(n0 + ni) * a.Cout + oc0 + oc) * HoWo + po];
+            const int oc = item / P, qq = item - oc * P, n2 = qq / HoWo, p2 = qq - n2 * HoWo;
+            rv[k] = a.res[((size_t)(n0 + n2) * a.Cout + oc0 + oc) * HoWo + p2];
         }
     }
     __syncthreads();
     for (int oc = wave; oc < SC_NOC; oc += NW) {
         float s = 0.f, ss = 0.f;
-        for (int q = lane; q < P; q += 64) {
-            const float v = Z[oc * P + q];
+        for (int qq = lane; qq < P; qq += 64) {
+            const float v = Z[oc * P + qq];
             s += v;
             ss = fmaf(v, v, ss);
         }
         s = wave_sum(s);
         ss = wave_sum(ss);
         if (lane == 0) {
-            const int ch = oc0 + oc;
-            conv_small_scale_shift_p(s, ss, (double)P, prm + oc * 4, a.eps, a.training, sc[oc], sh[oc]);
-            if (a.training) {
-                a.partials[((size_t)grp * a.Cout + ch) * 2] = s;
-                a.partials[((size_t)grp * a.Cout + ch) * 2 + 1] = ss;
-            }
+            sums[oc * 2] = s;
+            sums[oc * 2 + 1] = ss;
+        }
+    }
+    __syncthreads();
+    if (tid < SC_NOC) {                               // the double-precision finalisation of the 16 channels side by side
+        const int ch = oc0 + tid;
+        const float s = sums[tid * 2], ss = sums[tid * 2 + 1];
+        conv_small_scale_shift_p(s, ss, (double)P, prm + tid * 4, a.eps, a.training, sc[tid], sh[tid]);
+        if (a.training) {
+            a.partials[((size_t)grp * a.Cout + ch) * 2] = s;
+            a.partials[((size_t)grp * a.Cout + ch) * 2 + 1] = ss;
         }
     }
     __syncthreads();
@@ -166,8 +222,8 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
     for (int k = 0; k < RI; ++k) {
         const int item = tid + k * T;
         if (item < SC_NOC * P) {
-            const int oc = item / P, q = item - oc * P, ni = q / HoWo, po = q - ni * HoWo;
-            const size_t idx = ((size_t)(n0 + ni) * a.Cout + oc0 + oc) * HoWo + po;
+            const int oc = item / P, qq = item - oc * P, n2 = qq / HoWo, p2 = qq - n2 * HoWo;
+            const size_t idx = ((size_t)(n0 + n2) * a.Cout + oc0 + oc) * HoWo + p2;
             float v = fmaf(Z[item], sc[oc], sh[oc]);
             if (a.res) v += rv[k];
             if (a.relu) v = fmaxf(v, 0.f);
@@ -176,7 +232,10 @@ __global__ __launch_bounds__(1024) void conv1x1_bn_small_fwd_kernel(SmallConvArg
     }
 }
 
-static size_t conv_small_lds(int P, int Cin) { return ((size_t)SC_NOC * P + (size_t)Cin * SC_NOC + 6 * SC_NOC) * sizeof(float); }
+static size_t conv_small_lds(int P, int Cin) {
+    const int ks = conv_small_ksplit(P, Cin);
+    return ((size_t)SC_NOC * P + (size_t)Cin * SC_NOC + 8 * SC_NOC + (ks > 1 ? (size_t)ks * SC_NOC * P : 0)) * sizeof(float);
+}
 
 static bool conv_small_enabled() {
     static const bool on = [] { const char* e = getenv("MEDT_DISABLE_SMALL"); return !(e && e[0] == '1'); }();
@@ -198,9 +257,12 @@ int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, cons
     a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.stride = d.stride; a.npg = d.N / d.bn_groups;
     a.relu = d.relu; a.training = d.training ? 1 : 0; a.eps = d.eps;
     const int P = a.npg * (d.H / d.stride) * (d.W / d.stride);
-    const int threads = P <= 256 ? 256 : (P <= 512 ? 512 : 1024);
-    hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel, dim3(d.bn_groups, d.Cout / SC_NOC), dim3(threads),
-                       conv_small_lds(P, d.Cin), s, a);
+    const int threads = conv_small_threads(P);
+    const dim3 grid(d.bn_groups, d.Cout / SC_NOC);
+    const size_t lds = conv_small_lds(P, d.Cin);
+    if (threads == 256) hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel<256>, grid, dim3(256), lds, s, a);
+    else if (threads == 512) hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel<512>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel<1024>, grid, dim3(1024), lds, s, a);
     return launch_status("conv1x1_bn_small_fwd");
 }
 
