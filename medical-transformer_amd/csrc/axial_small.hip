@@ -151,7 +151,11 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         };
         auto load_x = [&](const float* xp, int c0) {
 #pragma unroll
-            for (int k = 0; k < XB; ++k) xv[k] = xp[(size_t)min(c0 + k, cpk - 1) * HW];
+            for (int k8 = 0; k8 < XB; k8 += 8)
+                if (c0 + k8 < cpk) {                             // (uniform: slices are multiples of 8 channels)
+#pragma unroll
+                    for (int k = k8; k < k8 + 8; ++k) xv[k] = xp[(size_t)(c0 + k) * HW];
+                }
         };
         bool act; int ks, q; const float* xp;
         locate(0, act, ks, q, xp);
@@ -229,12 +233,18 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         s = wave_sum(s);
         ss = wave_sum(ss);
         if (lane == 0) {
-            const int ch = hg * NCH + oc;
-            small_scale_shift_p(s, ss, (double)P, prm + oc * 4, a.eps, a.training, sc[oc], sh[oc]);
-            if (a.training) {
-                a.part_q[((size_t)grp * 2 * C + ch) * 2] = s;
-                a.part_q[((size_t)grp * 2 * C + ch) * 2 + 1] = ss;
-            }
+            red[oc * 2] = s;
+            red[oc * 2 + 1] = ss;
+        }
+    }
+    __syncthreads();
+    if (tid < NCH) {                                   // the double-precision finalisations side by side, not one per wave turn
+        const int ch = hg * NCH + tid;
+        const float s = red[tid * 2], ss = red[tid * 2 + 1];
+        small_scale_shift_p(s, ss, (double)P, prm + tid * 4, a.eps, a.training, sc[tid], sh[tid]);
+        if (a.training) {
+            a.part_q[((size_t)grp * 2 * C + ch) * 2] = s;
+            a.part_q[((size_t)grp * 2 * C + ch) * 2 + 1] = ss;
         }
     }
     __syncthreads();
@@ -323,12 +333,18 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         s = wave_sum(s);
         ss = wave_sum(ss);
         if (lane == 0) {
-            const int ch = hg * GP + c;
-            small_scale_shift_p(s, ss, (double)P, prm + (NCH + 1 + c) * 4, a.eps, a.training, sc[c], sh[c]);
-            if (a.training) {
-                a.part_o[((size_t)grp * C + ch) * 2] = s;
-                a.part_o[((size_t)grp * C + ch) * 2 + 1] = ss;
-            }
+            red[c * 2] = s;
+            red[c * 2 + 1] = ss;
+        }
+    }
+    __syncthreads();
+    if (tid < GP) {
+        const int ch = hg * GP + tid;
+        const float s = red[tid * 2], ss = red[tid * 2 + 1];
+        small_scale_shift_p(s, ss, (double)P, prm + (NCH + 1 + tid) * 4, a.eps, a.training, sc[tid], sh[tid]);
+        if (a.training) {
+            a.part_o[((size_t)grp * C + ch) * 2] = s;
+            a.part_o[((size_t)grp * C + ch) * 2 + 1] = ss;
         }
     }
     __syncthreads();
@@ -458,40 +474,78 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
         p_qkv[(tid - 64) * 3 + 2] = a.w_qkv_bn[ch];
     }
 
-    // normalised q|k|v of this head and the row log-sum-exps
-    for (int item = tid; item < NCH * P; item += T) {
-        const int oc = item / P, q = item - oc * P, ni = q / HW, p = q - ni * HW, ch = hg * NCH + oc;
-        Q[item] = fmaf(a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p], a.sq.scale[grp * 2 * C + ch],
-                       a.sq.shift[grp * 2 * C + ch]);
+    // Every global value the first phases need is requested in one go (a branch or a wait per element would turn this
+    // into a dozen dependent round trips): the row log-sum-exps, the first batch of q|k|v rows with their bn_qkv affine,
+    // and dy / y / stacked of this thread's positions.  Threads past the last position read position P-1 (ignored).
+    constexpr int QB = 8;
+    const int nQ = NCH * P;
+    float lsev[R], rawv[QB], scv[QB], shv[QB];
+    auto load_q = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < QB; ++k) {
+            const int item = min(base + tid + k * T, nQ - 1);
+            const int oc = item / P, q = item - oc * P, ni = q / HW, p = q - ni * HW, ch = hg * NCH + oc;
+            rawv[k] = a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p];
+            scv[k] = a.sq.scale[grp * 2 * C + ch];
+            shv[k] = a.sq.shift[grp * 2 * C + ch];
+        }
+    };
+    auto store_q = [&](int base) {                          // normalised q|k|v of this head
+#pragma unroll
+        for (int k = 0; k < QB; ++k) {
+            const int item = base + tid + k * T;
+            if (item < nQ) Q[item] = fmaf(rawv[k], scv[k], shv[k]);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = min(tid + r * T, P - 1), ni = q / HW, p = q - ni * HW;
+        lsev[r] = a.lse[((size_t)(n0 + ni) * G + hg) * HW + p];
     }
-    for (int q = tid; q < P; q += T) {
-        const int ni = q / HW, p = q - ni * HW;
-        lse[q] = a.lse[((size_t)(n0 + ni) * G + hg) * HW + p];
-    }
+    load_q(0);
     // 1. AvgPool2d + ReLU-mask + bn_output backward                                        (axialnet.py:242-253)
-    float gy[R][GP], sv[R][GP];
+    float gy[R][GP], sv[R][GP], yv[R][GP];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = min(tid + r * T, P - 1), ni = q / HW, p = q - ni * HW, h = p / W, w = p - h * W;
+        const size_t po = (size_t)(h / st) * Wo + (w / st);
+#pragma unroll
+        for (int c = 0; c < GP; ++c) {
+            const int ch = hg * GP + c;
+            const size_t yo = ((size_t)(n0 + ni) * C + ch) * Ho * Wo + po;
+            gy[r][c] = a.dy[yo];
+            if (a.out_relu) yv[r][c] = a.y[yo];
+            sv[r][c] = a.stacked[((size_t)(n0 + ni) * C + ch) * HW + p];
+        }
+    }
+    MEDT_SCHED_FENCE();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = tid + r * T;
+        if (q < P) lse[q] = lsev[r];
+    }
+    store_q(0);
+    for (int base = QB * T; base < nQ; base += QB * T) {
+        load_q(base);
+        MEDT_SCHED_FENCE();
+        store_q(base);
+    }
+    __syncthreads();                                        // (also publishes the prefetched statistics p_out / p_sim / p_qkv)
     {
         float v[2 * GP];
 #pragma unroll
         for (int k = 0; k < 2 * GP; ++k) v[k] = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int q = tid + r * T;
-            if (q < P) {
-                const int ni = q / HW, p = q - ni * HW, h = p / W, w = p - h * W;
-                const size_t po = (size_t)(h / st) * Wo + (w / st);
+            const bool valid = tid + r * T < P;
 #pragma unroll
-                for (int c = 0; c < GP; ++c) {
-                    const int ch = hg * GP + c;
-                    const size_t yo = ((size_t)(n0 + ni) * C + ch) * Ho * Wo + po;
-                    float d = a.dy[yo];
-                    if (a.out_relu && !(a.y[yo] > 0.f)) d = 0.f;
-                    const float s = a.stacked[((size_t)(n0 + ni) * C + ch) * HW + p];
-                    gy[r][c] = d;
-                    sv[r][c] = s;
-                    v[2 * c] += d;
-                    v[2 * c + 1] += d * ((s - a.so.mean[grp * C + ch]) * a.so.rstd[grp * C + ch]);
-                }
+            for (int c = 0; c < GP; ++c) {
+                float d = gy[r][c];
+                if (a.out_relu && !(yv[r][c] > 0.f)) d = 0.f;
+                if (!valid) d = 0.f;
+                gy[r][c] = d;
+                v[2 * c] += d;
+                v[2 * c + 1] += d * ((sv[r][c] - p_out[3 * c]) * p_out[3 * c + 1]);
             }
         }
         small_block_sum<2 * GP>(v, red, red + 512, NW);
@@ -638,21 +692,28 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (lane == 0) {
-            a.part_qb[((size_t)grp * 2 * C + ch) * 2] = s1;
-            a.part_qb[((size_t)grp * 2 * C + ch) * 2 + 1] = s2;
-            // bn_qkv's backward coefficients of this (group, channel) only need this workgroup's own sums: written here
-            // so the 1x1 dgrad behind does not wait for the finalisation launch (which is left with parameter gradients)
-            const double A = (double)p_qkv[3 * oc + 2] * (double)rstd;
-            float* cf = a.coef_qkv + ((size_t)grp * 2 * C + ch) * 3;
-            cf[0] = (float)A;
-            if (a.training) {
-                const double m1 = (double)s1 / a.row_count, m2 = (double)s2 / a.row_count;
-                cf[1] = (float)(-A * (double)rstd * m2);
-                cf[2] = (float)(A * ((double)rstd * (double)mean * m2 - m1));
-            } else {
-                cf[1] = 0.f;
-                cf[2] = 0.f;
-            }
+            red[oc * 2] = s1;
+            red[oc * 2 + 1] = s2;
+        }
+    }
+    __syncthreads();
+    if (tid < NCH) {                                   // the double-precision parts side by side, not one per wave turn
+        const int ch = hg * NCH + tid;
+        const float s1 = red[tid * 2], s2 = red[tid * 2 + 1], mean = p_qkv[3 * tid], rstd = p_qkv[3 * tid + 1];
+        a.part_qb[((size_t)grp * 2 * C + ch) * 2] = s1;
+        a.part_qb[((size_t)grp * 2 * C + ch) * 2 + 1] = s2;
+        // bn_qkv's backward coefficients of this (group, channel) only need this workgroup's own sums: written here
+        // so the 1x1 dgrad behind does not wait for the finalisation launch (which is left with parameter gradients)
+        const double A = (double)p_qkv[3 * tid + 2] * (double)rstd;
+        float* cfo = a.coef_qkv + ((size_t)grp * 2 * C + ch) * 3;
+        cfo[0] = (float)A;
+        if (a.training) {
+            const double m1 = (double)s1 / a.row_count, m2 = (double)s2 / a.row_count;
+            cfo[1] = (float)(-A * (double)rstd * m2);
+            cfo[2] = (float)(A * ((double)rstd * (double)mean * m2 - m1));
+        } else {
+            cfo[1] = 0.f;
+            cfo[2] = 0.f;
         }
     }
 }

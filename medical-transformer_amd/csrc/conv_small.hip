@@ -121,8 +121,17 @@ __global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a
         }
     };
     auto load_x = [&](int c0) {
+        if constexpr (T == 1024) {                   // (128 VGPRs per lane: the branch-free form allocates fewer)
 #pragma unroll
-        for (int k = 0; k < XB; ++k) xv[k] = xp[(size_t)min(c0 + k, cpk - 1) * HW];
+            for (int k = 0; k < XB; ++k) xv[k] = xp[(size_t)min(c0 + k, cpk - 1) * HW];
+        } else {
+#pragma unroll
+            for (int k8 = 0; k8 < XB; k8 += 8)
+                if (c0 + k8 < cpk) {                 // (uniform: slices are multiples of 8 channels)
+#pragma unroll
+                    for (int k = k8; k < k8 + 8; ++k) xv[k] = xp[(size_t)(c0 + k) * HW];
+                }
+        }
     };
     load_w(0);
     load_x(0);                                        // both batches in flight together
