@@ -11,3 +11,4 @@ done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python bench.py --no-cpu-baseline --no-roofline > $O/bench_prof.log 2>&1
 find $O -name "*kernel_trace.csv" -size +30M -delete
 cat $O/tests.txt; cat $O/ab.txt
+if [ -n "$ROOF" ]; then timeout 300 python bench.py --roofline-only 2>/dev/null | tail -1 > $O/roofline.json; cat $O/roofline.json | cut -c1-1500; fi
