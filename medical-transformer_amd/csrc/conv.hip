@@ -229,10 +229,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
 template <int K, int CT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int H, int W,
-    int Cout, int Ho, int Wo, int stride, int pad, const float* __restrict__ add) {
+    int Cout, int Ho, int Wo, int stride, int pad, const float* __restrict__ add, int stage_dy) {
     constexpr int KK = K * K;
     __shared__ float red[3][CT][64];
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CT][KK]: this workgroup's weight slice
+    // stage_dy: the output gradient of the images this workgroup touches fits in LDS too ([image][Cout][Ho*Wo], after the
+    // weights): the contraction loop then has no global loads at all (decoder1_p: 2x2 -> 1x1 maps, 16 images per workgroup)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int HW = H * W;
     const long q = (long)blockIdx.x * 64 + lane;
@@ -240,6 +242,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     for (int e = threadIdx.x; e < Cout * CT * KK; e += MEDT_THREADS) {
         const int o = e / (CT * KK), r = e - o * (CT * KK);
         wl[e] = w[((size_t)o * Cin + c0) * KK + r];
+    }
+    float* dl = wl + Cout * CT * KK;
+    const int HoWo_ = Ho * Wo;
+    const int nb0 = (int)(((long)blockIdx.x * 64) / HW);
+    if (stage_dy) {
+        const int nb1 = min(N - 1, (int)(((long)blockIdx.x * 64 + 63) / HW));
+        const int cnt = (nb1 - nb0 + 1) * Cout * HoWo_;
+        const float* src = dy + (size_t)nb0 * Cout * HoWo_;
+        for (int e = threadIdx.x; e < cnt; e += MEDT_THREADS) dl[e] = src[e];
     }
     const bool ok = q < (long)N * HW;
     const int n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
@@ -265,14 +276,22 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     __syncthreads();
     constexpr int U = K == 1 ? 16 : 4;                             // output channels per batch of loads
     const int HoWo = Ho * Wo;
+    const float* dln = dl + (size_t)(n - nb0) * Cout * HoWo;   // (stage_dy) this lane's image in LDS
     auto taps = [&](auto u_tag, int o) {
         constexpr int UU = decltype(u_tag)::value;
         float dr[UU][KK];
+        if (stage_dy) {
 #pragma unroll
-        for (int u = 0; u < UU; ++u)
+            for (int u = 0; u < UU; ++u)
 #pragma unroll
-            for (int t = 0; t < KK; ++t) dr[u][t] = dyn[(size_t)(o + u) * HoWo + max(off[t], 0)];
-        MEDT_SCHED_FENCE();
+                for (int t = 0; t < KK; ++t) dr[u][t] = dln[(o + u) * HoWo + max(off[t], 0)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < UU; ++u)
+#pragma unroll
+                for (int t = 0; t < KK; ++t) dr[u][t] = dyn[(size_t)(o + u) * HoWo + max(off[t], 0)];
+            MEDT_SCHED_FENCE();
+        }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             float dv[KK];
@@ -316,12 +335,17 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
     if constexpr (K != 7) {
         if ((long)N * H * W <= 4096 && Cout >= 64 && conv_bwd_data_ws_enabled()) {
             const unsigned g64 = (unsigned)(((long)N * H * W + 63) / 64);
+            // images one 64-position workgroup can touch, and their output gradient in floats
+            const int imgs = H * W >= 64 ? 2 : 64 / (H * W) + 1;
+            const size_t dy_floats = (size_t)imgs * Cout * Ho * Wo;
 #define MEDT_LAUNCH_WS(CT)                                                                                           \
     hipLaunchKernelGGL((conv2d_bwd_data_ws_kernel<K, CT>), dim3(g64, Cin / CT), dim3(MEDT_THREADS),                   \
-                       (size_t)Cout * CT * K * K * sizeof(float), s, dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, add)
+                       ((size_t)Cout * CT * K * K + (stage ? dy_floats : 0)) * sizeof(float), s, dy, w, dx, N, Cin, H, W, \
+                       Cout, Ho, Wo, stride, pad, add, stage)
             int ct = pick_tile(Cin, K == 1 ? 8 : 4, g64);
             while (ct > 1 && (size_t)Cout * ct * K * K * sizeof(float) > 48 * 1024) ct >>= 1;
             if ((size_t)Cout * ct * K * K * sizeof(float) > 48 * 1024) ct = 0;          // does not fit: the kernel below
+            const int stage = (K == 3 && ct && ((size_t)Cout * ct * K * K + dy_floats) * sizeof(float) <= 60 * 1024) ? 1 : 0;
             switch (ct) {
                 case 0: break;
                 case 8: if constexpr (K == 1) { MEDT_LAUNCH_WS(8); } break;

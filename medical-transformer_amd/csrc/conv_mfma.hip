@@ -379,7 +379,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
     if (q < per_group) {
         const size_t qg = (size_t)grp * ppg64 * 64 + q;          // position index used by the tile kernel
         float a = bias ? bias[o] : 0.f;
-        for (int s = 0; s < nslices; ++s) a += slices[s * slice_stride + qg * Cout + o];
+        const float* sp = slices + qg * Cout + o;
+        int s = 0;
+        for (; s + 8 <= nslices; s += 8) {                 // 8 slices' loads in flight, summed in slice order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(s + u) * slice_stride];
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+            MEDT_SCHED_FENCE();
+        }
+        for (; s < nslices; ++s) a += sp[(size_t)s * slice_stride];
         const int n = grp * npg + q / HoWo, p = q % HoWo;
         y[((size_t)n * Cout + o) * HoWo + p] = relu ? fmaxf(a, 0.f) : a;
         v[0] = a;
