@@ -678,22 +678,53 @@ __global__ __launch_bounds__(512) void wopos_small_bwd_kernel(SmallBwdArgs a) {
         }
     }
     __syncthreads();
-    for (int oc = wave; oc < NCH; oc += NW) {
-        const int ch = hg * NCH + oc;
-        const float mean = p_qkv[3 * oc], rstd = p_qkv[3 * oc + 1];
-        float s1 = 0.f, s2 = 0.f;
-        for (int q = lane; q < P; q += 64) {
-            const int ni = q / HW, p = q - ni * HW;
-            const float g = Q[oc * P + q];
-            const float xh = (a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p] - mean) * rstd;
-            s1 += g;
-            s2 = fmaf(g, xh, s2);
+    {
+        // each wave reduces channels wave, wave + NW, ...: the saved pre-BatchNorm activations of all of them are requested
+        // in one batch (4 positions per lane at a time) instead of one global round trip per channel
+        constexpr int NWc = R == 2 ? 8 : 4, CPW = (NCH + NWc - 1) / NWc, QB = 4;
+        float s1[CPW], s2[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) s1[j] = s2[j] = 0.f;
+        for (int q0 = lane; q0 < P; q0 += 64 * QB) {
+            float rw[CPW][QB];
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int ch = hg * NCH + min(wave + j * NWc, NCH - 1);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const int q = min(q0 + 64 * u, P - 1), ni = q / HW, p = q - ni * HW;
+                    rw[j][u] = a.qkv_raw[((size_t)(n0 + ni) * 2 * C + ch) * HW + p];
+                }
+            }
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int oc = wave + j * NWc;
+                if (oc < NCH) {
+                    const float mean = p_qkv[3 * oc], rstd = p_qkv[3 * oc + 1];
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) {
+                        const int q = q0 + 64 * u;
+                        if (q < P) {
+                            const float g = Q[oc * P + q];
+                            s1[j] += g;
+                            s2[j] = fmaf(g, (rw[j][u] - mean) * rstd, s2[j]);
+                        }
+                    }
+                }
+            }
+            MEDT_SCHED_FENCE();
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) {
-            red[oc * 2] = s1;
-            red[oc * 2 + 1] = s2;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const int oc = wave + j * NWc;
+            if (oc < NCH) {
+                const float t1 = wave_sum(s1[j]), t2 = wave_sum(s2[j]);
+                if (lane == 0) {
+                    red[oc * 2] = t1;
+                    red[oc * 2 + 1] = t2;
+                }
+            }
         }
     }
     __syncthreads();

@@ -239,18 +239,40 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     const int HW = H * W;
     const long q = (long)blockIdx.x * 64 + lane;
     const int c0 = blockIdx.y * CT;
-    for (int e = threadIdx.x; e < Cout * CT * KK; e += MEDT_THREADS) {
-        const int o = e / (CT * KK), r = e - o * (CT * KK);
-        wl[e] = w[((size_t)o * Cin + c0) * KK + r];
+    {
+        const int nw = Cout * CT * KK;
+        for (int e0 = threadIdx.x; e0 < nw; e0 += 8 * MEDT_THREADS) {            // 8 loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * MEDT_THREADS, nw - 1), o = e / (CT * KK), r = e - o * (CT * KK);
+                v[u] = w[((size_t)o * Cin + c0) * KK + r];
+            }
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * MEDT_THREADS < nw) wl[e0 + u * MEDT_THREADS] = v[u];
+        }
     }
     float* dl = wl + Cout * CT * KK;
     const int HoWo_ = Ho * Wo;
     const int nb0 = (int)(((long)blockIdx.x * 64) / HW);
+    const int img_stride = Cout * HoWo_ + 1;                       // +1: lanes of different images hit different banks
     if (stage_dy) {
         const int nb1 = min(N - 1, (int)(((long)blockIdx.x * 64 + 63) / HW));
-        const int cnt = (nb1 - nb0 + 1) * Cout * HoWo_;
-        const float* src = dy + (size_t)nb0 * Cout * HoWo_;
-        for (int e = threadIdx.x; e < cnt; e += MEDT_THREADS) dl[e] = src[e];
+        const int per = Cout * HoWo_, cnt = (nb1 - nb0 + 1) * per;
+        const float* src = dy + (size_t)nb0 * per;
+        for (int e0 = threadIdx.x; e0 < cnt; e0 += 8 * MEDT_THREADS) {      // 8 loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * MEDT_THREADS, cnt - 1)];
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * MEDT_THREADS;
+                if (e < cnt) { const int im = e / per; dl[im * img_stride + (e - im * per)] = v[u]; }
+            }
+        }
     }
     const bool ok = q < (long)N * HW;
     const int n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     __syncthreads();
     constexpr int U = K == 1 ? 16 : 4;                             // output channels per batch of loads
     const int HoWo = Ho * Wo;
-    const float* dln = dl + (size_t)(n - nb0) * Cout * HoWo;   // (stage_dy) this lane's image in LDS
+    const float* dln = dl + (n - nb0) * img_stride;            // (stage_dy) this lane's image in LDS
     auto taps = [&](auto u_tag, int o) {
         constexpr int UU = decltype(u_tag)::value;
         float dr[UU][KK];
@@ -337,7 +359,7 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
             const unsigned g64 = (unsigned)(((long)N * H * W + 63) / 64);
             // images one 64-position workgroup can touch, and their output gradient in floats
             const int imgs = H * W >= 64 ? 2 : 64 / (H * W) + 1;
-            const size_t dy_floats = (size_t)imgs * Cout * Ho * Wo;
+            const size_t dy_floats = (size_t)imgs * (Cout * Ho * Wo + 1);
 #define MEDT_LAUNCH_WS(CT)                                                                                           \
     hipLaunchKernelGGL((conv2d_bwd_data_ws_kernel<K, CT>), dim3(g64, Cin / CT), dim3(MEDT_THREADS),                   \
                        ((size_t)Cout * CT * K * K + (stage ? dy_floats : 0)) * sizeof(float), s, dy, w, dx, N, Cin, H, W, \

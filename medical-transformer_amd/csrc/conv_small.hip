@@ -60,7 +60,7 @@ __device__ __forceinline__ void conv_small_scale_shift_p(float s, float ss, doub
     }
 }
 
-constexpr int SC_NOC = 16;              // output channels per workgroup
+constexpr int SC_NOC_MAX = 16;          // output channels per workgroup (8 when the group's 16 x P tile does not fit LDS)
 
 // Everything in this kernel is a chain of dependent global round trips (one workgroup, a few thousand floats), so the
 // structure minimises them: the weight slab and the input values of the first 32 channels are requested together, and
@@ -74,8 +74,8 @@ static __host__ __device__ inline int conv_small_ksplit(int P, int Cin) {
     return ks;
 }
 
-template <int T>                                    // 256 ... 1024 threads: one position per thread when the group has 1024
-__global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a) {
+template <int T, int SC_NOC>                        // T = 256 ... 1024 threads (one position per thread when the group has
+__global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a) {      // 1024), SC_NOC output channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = blockIdx.x, oc0 = blockIdx.y * SC_NOC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = T >> 6;
@@ -241,9 +241,15 @@ __global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a
     }
 }
 
-static size_t conv_small_lds(int P, int Cin) {
+static size_t conv_small_lds(int P, int Cin, int noc) {
     const int ks = conv_small_ksplit(P, Cin);
-    return ((size_t)SC_NOC * P + (size_t)Cin * SC_NOC + 8 * SC_NOC + (ks > 1 ? (size_t)ks * SC_NOC * P : 0)) * sizeof(float);
+    return ((size_t)noc * P + (size_t)Cin * noc + 8 * noc + (ks > 1 ? (size_t)ks * noc * P : 0)) * sizeof(float);
+}
+
+static int conv_small_noc(int P, int Cin) {                         // 16, 8 or 0 (does not fit)
+    for (int noc = SC_NOC_MAX; noc >= 8; noc >>= 1)
+        if (conv_small_lds(P, Cin, noc) <= 64 * 1024) return noc;
+    return 0;
 }
 
 static bool conv_small_enabled() {
@@ -254,9 +260,9 @@ static bool conv_small_enabled() {
 bool conv_small_ok(const medt_conv_desc& d) {
     if (!conv_small_enabled() || !d.has_bn || d.K != 1 || d.pad != 0 || d.has_bias) return false;
     if (d.stride < 1 || d.H % d.stride || d.W % d.stride) return false;
-    if ((d.Cin & 15) || (d.Cout % SC_NOC)) return false;
+    if ((d.Cin & 15) || (d.Cout % SC_NOC_MAX)) return false;
     const int P = (d.N / d.bn_groups) * (d.H / d.stride) * (d.W / d.stride);
-    return P <= 1024 && conv_small_lds(P, d.Cin) <= 64 * 1024;
+    return P <= 1024 && conv_small_noc(P, d.Cin) != 0;
 }
 
 int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,
@@ -267,11 +273,18 @@ int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, cons
     a.relu = d.relu; a.training = d.training ? 1 : 0; a.eps = d.eps;
     const int P = a.npg * (d.H / d.stride) * (d.W / d.stride);
     const int threads = conv_small_threads(P);
-    const dim3 grid(d.bn_groups, d.Cout / SC_NOC);
-    const size_t lds = conv_small_lds(P, d.Cin);
-    if (threads == 256) hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel<256>, grid, dim3(256), lds, s, a);
-    else if (threads == 512) hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel<512>, grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(conv1x1_bn_small_fwd_kernel<1024>, grid, dim3(1024), lds, s, a);
+    const int noc = conv_small_noc(P, d.Cin);
+    const dim3 grid(d.bn_groups, d.Cout / noc);
+    const size_t lds = conv_small_lds(P, d.Cin, noc);
+#define MEDT_SMALL_CONV(TT)                                                                              \
+    do {                                                                                                 \
+        if (noc == 16) hipLaunchKernelGGL((conv1x1_bn_small_fwd_kernel<TT, 16>), grid, dim3(TT), lds, s, a); \
+        else hipLaunchKernelGGL((conv1x1_bn_small_fwd_kernel<TT, 8>), grid, dim3(TT), lds, s, a);         \
+    } while (0)
+    if (threads == 256) MEDT_SMALL_CONV(256);
+    else if (threads == 512) MEDT_SMALL_CONV(512);
+    else MEDT_SMALL_CONV(1024);
+#undef MEDT_SMALL_CONV
     return launch_status("conv1x1_bn_small_fwd");
 }
 

@@ -150,7 +150,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long q = (long)blockIdx.x * 64 + lane;
     const int  c0 = blockIdx.y * CT;
-    for (int e = threadIdx.x; e < Cout * CT; e += MEDT_THREADS) wl[e] = w[(e / CT) * Cin + c0 + (e % CT)];
+    for (int e0 = threadIdx.x; e0 < Cout * CT; e0 += 8 * MEDT_THREADS) {          // 8 loads in flight per lane
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u * MEDT_THREADS, Cout * CT - 1);
+            v[u] = w[(e / CT) * Cin + c0 + (e % CT)];
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * MEDT_THREADS < Cout * CT) wl[e0 + u * MEDT_THREADS] = v[u];
+    }
     const bool ok = q < (long)N * HW;
     const int  n = ok ? (int)(q / HW) : 0, p = ok ? (int)(q - (long)n * HW) : 0;
     const size_t base = (size_t)n * Cout * HW + p;
