@@ -19,9 +19,6 @@ ENABLED = os.environ.get("MEDT_DEFER", "1") != "0"
 # one queue per recording stream: the stream whose pass ends first (MedT's global branch) issues its own grouped
 # launches right there, under the other branch's latency-bound chain, instead of after the join (net.medt_forward)
 SPLIT = os.environ.get("MEDT_SPLIT_FLUSH", "1") != "0"
-# jobs recorded up to a mark inside the longer (local) branch's backward are issued on an auxiliary stream right there:
-# the grouped kernels fill the CUs the two latency-bound chains leave idle instead of waiting for the end of the pass
-MID = os.environ.get("MEDT_MID_FLUSH", "1") != "0"
 _current = None
 
 
@@ -30,9 +27,6 @@ class StepQueue:
         self._handles = {}             # stream -> queue handle (one shared handle under key None when not SPLIT)
         self._keep = {}                # handle -> tensors the recorded jobs point into
         self._bound = set()
-        self._aux = None               # auxiliary stream of the mid-pass flush
-        self._aux_used = False
-        self._late = []                # tensors of jobs issued on the auxiliary stream: held until the streams have joined
 
     def __del__(self):
         try:
@@ -62,32 +56,8 @@ class StepQueue:
     def pending(self) -> int:
         return sum(int(L.lib().medt_queue_pending(h)) for h in self._handles.values())
 
-    def seal_current_stream(self):
-        """Issue what the current stream has recorded so far on the auxiliary stream, ordered after the current stream's
-        work up to this point.  The recorded jobs' tensors stay referenced until the final flush: they were allocated on
-        the recording stream, which must not reuse their memory while the auxiliary stream reads it."""
-        if not (SPLIT and MID):
-            return
-        cur_stream = torch.cuda.current_stream()
-        h = self._handles.get(cur_stream.cuda_stream)
-        if h is None or int(L.lib().medt_queue_pending(h)) == 0:
-            return
-        if self._aux is None:
-            self._aux = torch.cuda.Stream(device=cur_stream.device)
-        ev = torch.cuda.Event()
-        ev.record(cur_stream)
-        self._aux.wait_event(ev)
-        L.check(L.lib().medt_queue_flush(h, self._aux.cuda_stream), "medt_queue_flush")
-        self._late.extend(self._keep[h])
-        self._keep[h].clear()
-        self._aux_used = True
-
     def flush(self):
         """Issue everything recorded so far on the current stream (all recording streams must have been joined into it)."""
-        if self._aux_used:
-            torch.cuda.current_stream().wait_stream(self._aux)
-            self._aux_used = False
-        self._late.clear()
         cur = torch.cuda.current_stream().cuda_stream
         for h in self._handles.values():
             L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
@@ -124,22 +94,12 @@ class StepQueue:
             self._unbind_all()
             for k in self._keep.values():
                 k.clear()
-            if self._aux_used:                     # (an exception between the mark and the final flush)
-                torch.cuda.current_stream().wait_stream(self._aux)
-                self._aux_used = False
-            self._late.clear()
 
 
 def flush_current_stream():
     """Called where one branch's backward pass ends (ops.ConvBlockFn, cfg.last_of_branch)."""
     if _current is not None:
         _current.flush_current_stream()
-
-
-def seal_current_stream():
-    """Called from the mark inside a branch's backward (ops.FlushMarkFn)."""
-    if _current is not None:
-        _current.seal_current_stream()
 
 
 def recording(allow: bool = True):

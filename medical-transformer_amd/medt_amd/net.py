@@ -74,11 +74,9 @@ def _stem(net, x, sfx="", bn_groups=1, first_of_branch=False):
     return x
 
 
-def _unet_body(net, x, sfx="", bn_groups=1, mark=False):
+def _unet_body(net, x, sfx="", bn_groups=1):
     g = lambda n: getattr(net, n + sfx)
     x1 = _layer(g("layer1"), x, bn_groups)
-    if mark:                        # backward: everything behind layer1 is done here, its recorded jobs can go out
-        x1 = ops.flush_mark(x1)
     x2 = _layer(g("layer2"), x1, bn_groups)
     x3 = _layer(g("layer3"), x2, bn_groups)
     x4 = _layer(g("layer4"), x3, bn_groups)
@@ -125,7 +123,7 @@ def medt_forward(net, x):
     if side is not None:
         with torch.cuda.stream(side):
             xp = ops.patch_gather(xin, PATCH, GRID)
-            yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups, mark=True)
+            yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
         main.wait_stream(side)
         yp.record_stream(main)
     else:

@@ -58,24 +58,6 @@ def sink_of(x):
     return s
 
 
-class FlushMarkFn(torch.autograd.Function):
-    """Identity.  When the backward pass comes by, the jobs its stream has recorded so far (weight gradients of the
-    layers behind this point) are issued on an auxiliary stream (defer.StepQueue.seal_current_stream)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        DEFER.seal_current_stream()
-        return g
-
-
-def flush_mark(x):
-    return FlushMarkFn.apply(x) if (x.requires_grad and DEFER.ENABLED and DEFER.SPLIT and DEFER.MID) else x
-
-
 class ConvBlockCfg:
     __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink", "last_of_branch")
 
