@@ -10,6 +10,7 @@
 // kernel + bn_bwd_finalize (parameter gradients: sums over the groups).  Same saved tensors either way.
 #include "medt_common.h"
 #include "medt_kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace medt {
@@ -246,8 +247,12 @@ static size_t conv_small_lds(int P, int Cin, int noc) {
     return ((size_t)noc * P + (size_t)Cin * noc + 8 * noc + (ks > 1 ? (size_t)ks * noc * P : 0)) * sizeof(float);
 }
 
-static int conv_small_noc(int P, int Cin) {                         // 16, 8 or 0 (does not fit)
-    for (int noc = SC_NOC_MAX; noc >= 8; noc >>= 1)
+// 16, or 0 (does not fit).  The 8-channel tile (MEDT_SMALL_NOC8=1) would admit the 1024-position groups of layer1_p, but
+// measured there the fused forward ties with conv + finalize + apply (14.5 vs 15.6 us) and the one-wave-per-channel
+// backward loses (20 vs 15 us), so those blocks stay on the layer-by-layer kernels.
+static int conv_small_noc(int P, int Cin) {
+    static const int min_noc = [] { const char* e = getenv("MEDT_SMALL_NOC8"); return (e && e[0] == '1') ? 8 : 16; }();
+    for (int noc = SC_NOC_MAX; noc >= min_noc; noc >>= 1)
         if (conv_small_lds(P, Cin, noc) <= 64 * 1024) return noc;
     return 0;
 }
