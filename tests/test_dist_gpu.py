@@ -22,8 +22,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd, env):
+def _run(cmd, env, retries=0):
     r = subprocess.run(cmd, cwd=H.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and retries:
+        # the torchrun worker was seen to abort (SIGABRT) once in ~10 launches on the shared GPU boxes, right after other
+        # GPU tests of this process; the first attempt's stderr is kept next to the profiles for inspection
+        out = os.path.join(H.ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "dist_first_attempt_stderr.log"), "w") as f:
+                f.write(r.stderr[-20000:])
+        return _run(cmd, env, retries - 1)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line), r.stderr
@@ -35,7 +43,7 @@ def test_forced_collectives_over_rccl_match_single_process():
     plain, _ = _run([sys.executable, "bench.py", *ARGS], env)
     env["MEDT_FORCE_DIST"] = "1"
     dist_, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", *ARGS], env)
+                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", *ARGS], env, retries=1)
     assert plain["collective"] is None and "nccl" in dist_["collective"]
     assert "process group up, backend=nccl" in err
     assert dist_["n_gpus"] == 1 and dist_["hip_graph"]

@@ -234,7 +234,9 @@ def test_training_trajectory_vs_oracle(device):
     # (shallow layers only: the deep ones normalise over 32-value populations whose statistics follow every rounding)
     for k in ("bn1.running_mean", "bn2.running_var", "layer1.0.hight_block.bn_similarity.running_var",
               "layer1.0.hight_block.bn_qkv.running_mean"):
-        assert H.rel_err(sd[k], ost[k]) < 3e-2, k          # (weights have moved by up to 3 lr-sized Adam steps)
+        # (weights have moved by up to 3 lr-sized Adam steps, in noise-driven directions where the gradient is ~0:
+        #  3.2e-2 observed on bn1.running_mean in 1 of ~10 runs; a wrong momentum or count is a > 10 % error)
+        assert H.rel_err(sd[k], ost[k]) < 8e-2, k
     assert int(sd["bn1.num_batches_tracked"].item()) == STEPS
     print(f"trajectory: product losses {losses} vs oracle {want}")
 
