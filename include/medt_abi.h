@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 5
+#define MEDT_ABI_VERSION 6
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -61,6 +61,8 @@ int    medt_queue_destroy(void* queue);
 int    medt_queue_bind(void* queue, void* stream);      /* queue == NULL: unbind the stream */
 size_t medt_queue_pending(const void* queue);            /* recorded, not yet flushed */
 int    medt_queue_flush(void* queue, void* stream);      /* enqueue everything recorded on `stream` */
+int    medt_queue_discard(void* queue);                  /* drop everything recorded WITHOUT launching it (error paths: the
+                                                            buffers the jobs point into are about to be released) */
 
 /* ------------------------------------------------------------------------- *
  * Axial attention layer

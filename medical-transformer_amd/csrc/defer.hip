@@ -63,4 +63,11 @@ int medt_queue_flush(void* qv, void* stream) {
     return rc;
 }
 
+int medt_queue_discard(void* qv) {
+    if (!qv) { set_error("queue discard: null queue"); return MEDT_EINVAL; }
+    Queue& q = *(Queue*)qv;
+    q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
+    return MEDT_OK;
+}
+
 }  // extern "C"

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: provides the HIP runtime the lib
 from .build import LIB_PATH
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MedtError(RuntimeError):
@@ -65,6 +65,7 @@ SIGNATURES = {
     "medt_queue_bind": (C.c_int, [C.c_void_p, C.c_void_p]),
     "medt_queue_pending": (C.c_size_t, [C.c_void_p]),
     "medt_queue_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "medt_queue_discard": (C.c_int, [C.c_void_p]),
     "medt_axial_stats_floats": (C.c_size_t, [C.POINTER(AxialDesc)]),
     "medt_axial_workspace_bytes": (C.c_size_t, [C.POINTER(AxialDesc)]),
     "medt_axial_layer_fwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.c_void_p, C.c_void_p,

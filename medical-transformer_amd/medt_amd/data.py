@@ -14,6 +14,7 @@ Colour jitter / random affine are accepted and rejected loudly if requested: tra
 from __future__ import annotations
 
 import os
+import threading
 from collections import defaultdict
 from numbers import Number
 
@@ -180,6 +181,13 @@ def make_synthetic_dataset(root, n=16, size=128, seed=3000, gray=False):
     return root
 
 
+# Held by the prefetch thread around its device work (pinned allocations, event waits, H2D copies) and by
+# medt_amd.trainer.TrainStep around hipGraph capture: runtime calls from another thread (hipHostMalloc, event queries,
+# caching-allocator device allocations) must not land inside a capture -- the epoch-10 gate switch and a new last-batch
+# shape both re-capture while the producer is running.
+GPU_CAPTURE_LOCK = threading.RLock()
+
+
 class DevicePrefetcher:
     """Iterate a DataLoader `depth` batches ahead of the training step.
 
@@ -212,9 +220,10 @@ class DevicePrefetcher:
 
         def staged(t):
             key = (tuple(t.shape), t.dtype)
-            bufs = ring.setdefault(key, [])
-            if len(bufs) < self.depth + 2:
-                bufs.append([torch.empty(t.shape, dtype=t.dtype).pin_memory(), None])
+            bufs = ring.get(key)
+            if bufs is None:           # the whole ring of a new batch shape at once (not one hipHostMalloc per step)
+                bufs = ring[key] = [[torch.empty(t.shape, dtype=t.dtype).pin_memory(), None]
+                                    for _ in range(self.depth + 2)]
             slot = bufs[cursor[key] % len(bufs)]
             cursor[key] += 1
             if slot[1] is not None:
@@ -238,7 +247,7 @@ class DevicePrefetcher:
                     if stop.is_set():
                         return
                     out = list(batch)
-                    with torch.cuda.stream(copy_stream):
+                    with GPU_CAPTURE_LOCK, torch.cuda.stream(copy_stream):
                         slots = [staged(t) for t in out[:2]]
                         for i, slot in enumerate(slots):
                             out[i] = slot[0].to(self.device, non_blocking=True)

@@ -73,6 +73,14 @@ class StepQueue:
             L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
             self._keep[h].clear()
 
+    def discard(self):
+        """Drop everything recorded without launching it (the step raised: the tensors the jobs point into are about
+        to be released, so a later flush would write through dangling pointers)."""
+        lib = L.lib()
+        for h in self._handles.values():
+            lib.medt_queue_discard(h)
+            self._keep[h].clear()
+
     def _unbind_all(self):
         lib = L.lib()
         for s in self._bound:
@@ -86,12 +94,16 @@ class StepQueue:
             yield self
             return
         _current = self
+        ok = False
         try:
             yield self
             self.flush()
+            ok = True
         finally:
             _current = None
             self._unbind_all()
+            if not ok:             # the body (or the flush) raised: nothing recorded may run later
+                self.discard()
             for k in self._keep.values():
                 k.clear()
 

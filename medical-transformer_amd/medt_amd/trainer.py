@@ -57,7 +57,14 @@ class TrainStep:
                 self._queue = StepQueue()
             with self._queue.active() as q:
                 out = self.model(x)
-                loss = self.criterion(out, y)
+                try:
+                    loss = self.criterion(out, y)
+                except BaseException:
+                    # e.g. class indices outside [0, K): the forward pass is complete, so its recorded bookkeeping
+                    # (saved statistics, running-stat updates) is issued like the reference's eager forward would
+                    # have; whatever else is pending when a step dies is dropped by StepQueue.active()
+                    q.flush()
+                    raise
                 q.flush()
                 self.opt.zero_grad()
                 loss.backward()
@@ -98,6 +105,11 @@ class TrainStep:
         batch but their effect -- weights, Adam moments and step counters, BatchNorm running statistics,
         num_batches_tracked -- is rolled back before capture, so capture + replay performs exactly the one update the
         reference's loop (train.py:159-161) performs for this batch."""
+        from .data import GPU_CAPTURE_LOCK
+        with GPU_CAPTURE_LOCK:         # no prefetch-thread runtime calls while the stream is capturing
+            return self._capture_locked(x, y)
+
+    def _capture_locked(self, x, y):
         static_x, static_y = x.clone(), y.clone()
         snap = self._snapshot()
         side = torch.cuda.Stream()
@@ -109,7 +121,9 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         single = not _distributed()
-        with torch.cuda.graph(graph):
+        # thread_local: runtime calls of OTHER host threads (a data-loader / pin-memory thread of the caller's own) do
+        # not invalidate this capture; the prefetcher of medt_amd.data additionally holds GPU_CAPTURE_LOCK
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             loss = self._fwd_bwd(static_x, static_y)
             if single:
                 self.opt.apply(1)

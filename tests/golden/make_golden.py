@@ -231,6 +231,7 @@ def main():
         ("gatedaxialunet", 128, 2, 101, "evalgrad"),
         ("MedT", 128, 2, 102, "train"),
         ("MedT", 128, 2, 102, "evalgrad"),
+        ("MedT", 128, 4, 106, "train"),          # the benchmarked workload itself: BASELINE configs[2], train mode, bs 4
         ("axialunet", 64, 2, 103, "train"),
         ("logo", 128, 1, 104, "evalgrad"),
         ("MedT", 256, 1, 105, "eval"),
