@@ -1,0 +1,842 @@
+// axial_bwd.hip -- the attention backward of the position-encoded layers as ONE L x L sweep.
+//
+// Replaces the autograd of reference lib/models/axialnet.py:155-178.  In training mode that
+// backward has a global barrier in the middle: bn_similarity's backward needs mean(dY) and mean(dY * xhat) over
+// (B*, L, L) before dq / dk / the table gradients can be formed, which is why the generic kernels of axial_core.hip
+// recompute the L x L softmax twice (pass A: the two means; pass B: the gradients).  Here (algebra spelled out and
+// checked against autograd in tests/test_bwd_algebra.py):
+//
+//     dS_x = e_x dZ + u_x S_x + w_x       x in {qk, qr, kr};  e_x = gamma_x rstd_x is known BEFORE the sweep
+//
+//   * the sweep accumulates everything that is linear in dZ -- row sums Dqk = sum_j dZ k_j, Dqr = sum_j dZ Rq[i-j],
+//     column sums Eqk = sum_i dZ q_i, Dkr = sum_i dZ Rk[j-i], dv, and the table gradients along the diagonals;
+//   * the barrier quantities fall out of those accumulators: sum dZ S_qk = q . Dqk, sum dZ S_qr = f_qr q . Dqr,
+//     sum dZ S_kr = f_kr k . Dkr, sum dZ = 0 -- no second L x L pass;
+//   * the u / w terms do not involve dZ: they are closed forms in per-sequence Gram matrices of q and k and sliding-window
+//     sums of the relative table (attn_bwd_fix_kernel: one elementwise pass over dq | dk; attn_bwd_relfix_kernel: the
+//     table and gate gradients from per-position Gram sums).  In running-statistics mode u = w = 0 and the sweep is final.
+//
+// Work decomposition of the sweep (gfx950, wave64), chosen so that NO operand of an (i, j) pair is fetched in the inner
+// loop and the table gradients need no atomics (bit-reproducible):
+//   * LS lanes share one sequence, every lane owns D = L / LS key columns j: k, v and the column accumulators
+//     (Eqk, Dkr, dv) are lane-private registers for the whole sweep;
+//   * all lanes of a sequence walk the query rows i = 0 .. L-1 together: the row's q | dsv | dse | lse | delta record is
+//     one LDS broadcast per row, the row accumulators (Dqk, Dqr) are all-reduced over the LS lanes with DPP once per row;
+//   * the pair (i, j) uses table entry d = i - j + L - 1.  When i advances, every column's d advances by one: the
+//     D table operands AND their gradient accumulators shift one slot, the last slot moves to the next lane
+//     (DPP row_shr:1) -- a chain through the LS lanes that a diagonal enters at lane 0 (fresh entry from LDS) and
+//     leaves at the last lane, complete, after having met every row it intersects.  The slots are renamed at compile
+//     time (the loop is unrolled by D), so a shift costs one DPP move per register per row.
+// Per (i, j) pair that is 18 FMAs + 1 exp2 (gp = 2) against ~7 instructions of per-row bookkeeping amortised over D pairs.
+#include "axial_tiles.h"
+#include "sim_tables.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace medt {
+
+namespace {
+
+template <int GP, int L_, int LS_>
+struct Sw {
+    static constexpr int HQ = GP / 2, NCH = 2 * GP, L = L_, LS = LS_, D = L / LS, SPW = 64 / LS, TL = 2 * L - 1;
+    static constexpr int NT = 2 * HQ + GP;                   // diagonal record: Rq | Rk(reversed) | Rv
+    static constexpr int TREC = (NT + 3) & ~3;
+    static constexpr int RREC = (HQ + 2 * GP + 2 + 3) & ~3;  // row record: q | dsv | dse | lse | delta
+    static constexpr int CREC = TREC;                        // column record in: k | v ; out: dq | dk | dv
+    static constexpr int NP = HQ * (HQ + 1) / 2;
+    static constexpr int NPG = 2 * (NP + HQ);                // Gq pairs (a <= b) | Sq | Gk pairs | Sk
+    // row records of one sequence: + 8 floats so that the records the sequences of a wave read together (same row, one
+    // broadcast address per sequence) fall into different LDS banks
+    static constexpr int RS = L * RREC + 8;
+    static_assert(L % LS == 0 && (LS == 8 || LS == 16), "lanes per sequence");
+};
+
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float dpp(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROWMASK, 0xf, false));
+}
+// every lane has a valid source (rotations / permutations inside a row): bound_ctrl lets the compiler fold the move into
+// the consuming VOP2 (v_add_f32_dpp), one instruction per reduction step
+template <int CTRL>
+__device__ __forceinline__ float dppv(float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the LS lanes of a sequence, result in all of them
+template <int LS>
+__device__ __forceinline__ float seq_allsum(float v) {
+    if (LS == 16) {
+        v += dppv<0x128>(v);           // row_ror:8
+        v += dppv<0x124>(v);           // row_ror:4
+        v += dppv<0x122>(v);           // row_ror:2
+        v += dppv<0x121>(v);           // row_ror:1
+    } else {                           // LS == 8: the two halves of a 16-lane row are different sequences
+        v += dppv<0xB1>(v);            // quad_perm [1,0,3,2]
+        v += dppv<0x4E>(v);            // quad_perm [2,3,0,1]
+        v += dppv<0x141>(v);           // row_half_mirror: the other quad of the half row (all its lanes hold the quad sum)
+    }
+    return v;
+}
+
+// x <- the value of the previous lane of the sequence; the first lane of every sequence takes `fresh`
+template <int LS>
+__device__ __forceinline__ float chain_shift(float x, float fresh, bool head) {
+    float r = dpp<0x111>(fresh, x);    // row_shr:1 (lane 0 of each 16-lane row keeps `fresh`)
+    if (LS < 16) r = head ? fresh : r;
+    return r;
+}
+// the same with fresh = 0 (accumulators): bound_ctrl zero-fills lane 0 of the row, no `old` operand to set up
+template <int LS>
+__device__ __forceinline__ float chain_shift0(float x, bool head) {
+    float r = dppv<0x111>(x);
+    if (LS < 16) r = head ? 0.f : r;
+    return r;
+}
+
+// lane-wise sum over the sequences of the wave (lane b of every sequence), result in all lanes
+template <int LS>
+__device__ __forceinline__ float seqs_sum(float v) {
+    if (LS == 8) v += dppv<0x128>(v);                        // row_ror:8
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct SweepArgs {
+    AxialGeom g;
+    const float *qkv_raw, *stacked, *lse, *dy, *relative, *out_coef;
+    BnStats qs, ss;
+    GatePtrs gates;
+    int pool;
+    float *dqkv, *part_qb, *part_sb, *rel_part, *pg_part, *gram, *gate_raw;
+    int tiles, nparts;             // tiles of S_T sequences per BN group; workgroups per BN group
+    int qb_rpg;                    // rows per BN group of part_qb (the sweep's nparts rows first, then the fix kernel's)
+};
+
+// Sum K per-thread values over the workgroup (nw waves, fixed order); thread k < K stores value k to out[k].
+template <int K>
+__device__ __forceinline__ void wg_sum(float (&v)[K], float* red, float* out, int nw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) red[wave * K + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w * K + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+template <int GP, int L, int LS, bool GATES>
+__global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_kernel(SweepArgs a) {
+    using C = Sw<GP, L, LS>;
+    constexpr int HQ = C::HQ, NCH = C::NCH, D = C::D, SPW = C::SPW, TL = C::TL, NT = C::NT, TREC = C::TREC,
+                  RREC = C::RREC, CREC = C::CREC, NP = C::NP, NPG = C::NPG, RS = C::RS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AxialGeom& g = a.g;
+    const int nw = blockDim.x >> 6, S_T = nw * SPW, nthreads = blockDim.x;
+    float* rowrec = smem;                                     // [S_T][RS]         row records, RREC floats per position
+    float* colrec = rowrec + S_T * RS;                        // [S_T][L][CREC]    (in: k | v ; out: dq | dk | dv)
+    float* tab = colrec + S_T * L * CREC;                     // [TL + 1][TREC]
+    // per wave: table-gradient accumulators [2][NT][D][LS] (low half: d = j, high half: d = 2L-2-j; lane-contiguous) and
+    // per-position Gram sums [NPG][D][LS]
+    float* wacc = tab + (TL + 1) * TREC;
+    float* pg = wacc + nw * 2 * NT * L;
+    float* red = pg + nw * L * NPG;                           // [4 * 32]
+    float* dump = red + 128 + threadIdx.x * CREC;             // [threads][CREC] write-only slots of the branch-free exit stores
+    const int grp = blockIdx.x / a.nparts, part = blockIdx.x - grp * a.nparts, hg = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sg = lane / LS, cb = lane % LS;                 // sequence of the wave, column block of the sequence
+    const bool head = cb == 0;
+    const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr), f_sve = gate(a.gates.f_sve), f_sv = gate(a.gates.f_sv);
+    const float e_qk = a.ss.scale[grp * g.SC + hg], e_qr = a.ss.scale[grp * g.SC + g.G + hg],
+                e_kr = a.ss.scale[grp * g.SC + 2 * g.G + hg];
+    const float s_qk = e_qk * MEDT_LOG2E, s_qr = e_qr * f_qr * MEDT_LOG2E, s_kr = e_kr * f_kr * MEDT_LOG2E;
+    // ---- tables: record d = { Rq[c][d] | Rk[c][2L-2-d] | Rv[c][d] } ---------------------------------------------
+    for (int e = threadIdx.x; e < (TL + 1) * TREC; e += nthreads) {
+        const int d = e / TREC, r = e - d * TREC;
+        float v = 0.f;
+        if (d < TL && r < NT) v = (r >= HQ && r < GP) ? a.relative[r * TL + (TL - 1 - d)] : a.relative[r * TL + d];
+        tab[e] = v;
+    }
+    for (int e = threadIdx.x; e < nw * (2 * NT * L + L * NPG); e += nthreads) wacc[e] = 0.f;        // wacc | pg contiguous
+    float sc[NCH], sh[NCH], vmean[GP], vrstd[GP], cf[NCH][3];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        sc[ch] = a.qs.scale[grp * 2 * g.C + hg * NCH + ch];
+        sh[ch] = a.qs.shift[grp * 2 * g.C + hg * NCH + ch];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cf[ch][k] = a.out_coef[((size_t)grp * g.OC + hg * NCH + ch) * 3 + k];
+    }
+#pragma unroll
+    for (int c = 0; c < GP; ++c) {
+        vmean[c] = a.qs.mean[grp * 2 * g.C + hg * NCH + GP + c];
+        vrstd[c] = a.qs.rstd[grp * 2 * g.C + hg * NCH + GP + c];
+    }
+    // sums over everything this workgroup sees.  T_qk / T_qr are accumulated by all LS lanes of a sequence (scaled at the end)
+    float T_qk = 0.f, T_qr = 0.f, T_kr = 0.f, g_pe = 0.f, g_pv = 0.f;
+    float vst[2 * GP];                                        // bn_qkv backward partials of the v channels
+#pragma unroll
+    for (int k = 0; k < 2 * GP; ++k) vst[k] = 0.f;
+    const int Ho = g.H / a.pool, Wo = g.W / a.pool;
+    // uniform bases of the per-lane 32-bit offsets (saddr + voffset addressing: no 64-bit address arithmetic per load)
+    const size_t es = g.bf16 ? 2 : 4;
+    const char* qbase = reinterpret_cast<const char*>(a.qkv_raw) + (size_t)hg * NCH * g.HW * es;
+    const char* sbase = reinterpret_cast<const char*>(a.stacked) + (size_t)hg * NCH * g.HW * es;
+    const float* dybase = a.dy + (size_t)hg * GP * Ho * Wo;
+    const float* lbase = a.lse + (size_t)hg * g.HW;
+    float* obase = a.dqkv + (size_t)hg * NCH * g.HW;
+    // (sequence, position) of element kk of this thread in a tile of nseq sequences; false: idle slot of a ragged tile
+    auto locate = [&](int kk, int seq0, int nseq, int& ls, int& i, int& n, int& h, int& w) -> bool {
+        const int e = threadIdx.x + kk * nthreads;
+        const bool ok = e < nseq * L;
+        if (g.axis == 1 || !ok) { ls = e / L; i = e % L; } else { i = e / nseq; ls = e - i * nseq; }
+        const int b = grp * g.spg + seq0 + (ok ? ls : 0);
+        n = b / g.Bo;
+        const int sq = b - n * g.Bo;
+        h = g.axis == 1 ? sq : i;
+        w = g.axis == 1 ? i : sq;
+        return ok;
+    };
+    for (int tile = part; tile < a.tiles; tile += a.nparts) {
+        const int seq0 = tile * S_T, nseq = min(S_T, g.spg - seq0);
+        __syncthreads();                                      // the previous tile's outputs have been read
+        // ---- stage the tile: one (sequence, position) per thread and step, lanes along the contiguous NCHW direction
+        auto stage = [&](auto bf) {
+            constexpr bool BF = decltype(bf)::value;
+            constexpr unsigned ES = BF ? 2u : 4u;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) {
+                int ls, i, n, h, w;
+                const bool ok = locate(kk, seq0, nseq, ls, i, n, h, w);
+                float q[HQ], kv[HQ + GP], dsv[GP], dse[GP], lse = 0.f, delta = 0.f;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) q[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < HQ + GP; ++c) kv[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < GP; ++c) { dsv[c] = 0.f; dse[c] = 0.f; }
+                if (ok) {                                     // (idle sequences of a ragged tile get all-zero records)
+                    const int pix = h * g.W + w;
+                    const unsigned qoff = ((unsigned)n * 2u * g.C * g.HW + pix) * ES;
+                    const int ho = h / a.pool, wo = w / a.pool;
+                    const bool in = ho < Ho && wo < Wo;
+                    const unsigned doff = (((unsigned)n * g.C * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1)) * 4u;
+                    float raw[NCH], stk[NCH], dyv[GP];
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const unsigned o = qoff + (unsigned)(ch * g.HW) * ES;
+                        if (BF) {
+                            raw[ch] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(qbase + o));
+                            stk[ch] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(sbase + o));
+                        } else {
+                            raw[ch] = *reinterpret_cast<const float*>(qbase + o);
+                            stk[ch] = *reinterpret_cast<const float*>(sbase + o);           // OC == 2C: same layout
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < GP; ++c)
+                        dyv[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dybase) + doff + (unsigned)(c * Ho * Wo) * 4u);
+                    lse = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lbase) + ((unsigned)n * g.G * g.HW + pix) * 4u);
+                    MEDT_SCHED_FENCE();
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) q[c] = fmaf(raw[c], sc[c], sh[c]);
+#pragma unroll
+                    for (int c = 0; c < HQ + GP; ++c) kv[c] = fmaf(raw[HQ + c], sc[HQ + c], sh[HQ + c]);
+#pragma unroll
+                    for (int k2 = 0; k2 < NCH; ++k2) {        // gradient wrt the stacked sv | sve values (bn_output backward)
+                        const float d0 = in ? dyv[k2 >> 1] : 0.f;
+                        const float ds = fmaf(cf[k2][0], d0, fmaf(cf[k2][1], stk[k2], cf[k2][2]));
+                        delta = fmaf(ds, stk[k2], delta);
+                        if (k2 & 1) dse[k2 >> 1] = GATES ? ds : ds * f_sve; else dsv[k2 >> 1] = GATES ? ds : ds * f_sv;
+                    }
+                }
+                float* rr = rowrec + ls * RS + i * RREC;
+                float* cr = colrec + (ls * L + i) * CREC;
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) rr[c] = q[c];
+#pragma unroll
+                for (int c = 0; c < GP; ++c) { rr[HQ + c] = dsv[c]; rr[HQ + GP + c] = dse[c]; }
+                rr[HQ + 2 * GP] = lse;
+                rr[HQ + 2 * GP + 1] = delta;
+#pragma unroll
+                for (int c = 0; c < HQ + GP; ++c) cr[c] = kv[c];
+            }
+        };
+        if (g.bf16) stage(std::true_type{}); else stage(std::false_type{});
+        __syncthreads();
+        // ---- the sweep ----------------------------------------------------------------------------------------------
+        const int ls = wave * SPW + sg;                       // this lane's sequence of the tile
+        const float* rrow = rowrec + ls * RS;
+        float* crow = colrec + ls * L * CREC;
+        float kc[D][HQ], kb[D][HQ], vc[D][GP], Eqk[D][HQ], Dkr[D][HQ], dv[D][GP], dq_own[D][HQ];
+        float tq[D][HQ], tk[D][HQ], tv[D][GP], aq[D][HQ], ak[D][HQ], av[D][GP];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const float* cr = crow + (cb * D + s) * CREC;
+            const float* tr = tab + (L - 1 - cb * D - s) * TREC;          // row 0: d = -j + L - 1
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                kc[s][c] = cr[c];
+                kb[s][c] = cr[c] * s_kr;
+                Eqk[s][c] = 0.f; Dkr[s][c] = 0.f; dq_own[s][c] = 0.f;
+                tq[s][c] = tr[c]; tk[s][c] = tr[HQ + c];
+                aq[s][c] = 0.f; ak[s][c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                vc[s][c] = cr[HQ + c];
+                dv[s][c] = 0.f;
+                tv[s][c] = tr[GP + c];
+                av[s][c] = 0.f;
+            }
+        }
+        // per-sequence Gram matrices / sums of q and k (the fix kernel's operands) and the per-position products
+        {
+            float pr[D][NPG], gsum[NPG];
+#pragma unroll
+            for (int m = 0; m < NPG; ++m) gsum[m] = 0.f;
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const float* rq = rrow + (cb * D + s) * RREC;
+                float qv[HQ];
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) qv[c] = rq[c];
+                int m = 0;
+#pragma unroll
+                for (int x = 0; x < HQ; ++x)
+#pragma unroll
+                    for (int y = x; y < HQ; ++y, ++m) { pr[s][m] = qv[x] * qv[y]; pr[s][NP + HQ + m] = kc[s][x] * kc[s][y]; }
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) { pr[s][NP + c] = qv[c]; pr[s][2 * NP + HQ + c] = kc[s][c]; }
+#pragma unroll
+                for (int m2 = 0; m2 < NPG; ++m2) gsum[m2] += pr[s][m2];
+            }
+#pragma unroll
+            for (int m = 0; m < NPG; ++m) gsum[m] = seq_allsum<LS>(gsum[m]);
+            if (head && ls < nseq) {
+                float* gr = a.gram + ((size_t)(grp * g.spg + seq0 + ls) * g.G + hg) * NPG;
+#pragma unroll
+                for (int m = 0; m < NPG; ++m) gr[m] = gsum[m];
+            }
+            float* pgw = pg + wave * L * NPG + cb;
+#pragma unroll
+            for (int s = 0; s < D; ++s)
+#pragma unroll
+                for (int m = 0; m < NPG; ++m) {
+                    const float t = seqs_sum<LS>(pr[s][m]);
+                    if (sg == 0) pgw[(m * D + s) * LS] += t;
+                }
+        }
+        float* waccw = wacc + wave * 2 * NT * L + cb;
+        // the row record (and the table entry that enters the chain behind it) of row i + 1 is fetched while row i is
+        // computed: the loads sit in front of the row's exit store, whose address the compiler cannot tell apart
+        float nrec[RREC], nfr[TREC];
+#pragma unroll
+        for (int k = 0; k < RREC; ++k) nrec[k] = rrow[k];
+#pragma unroll
+        for (int k = 0; k < TREC; ++k) nfr[k] = tab[L * TREC + k];
+#pragma unroll 1
+        for (int it = 0; it < LS; ++it) {
+            const bool owner = cb == it;                      // this lane's columns are the rows of this iteration
+#pragma unroll
+            for (int t = 0; t < D; ++t) {
+                float rec[RREC], fr[TREC];
+#pragma unroll
+                for (int k = 0; k < RREC; ++k) rec[k] = nrec[k];
+#pragma unroll
+                for (int k = 0; k < TREC; ++k) fr[k] = nfr[k];
+                {
+                    const int inext = min(it * D + t + 1, L - 1);
+                    const float* rr = rrow + inext * RREC;
+                    const float* tf = tab + (inext + L) * TREC;
+#pragma unroll
+                    for (int k = 0; k < RREC; ++k) nrec[k] = rr[k];
+#pragma unroll
+                    for (int k = 0; k < TREC; ++k) nfr[k] = tf[k];
+                }
+                float q[HQ], qa[HQ], qb[HQ], dsv[GP], dse[GP], Dqk[HQ], Dqr[HQ];
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) { q[c] = rec[c]; qa[c] = q[c] * s_qk; qb[c] = q[c] * s_qr; Dqk[c] = 0.f; Dqr[c] = 0.f; }
+#pragma unroll
+                for (int c = 0; c < GP; ++c) { dsv[c] = rec[HQ + c]; dse[c] = rec[HQ + GP + c]; }
+                const float nlse = -rec[HQ + 2 * GP], ndelta = -rec[HQ + 2 * GP + 1];
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    const int p = (s - t + D) % D;            // physical slot of the diagonal column s meets in this row
+                    float z = nlse;
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) z = fmaf(qa[c], kc[s][c], fmaf(qb[c], tq[p][c], fmaf(kb[s][c], tk[p][c], z)));
+                    const float P = __builtin_amdgcn_exp2f(z);
+                    float dZ;
+                    if (GATES) {
+                        float tvv = 0.f, tee = 0.f;
+#pragma unroll
+                        for (int c = 0; c < GP; ++c) { tvv = fmaf(dsv[c], vc[s][c], tvv); tee = fmaf(dse[c], tv[p][c], tee); }
+                        g_pv = fmaf(P, tvv, g_pv);
+                        g_pe = fmaf(P, tee, g_pe);
+                        dZ = P * fmaf(f_sv, tvv, fmaf(f_sve, tee, ndelta));
+                    } else {
+                        float t2 = ndelta;
+#pragma unroll
+                        for (int c = 0; c < GP; ++c) t2 = fmaf(dsv[c], vc[s][c], fmaf(dse[c], tv[p][c], t2));
+                        dZ = P * t2;
+                    }
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) {
+                        Dqk[c] = fmaf(dZ, kc[s][c], Dqk[c]);
+                        Dqr[c] = fmaf(dZ, tq[p][c], Dqr[c]);
+                        Eqk[s][c] = fmaf(dZ, q[c], Eqk[s][c]);
+                        Dkr[s][c] = fmaf(dZ, tk[p][c], Dkr[s][c]);
+                        aq[p][c] = fmaf(dZ, q[c], aq[p][c]);
+                        ak[p][c] = fmaf(dZ, kc[s][c], ak[p][c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GP; ++c) {
+                        dv[s][c] = fmaf(P, dsv[c], dv[s][c]);
+                        av[p][c] = fmaf(P, dse[c], av[p][c]);
+                    }
+                }
+                // row totals over the LS lanes of the sequence; the lane that owns column j = i keeps dq of the row
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                    const float a0 = seq_allsum<LS>(Dqk[c]), a1 = seq_allsum<LS>(Dqr[c]);
+                    T_qk = fmaf(q[c], a0, T_qk);
+                    T_qr = fmaf(q[c], a1, T_qr);
+                    const float dqv = fmaf(e_qk, a0, (f_qr * e_qr) * a1);
+                    dq_own[t][c] = owner ? dqv : dq_own[t][c];
+                }
+                // the diagonal in slot D-1 leaves the lane: the last lane's is complete (d = i) and is parked in the column
+                // record of position i of its sequence (dead between the initial column loads and the out records); every
+                // other one moves to the next lane, lane 0 of the sequence takes the next table entry
+                const int px = (2 * D - 1 - t) % D;
+                if (t < D - 1 || it < LS - 1) {
+                    {   // (no branch: the row steps of an iteration stay one scheduling region; the other lanes store to a
+                        //  private dump slot)
+                        float* ex = cb == LS - 1 ? crow + (it * D + t) * CREC : dump;
+#pragma unroll
+                        for (int c = 0; c < HQ; ++c) { ex[c] = aq[px][c]; ex[HQ + c] = ak[px][c]; }
+#pragma unroll
+                        for (int c = 0; c < GP; ++c) ex[GP + c] = av[px][c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < HQ; ++c) {
+                        tq[px][c] = chain_shift<LS>(tq[px][c], fr[c], head);
+                        tk[px][c] = chain_shift<LS>(tk[px][c], fr[HQ + c], head);
+                        aq[px][c] = chain_shift0<LS>(aq[px][c], head);
+                        ak[px][c] = chain_shift0<LS>(ak[px][c], head);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GP; ++c) {
+                        tv[px][c] = chain_shift<LS>(tv[px][c], fr[GP + c], head);
+                        av[px][c] = chain_shift0<LS>(av[px][c], head);
+                    }
+                }
+            }
+        }
+        // ---- table gradients of the tile -> the wave's accumulators: the diagonals parked by the last lanes (d = 0 .. L-2,
+        // this lane folds d = its own D positions) and the ones still in the chain (d = 2L-2-j; slot s sits in physical
+        // (s + 1) % D after the last row); the sequences of the wave are summed lane-wise, sequence 0's lanes accumulate
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int p = (s + 1) % D;
+            const int j = cb * D + s;
+            const float* pk = crow + j * CREC;
+            float ex[NT], ch[NT];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ex[m] = seqs_sum<LS>(j < L - 1 ? pk[m] : 0.f);
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) { ch[c] = seqs_sum<LS>(aq[p][c]); ch[HQ + c] = seqs_sum<LS>(ak[p][c]); }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) ch[GP + c] = seqs_sum<LS>(av[p][c]);
+            if (sg == 0) {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    waccw[(m * D + s) * LS] += ex[m];                     // d = j
+                    waccw[NT * L + (m * D + s) * LS] += ch[m];            // d = 2L-2-j
+                }
+            }
+        }
+        // ---- column results: dq of the lane's own positions, dk, dv -> the out records (alias of the column records)
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            float* cr = crow + (cb * D + s) * CREC;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                T_kr = fmaf(kc[s][c], Dkr[s][c], T_kr);
+                cr[c] = dq_own[s][c];
+                cr[HQ + c] = fmaf(e_qk, Eqk[s][c], (f_kr * e_kr) * Dkr[s][c]);
+            }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) cr[GP + c] = GATES ? f_sv * dv[s][c] : dv[s][c];
+        }
+        __syncthreads();
+        // ---- write dqkv (NCHW), bn_qkv backward partials of the v channels (raw v re-read: L2-resident) --------------------
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            int ls2, i2, n, h, w;
+            if (locate(kk, seq0, nseq, ls2, i2, n, h, w)) {
+                const float* cr = colrec + (ls2 * L + i2) * CREC;
+                const int pix = h * g.W + w;
+                const unsigned ooff = ((unsigned)n * 2u * g.C * g.HW + pix) * 4u;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(obase) + ooff + (unsigned)(ch * g.HW) * 4u) = cr[ch];
+#pragma unroll
+                for (int c = 0; c < GP; ++c) {
+                    const unsigned o = ((unsigned)n * 2u * g.C * g.HW + pix + (unsigned)((GP + c) * g.HW)) * (unsigned)es;
+                    const float rv = g.bf16 ? bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(qbase + o))
+                                            : *reinterpret_cast<const float*>(qbase + o);
+                    const float d = cr[GP + c];
+                    vst[2 * c] += d;
+                    vst[2 * c + 1] = fmaf(d, (rv - vmean[c]) * vrstd[c], vst[2 * c + 1]);
+                }
+            }
+        }
+    }
+    // ---- workgroup results ------------------------------------------------------------------------------------------
+    __syncthreads();
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;       // (head, group, part)
+    {   // table gradients: waves in fixed order, the per-head scales, `relative`'s layout (Rk rows reversed back)
+        float* rp = a.rel_part + blk * NCH * TL;
+        const float sq = f_qr * e_qr, sk = f_kr * e_kr, sv = GATES ? f_sve : 1.f;
+        for (int e = threadIdx.x; e < NCH * TL; e += nthreads) {
+            const int r = e / TL, d = e - r * TL;
+            const int dd = (r >= HQ && r < GP) ? TL - 1 - d : d;
+            const int half = dd >= L - 1, j = half ? 2 * L - 2 - dd : dd;
+            const int idx = half * NT * L + (r * D + j % D) * LS + j / D;
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += wacc[w * 2 * NT * L + idx];
+            rp[e] = s * (r < HQ ? sq : (r < GP ? sk : sv));
+        }
+        float* pp = a.pg_part + blk * L * NPG;
+        for (int e = threadIdx.x; e < L * NPG; e += nthreads) {
+            const int j = e / NPG, m = e - j * NPG;
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += pg[w * L * NPG + (m * D + j % D) * LS + j / D];
+            pp[e] = s;
+        }
+    }
+    const float inv_ls = 1.f / (float)LS;                     // (T_qk, T_qr: every lane of a sequence saw the same rows)
+    {
+        float v[4] = {0.f, T_qk * inv_ls, f_qr * T_qr * inv_ls, f_kr * T_kr};     // sum dZ * {1, S_qk, S_qr, S_kr}
+        wg_sum<4>(v, red, a.part_sb + ((size_t)blockIdx.x * g.G + hg) * 4, nw);
+    }
+    {
+        // bn_qkv backward partials [group][row][2C][2]: this head's v channels; its q | k columns are written as zeros
+        // (attn_bwd_fix_kernel's rows carry those)
+        float* dst = a.part_qb + ((size_t)(grp * a.qb_rpg + part) * 2 * g.C + hg * NCH) * 2;
+        if (threadIdx.x < 2 * GP) dst[threadIdx.x] = 0.f;
+        wg_sum<2 * GP>(vst, red, dst + 2 * GP, nw);
+    }
+    if (GATES) {
+        float v[4] = {T_qr * inv_ls, T_kr, g_pe, g_pv};       // sum dZ rq, sum dZ rk (ungated), sum P dPe, sum P dPv
+        wg_sum<4>(v, red, a.gate_raw + blk * 4, nw);
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// The u / w terms of dq | dk (closed forms, see the header) + the bn_qkv backward partials of the q | k channels.
+// Elementwise: one lane per position of the BN group, one head per blockIdx.y.
+// --------------------------------------------------------------------------- //
+struct FixArgs {
+    AxialGeom g;
+    const float *qkv_raw, *sim_coef, *tables, *gram;
+    BnStats qs;
+    GatePtrs gates;
+    float *dqkv, *part_qb;
+    int fparts, qb_rpg, qb_row0, apply;
+};
+
+template <int HQ>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
+    constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), NR = HQ + NP;
+    __shared__ float red[MEDT_WAVES * 4 * HQ];
+    const AxialGeom& g = a.g;
+    const int grp = blockIdx.x / a.fparts, part = blockIdx.x - grp * a.fparts, hg = blockIdx.y;
+    const int per_group = g.npg * g.HW;
+    const int qpos = part * MEDT_THREADS + threadIdx.x;
+    float v[4 * HQ];
+#pragma unroll
+    for (int k = 0; k < 4 * HQ; ++k) v[k] = 0.f;
+    if (qpos < per_group) {
+        const int ni = qpos / g.HW, pix = qpos - ni * g.HW, n = grp * g.npg + ni;
+        const int h = pix / g.W, w = pix - h * g.W;
+        const int i = g.axis == 1 ? w : h, sq = g.axis == 1 ? h : w;
+        const size_t off = ((size_t)n * 2 * g.C + hg * NCH) * g.HW + pix;
+        const int cbase = grp * 2 * g.C + hg * NCH;
+        float raw[GP], x[GP], d[GP];
+#pragma unroll
+        for (int c = 0; c < GP; ++c) {
+            raw[c] = ld_act(a.qkv_raw, off + (size_t)c * g.HW, g.bf16);
+            d[c] = a.dqkv[off + (size_t)c * g.HW];
+            x[c] = fmaf(raw[c], a.qs.scale[cbase + c], a.qs.shift[cbase + c]);
+        }
+        if (a.apply) {
+            const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr);
+            const float* cq = a.sim_coef + ((size_t)grp * g.SC + hg) * 3;
+            const float* cr = a.sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
+            const float* ck = a.sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
+            const float u_qk = cq[1], w_qk = cq[2];
+            const float u_qr = f_qr * f_qr * cr[1], w_qr = f_qr * cr[2], u_kr = f_kr * f_kr * ck[1], w_kr = f_kr * ck[2];
+            const float* gr = a.gram + ((size_t)(n * g.Bo + sq) * g.G + hg) * NPG;      // Gq pairs | Sq | Gk pairs | Sk
+            const float* tQ = a.tables + (size_t)i * NR;                             // U_c | T pairs (x2 off the diagonal)
+            const float* tK = a.tables + (size_t)(g.L + i) * NR;
+            float Gq[HQ][HQ], Gk[HQ][HQ], TQ[HQ][HQ], TK[HQ][HQ];
+            int m = 0;
+#pragma unroll
+            for (int p = 0; p < HQ; ++p)
+#pragma unroll
+                for (int r = p; r < HQ; ++r, ++m) {
+                    Gq[p][r] = Gq[r][p] = gr[m];
+                    Gk[p][r] = Gk[r][p] = gr[NP + HQ + m];
+                    const float hf = r > p ? 0.5f : 1.f;
+                    TQ[p][r] = TQ[r][p] = hf * tQ[HQ + m];
+                    TK[p][r] = TK[r][p] = hf * tK[HQ + m];
+                }
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                float fq = fmaf(w_qk, gr[2 * NP + HQ + c], w_qr * tQ[c]);          // w_qk Sk_c + f w_qr UQ_c[i]
+                float fk = fmaf(w_qk, gr[NP + c], w_kr * tK[c]);                   // w_qk Sq_c + f w_kr UK_c[i]
+#pragma unroll
+                for (int e = 0; e < HQ; ++e) {
+                    fq = fmaf(x[e], fmaf(u_qk, Gk[e][c], u_qr * TQ[e][c]), fq);
+                    fk = fmaf(x[HQ + e], fmaf(u_qk, Gq[e][c], u_kr * TK[e][c]), fk);
+                }
+                d[c] += fq;
+                d[HQ + c] += fk;
+            }
+#pragma unroll
+            for (int c = 0; c < GP; ++c) a.dqkv[off + (size_t)c * g.HW] = d[c];
+        }
+#pragma unroll
+        for (int c = 0; c < GP; ++c) {
+            v[2 * c] = d[c];
+            v[2 * c + 1] = d[c] * ((raw[c] - a.qs.mean[cbase + c]) * a.qs.rstd[cbase + c]);
+        }
+    }
+    float* dst = a.part_qb + ((size_t)(grp * a.qb_rpg + a.qb_row0 + part) * 2 * g.C + hg * NCH) * 2;
+    if (threadIdx.x < 2 * GP) dst[2 * GP + threadIdx.x] = 0.f;            // (the sweep's rows carry the v channels)
+    block_sum<4 * HQ>(v, red, dst);
+}
+
+// --------------------------------------------------------------------------- //
+// The u / w terms of the relative-table gradient and the gate gradients, one workgroup per (BN group, head):
+// written as one extra row per workgroup of the partial slabs the (deferred) row reductions sum.
+// --------------------------------------------------------------------------- //
+struct RelfixArgs {
+    AxialGeom g;
+    const float *relative, *sim_coef, *pg_part, *gate_raw;
+    BnStats ss;
+    GatePtrs gates;
+    float *rel_rows, *gate_rows;   // [groups * G][2gp * TL], [groups * G][4]
+    int nparts, sweep_gridx, training;
+    float eps;
+};
+
+template <int HQ>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_relfix_kernel(RelfixArgs a) {
+    constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ);
+    extern __shared__ float pgs[];                              // [L][NPG]
+    const AxialGeom& g = a.g;
+    const int L = g.L, TL = 2 * L - 1;
+    const int grp = blockIdx.x / g.G, hg = blockIdx.x - grp * g.G;
+    const size_t blk0 = (size_t)hg * a.sweep_gridx + (size_t)grp * a.nparts;
+    for (int e = threadIdx.x; e < L * NPG; e += MEDT_THREADS) {
+        const float* src = a.pg_part + blk0 * L * NPG + e;
+        float s = 0.f;
+        int p = 0;
+        for (; p + 8 <= a.nparts; p += 8) {                   // eight loads in flight, fixed summation order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(p + k) * L * NPG];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; p < a.nparts; ++p) s += src[(size_t)p * L * NPG];
+        pgs[e] = s;
+    }
+    __shared__ double gred[MEDT_WAVES][4];
+    double graw[4] = {0.0, 0.0, 0.0, 0.0};
+    if (a.gate_rows) {                                        // gate sums of this (group, head): parts over the threads
+        for (int p = threadIdx.x; p < a.nparts; p += MEDT_THREADS) {
+            const float* q = a.gate_raw + (blk0 + p) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) graw[k] += q[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) graw[k] += __shfl_xor(graw[k], o, 64);
+            if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6][k] = graw[k];
+        }
+    }
+    __syncthreads();
+    const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr);
+    const float* cr = a.sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
+    const float* ck = a.sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
+    float* out = a.rel_rows + (size_t)blockIdx.x * NCH * TL;
+    for (int e = threadIdx.x; e < NCH * TL; e += MEDT_THREADS) {
+        const int r = e / TL, d = e - r * TL;
+        float res = 0.f;
+        if (r < GP && a.training) {
+            const int side = r / HQ, c = r - side * HQ;
+            const float f = side ? f_kr : f_qr;
+            const float* cf = side ? ck : cr;
+            const double cu = (double)f * f * cf[1], cw = (double)f * cf[2];
+            const int lo = max(0, d - L + 1), hi = min(L - 1, d);
+            const int base = side * (NP + HQ);
+            double acc = 0.0;
+            float Rd[HQ];
+#pragma unroll
+            for (int x = 0; x < HQ; ++x) Rd[x] = a.relative[(size_t)(side * HQ + x) * TL + d];
+            for (int i = lo; i <= hi; ++i) {
+                const float* pp = pgs + i * NPG + base;
+                double t = 0.0;
+#pragma unroll
+                for (int x = 0; x < HQ; ++x) {
+                    const int lo2 = x < c ? x : c, hi2 = x < c ? c : x;
+                    const int m = lo2 * HQ - lo2 * (lo2 - 1) / 2 + (hi2 - lo2);       // pair index of (lo2 <= hi2)
+                    t += (double)Rd[x] * pp[m];
+                }
+                acc += cu * t + cw * pp[NP + c];
+            }
+            res = (float)acc;
+        }
+        out[e] = res;
+    }
+    if (a.gate_rows && threadIdx.x == 0) {
+        const double t_qr = (gred[0][0] + gred[1][0]) + (gred[2][0] + gred[3][0]), t_kr = (gred[0][1] + gred[1][1]) + (gred[2][1] + gred[3][1]);
+        const double pe = (gred[0][2] + gred[1][2]) + (gred[2][2] + gred[3][2]), pv = (gred[0][3] + gred[1][3]) + (gred[2][3] + gred[3][3]);
+        double gq = (double)cr[0] * t_qr, gk = (double)ck[0] * t_kr;
+        if (a.training) {
+            const double count = g.sim_count;
+            const int cq = grp * g.SC + g.G + hg, ckk = grp * g.SC + 2 * g.G + hg;
+            const double mq = a.ss.mean[cq], rq = a.ss.rstd[cq], mk = a.ss.mean[ckk], rk = a.ss.rstd[ckk];
+            const double s1q = count * mq, s2q = count * (1.0 / (rq * rq) - (double)a.eps + mq * mq);
+            const double s1k = count * mk, s2k = count * (1.0 / (rk * rk) - (double)a.eps + mk * mk);
+            if (f_qr != 0.f) gq += ((double)cr[1] * s2q + (double)cr[2] * s1q) / f_qr;
+            if (f_kr != 0.f) gk += ((double)ck[1] * s2k + (double)ck[2] * s1k) / f_kr;
+        }
+        float* go = a.gate_rows + (size_t)blockIdx.x * 4;
+        go[0] = (float)gq; go[1] = (float)gk; go[2] = (float)pe; go[3] = (float)pv;
+    }
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void bwd_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
+                                                                  int HQ, int L) {
+    extern __shared__ float lds[];
+    sim_tables_block(blockIdx.x, relative, tables, HQ, L, lds);
+}
+
+template <int GP, int L, int LS>
+size_t sweep_lds_bytes(int nw) {
+    using C = Sw<GP, L, LS>;
+    const int S_T = nw * C::SPW;
+    return ((size_t)S_T * (C::RS + L * C::CREC) + (size_t)(C::TL + 1) * C::TREC + (size_t)nw * (2 * C::NT * L + L * C::NPG) +
+            128 + (size_t)nw * 64 * C::CREC) * sizeof(float);
+}
+
+static bool sweep_enabled() {
+    static const bool on = [] { const char* e = getenv("MEDT_BWD_SWEEP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+}  // namespace
+
+// Plan: lanes per sequence, waves per workgroup, tiles, persistent workgroups.  Returns false when the generic two-pass
+// kernels of axial_core.hip have to run (gp > 4, other lengths, per-sequence gates, MEDT_BWD_SWEEP=0).
+bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
+    if (!g.pos || gate_stride != 0 || !sweep_enabled() || !fast_path_enabled()) return false;
+    int ls = 0;
+    if (g.gp == 2 && (g.L == 32 || g.L == 64 || g.L == 128)) ls = g.L == 32 ? 8 : 16;
+    else if (g.gp == 4 && (g.L == 32 || g.L == 64)) ls = g.L == 32 ? 8 : 16;
+    if (!ls) return false;
+    static const int env_nw = [] { const char* e = getenv("MEDT_BWD_NW"); return e ? atoi(e) : 0; }();
+    static const int env_cap = [] { const char* e = getenv("MEDT_BWD_CAP"); return e ? atoi(e) : 2048; }();
+    const int spw = 64 / ls;
+    int nw = g.axis == 0 ? 4 : 2;
+    // small problems: as many workgroups as there are sequences to give them
+    while (nw > 1 && (long)g.groups * g.G * cdiv(g.spg, nw * spw) < 1024) nw >>= 1;
+    if (env_nw == 1 || env_nw == 2 || env_nw == 4) nw = env_nw;
+    p->LS = ls;
+    p->nw = nw;
+    p->S_T = nw * spw;
+    p->tiles = cdiv(g.spg, p->S_T);
+    int cap = env_cap / (g.groups * g.G);
+    if (cap < 1) cap = 1;
+    p->nparts = p->tiles < cap ? p->tiles : cap;
+    p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS);
+    const int hq = g.hq, np = hq * (hq + 1) / 2;
+    p->npg_floats = 2 * (np + hq);
+    if (g.gp == 2) p->lds = g.L == 32 ? sweep_lds_bytes<2, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<2, 64, 16>(nw) : sweep_lds_bytes<2, 128, 16>(nw));
+    else p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : sweep_lds_bytes<4, 64, 16>(nw);
+    return p->lds <= 160 * 1024;
+}
+
+int axial_bwd_tables(const AxialGeom& g, const float* relative, float* tables, hipStream_t s) {
+    hipLaunchKernelGGL(bwd_tables_kernel, dim3(sim_tables_blocks(g)), dim3(MEDT_THREADS), (2 * g.L - 1) * 2 * sizeof(float), s,
+                       relative, tables, g.hq, g.L);
+    return launch_status("bwd_tables");
+}
+
+int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, BnStats sim,
+                         const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
+                         const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
+                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s) {
+    SweepArgs a;
+    a.g = g;
+    a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.relative = relative; a.out_coef = out_coef;
+    a.qs = qkv; a.ss = sim; a.gates = gates; a.pool = stride;
+    a.dqkv = dqkv; a.part_qb = part_qb; a.part_sb = part_sb; a.rel_part = rel_part; a.pg_part = pg_part; a.gram = gram;
+    a.gate_raw = gate_raw;
+    a.tiles = p.tiles; a.nparts = p.nparts; a.qb_rpg = qb_rpg;
+    const dim3 grid(g.groups * p.nparts, g.G), block(64 * p.nw);
+    const bool gt = gate_raw != nullptr;
+#define MEDT_SWEEP(GPv, Lv, LSv)                                                                                     \
+    do {                                                                                                             \
+        if (gt) hipLaunchKernelGGL((attn_bwd_sweep_kernel<GPv, Lv, LSv, true>), grid, block, p.lds, s, a);            \
+        else hipLaunchKernelGGL((attn_bwd_sweep_kernel<GPv, Lv, LSv, false>), grid, block, p.lds, s, a);              \
+    } while (0)
+    if (g.gp == 2 && g.L == 32) MEDT_SWEEP(2, 32, 8);
+    else if (g.gp == 2 && g.L == 64) MEDT_SWEEP(2, 64, 16);
+    else if (g.gp == 2 && g.L == 128) MEDT_SWEEP(2, 128, 16);
+    else if (g.gp == 4 && g.L == 32) MEDT_SWEEP(4, 32, 8);
+    else if (g.gp == 4 && g.L == 64) MEDT_SWEEP(4, 64, 16);
+    else { set_error("attn_bwd_sweep: no instantiation for gp=%d L=%d", g.gp, g.L); return MEDT_EUNSUPPORTED; }
+#undef MEDT_SWEEP
+    return launch_status("attn_bwd_sweep_kernel");
+}
+
+int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
+                       const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,
+                       int qb_rpg, hipStream_t s) {
+    FixArgs a;
+    a.g = g; a.qkv_raw = qkv_raw; a.sim_coef = sim_coef; a.tables = tables; a.gram = gram; a.qs = qkv; a.gates = gates;
+    a.dqkv = dqkv; a.part_qb = part_qb; a.fparts = p.fparts; a.qb_rpg = qb_rpg; a.qb_row0 = p.nparts; a.apply = apply;
+    const dim3 grid(g.groups * p.fparts, g.G), block(MEDT_THREADS);
+    if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_fix_kernel<1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fix_kernel<2>), grid, block, 0, s, a);
+    return launch_status("attn_bwd_fix_kernel");
+}
+
+int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* relative, const float* sim_coef, BnStats sim,
+                          GatePtrs gates, const float* pg_part, const float* gate_raw, int training, float eps,
+                          float* rel_rows, float* gate_rows, hipStream_t s) {
+    RelfixArgs a;
+    a.g = g; a.relative = relative; a.sim_coef = sim_coef; a.pg_part = pg_part; a.gate_raw = gate_raw; a.ss = sim;
+    a.gates = gates; a.rel_rows = rel_rows; a.gate_rows = gate_raw ? gate_rows : nullptr; a.nparts = p.nparts;
+    a.sweep_gridx = g.groups * p.nparts; a.training = training; a.eps = eps;
+    const size_t lds = (size_t)g.L * p.npg_floats * sizeof(float);
+    const dim3 grid(g.groups * g.G), block(MEDT_THREADS);
+    if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, lds, s, a);
+    return launch_status("attn_bwd_relfix_kernel");
+}
+
+}  // namespace medt

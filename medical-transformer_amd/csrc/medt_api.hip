@@ -53,26 +53,72 @@ struct FwdWs {
 struct BwdWs {
     float *part_ob, *coef_out, *part_sb, *coef_sim, *dqkv, *part_qb, *coef_qkv, *rel_part, *gate_part, *dw_scratch,
         *dy_masked, *gate_eff, *gate_tmp;
+    float *tables, *gram, *pg_part, *gate_raw, *gate_rows;     // single-sweep backward (axial_bwd.hip)
     size_t nblocks;
-    BwdWs(Carver& c, const AxialGeom& g, int stride, int out_relu) {
+    bool sweep;                  // the single-sweep backward runs (else the two generic passes of axial_core.hip)
+    SweepPlan plan;
+    size_t sweep_blocks;         // workgroups of the sweep = rows of rel_part / pg_part / gate_raw it writes
+    int qb_rpg;                  // rows per BN group of part_qb
+    BwdWs(Carver& c, const AxialGeom& g, int stride, int out_relu, int gate_mode) {
         gate_eff = c.take<float>(4);
         gate_tmp = c.take<float>(4);
         const int ppg = conv2d_parts_per_group(g.N, g.groups, g.HW), TL = 2 * g.L - 1;
+        sweep = axial_bwd_sweep_plan(g, gate_mode == 2 ? 4 : 0, &plan);
+        sweep_blocks = sweep ? (size_t)g.groups * plan.nparts * g.G : 0;
+        qb_rpg = sweep ? plan.nparts + plan.fparts : g.tpg;
         nblocks = (size_t)g.groups * g.tpg * g.G;
+        const size_t rel_rows = sweep ? sweep_blocks + (size_t)g.groups * g.G : nblocks;
         part_ob = c.take<float>((size_t)g.groups * ppg * g.OC * 2);
         coef_out = c.take<float>((size_t)g.groups * g.OC * 3);
         part_sb = c.take<float>((size_t)g.groups * g.tpg * g.G * 4);
         coef_sim = c.take<float>((size_t)g.groups * g.SC * 3);
         dqkv = c.take<float>((size_t)g.N * 2 * g.C * g.HW);
-        part_qb = c.take<float>((size_t)g.groups * g.tpg * 2 * g.C * 2);
+        part_qb = c.take<float>((size_t)g.groups * (qb_rpg > g.tpg ? qb_rpg : g.tpg) * 2 * g.C * 2);
         coef_qkv = c.take<float>((size_t)g.groups * 2 * g.C * 3);
-        rel_part = c.take<float>(g.pos ? nblocks * 2 * g.gp * TL : 0);
+        rel_part = c.take<float>(g.pos ? (rel_rows > nblocks ? rel_rows : nblocks) * 2 * g.gp * TL : 0);
         const size_t nseqh = (size_t)g.groups * g.spg * g.G;          // per-sequence gates: one row per (sequence, head)
         gate_part = c.take<float>(g.pos ? (nblocks > nseqh ? nblocks : nseqh) * 4 : 0);
         dw_scratch = c.take<float>((size_t)conv2d_bwd_weight_splits(g.N, g.C, 2 * g.C, 1, g.H, g.W) * 2 * g.C * g.C);
         dy_masked = c.take<float>(out_relu ? (size_t)g.N * g.C * (g.H / stride) * (g.W / stride) : 0);
+        tables = c.take<float>(sweep ? sim_tables_floats(g) : 0);
+        gram = c.take<float>(sweep ? (size_t)g.groups * g.spg * g.G * plan.npg_floats : 0);
+        pg_part = c.take<float>(sweep ? sweep_blocks * g.L * plan.npg_floats : 0);
+        gate_raw = c.take<float>(sweep ? sweep_blocks * 4 : 0);
+        gate_rows = c.take<float>(sweep ? (size_t)g.groups * g.G * 4 : 0);
     }
 };
+
+// The attention backward between bn_output's and bn_qkv's: dy -> dqkv (+ bn_qkv backward partials, relative-table and gate
+// partial rows, bn_similarity's parameter gradients).  Either the single sweep (+ the closed-form u / w terms) of
+// axial_bwd.hip, or the two generic L x L passes of axial_core.hip.
+static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, const medt_axial_params* p, const BwdWs& w,
+                              const float* qkv_raw, const float* stacked, const float* lse, const float* dy, const LayerStats& st,
+                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s) {
+    const int tr = d->training ? 1 : 0;
+    int rc;
+    if (w.sweep) {
+        if (tr && (rc = axial_bwd_tables(g, p->relative, w.tables, s))) return rc;
+        if ((rc = axial_attn_bwd_sweep(g, w.plan, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out,
+                                       d->stride, w.dqkv, w.part_qb, w.qb_rpg, w.part_sb, w.rel_part, w.pg_part, w.gram,
+                                       want_gates ? w.gate_raw : nullptr, s))) return rc;
+        AxialGeom gs = g;
+        gs.tpg = w.plan.nparts;                               // part_sb rows per group
+        if ((rc = axial_sim_bwd_finalize(gs, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, d_sim_w, d_sim_b, s)))
+            return rc;
+        if ((rc = axial_attn_bwd_fix(g, w.plan, qkv_raw, st.qkv, w.coef_sim, w.tables, w.gram, gates, tr, w.dqkv, w.part_qb,
+                                     w.qb_rpg, s))) return rc;
+        return axial_attn_bwd_relfix(g, w.plan, p->relative, w.coef_sim, st.sim, gates, w.pg_part,
+                                     want_gates ? w.gate_raw : nullptr, tr, d->eps,
+                                     w.rel_part + w.sweep_blocks * 2 * g.gp * (2 * g.L - 1), w.gate_rows, s);
+    }
+    // bn_similarity backward statistics (pass A), coefficients, attention backward (pass B)
+    if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out, d->stride,
+                                   w.part_sb, s))) return rc;
+    if ((rc = axial_sim_bwd_finalize(g, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, d_sim_w, d_sim_b, s)))
+        return rc;
+    return axial_attn_bwd(g, qkv_raw, st.qkv, st.sim, w.coef_sim, p->relative, gates, stacked, lse, dy, w.coef_out, d->stride,
+                          w.dqkv, w.part_qb, w.rel_part, want_gates ? w.gate_part : nullptr, s);
+}
 
 // The gates the kernels multiply with: the stored scalars, or (gate_mode 1) their sigmoids computed into `eff`.
 static int effective_gates(const medt_axial_desc* d, const medt_axial_params* p, float* eff, hipStream_t s, GatePtrs* out) {
@@ -125,7 +171,7 @@ size_t medt_axial_workspace_bytes(const medt_axial_desc* d) {
     if (!d || axial_geom(*d, &g)) return 0;
     Carver cf(nullptr, 0), cb(nullptr, 0);
     FwdWs f(cf, g);
-    BwdWs b(cb, g, d->stride, d->out_relu);
+    BwdWs b(cb, g, d->stride, d->out_relu, d->gate_mode);
     return align_up(cf.off > cb.off ? cf.off : cb.off, 256) + 256;
 }
 
@@ -173,18 +219,17 @@ int medt_axial_core_bwd(const medt_axial_desc* d, const medt_axial_params* p, co
     if (!dy || !sv->lse) { set_error("core_bwd: null dy / lse"); return MEDT_EINVAL; }
     if (d->out_relu) { set_error("core_bwd: out_relu layers are not supported by the benchmark entry"); return MEDT_EUNSUPPORTED; }
     Carver c(ws, ws_bytes);
-    BwdWs w(c, g, d->stride, d->out_relu);
+    BwdWs w(c, g, d->stride, d->out_relu, d->gate_mode);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
     GatePtrs gates;
     if ((rc = effective_gates(d, p, w.gate_eff, s, &gates))) return rc;
-    // pass A (bn_similarity backward statistics) and pass B (dq, dk, dv, table / gate gradients): the two L x L passes;
-    // coef_out / coef_sim are whatever the preceding medt_axial_layer_bwd left in the workspace
-    if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse, dy, w.coef_out,
-                                   d->stride, w.part_sb, s))) return rc;
-    return axial_attn_bwd(g, qkv_raw, st.qkv, st.sim, w.coef_sim, p->relative, gates, stacked, sv->lse, dy, w.coef_out,
-                          d->stride, w.dqkv, w.part_qb, w.rel_part, p->f_qr ? w.gate_part : nullptr, s);
+    // everything between bn_output's and bn_qkv's backward: the single sweep + its closed-form corrections, or the two
+    // generic L x L passes; coef_out is whatever the preceding medt_axial_layer_bwd left in the workspace, bn_similarity's
+    // parameter gradients land in scratch (part_ob is dead by then)
+    return attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, p->f_qr != nullptr, w.part_ob,
+                              w.part_ob + g.SC, s);
 }
 
 int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, float* y,
@@ -259,7 +304,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     }
     if (d->out_relu && !y) { set_error("out_relu backward needs the forward output y"); return MEDT_EINVAL; }
     Carver c(ws, ws_bytes);
-    BwdWs w(c, g, d->stride, d->out_relu);
+    BwdWs w(c, g, d->stride, d->out_relu, d->gate_mode);
     if (!ws || !c.ok()) { set_error("workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     LayerStats st(sv->stats, g);
@@ -288,17 +333,11 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, 1.f / (float)(d->stride * d->stride),
                               st.out, p->bn_output.weight, tr, w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s)))
         return rc;
-    // bn_similarity backward statistics (pass A), coefficients
-    if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse, dy,
-                                   w.coef_out, d->stride, w.part_sb, s))) return rc;
-    if ((rc = axial_sim_bwd_finalize(g, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, gr->bn_sim_weight,
-                                     gr->bn_sim_bias, s))) return rc;
-    // attention backward (pass B)
-    if ((rc = axial_attn_bwd(g, qkv_raw, st.qkv, st.sim, w.coef_sim, p->relative, gates, stacked, sv->lse, dy,
-                             w.coef_out, d->stride, w.dqkv, w.part_qb, w.rel_part, gr->gates ? w.gate_part : nullptr,
-                             s))) return rc;
+    // softmax / bn_similarity / logits backward: dqkv, the partial rows of bn_qkv's backward, of the tables and of the gates
+    if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
+                                 gr->bn_sim_weight, gr->bn_sim_bias, s))) return rc;
     // bn_qkv backward, qkv_transform backward
-    if ((rc = bn_bwd_finalize(w.part_qb, g.tpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
+    if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
     if (g.bf16) {       // bf16 storage: materialise the bn_qkv backward in fp32, then the plain 1x1 dgrad / wgrad
@@ -312,15 +351,19 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if ((rc = conv2d_bwd_weight(w.dqkv, bq_raw, bq_coef, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C, 1,
                                 1, 0, g.groups, s, q))) return rc;
     if (g.pos) {
-        if (q) q->reduce.push_back(RJob{w.rel_part, gr->relative, (int)w.nblocks, 2 * g.gp * TL});
-        else if ((rc = reduce_rows(w.rel_part, (int)w.nblocks, 2 * g.gp * TL, gr->relative, s))) return rc;
+        // partial rows -> gradients (single sweep: one row per workgroup + one correction row per (group, head))
+        const int rel_rows = w.sweep ? (int)w.sweep_blocks + g.groups * g.G : (int)w.nblocks;
+        const float* gate_src = w.sweep ? w.gate_rows : w.gate_part;
+        const int gate_rows = w.sweep ? g.groups * g.G : (int)w.nblocks;
+        if (q) q->reduce.push_back(RJob{w.rel_part, gr->relative, rel_rows, 2 * g.gp * TL});
+        else if ((rc = reduce_rows(w.rel_part, rel_rows, 2 * g.gp * TL, gr->relative, s))) return rc;
         if (gr->gates && d->gate_mode == 2) {
             if ((rc = gate_seq_reduce(w.gate_part, gr->gates, g.groups * g.spg, g.G, s))) return rc;
         } else if (gr->gates) {
             const bool sig = d->gate_mode == 1 && p->f_qr;
-            if (q && !sig) q->reduce.push_back(RJob{w.gate_part, gr->gates, (int)w.nblocks, 4});
+            if (q && !sig) q->reduce.push_back(RJob{gate_src, gr->gates, gate_rows, 4});
             else {
-                if ((rc = reduce_rows(w.gate_part, (int)w.nblocks, 4, sig ? w.gate_tmp : gr->gates, s))) return rc;
+                if ((rc = reduce_rows(gate_src, gate_rows, 4, sig ? w.gate_tmp : gr->gates, s))) return rc;
                 if (sig && (rc = gate_sigmoid_bwd(w.gate_tmp, w.gate_eff, gr->gates, s))) return rc;
             }
         }

@@ -197,4 +197,32 @@ int axial_attn_bwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStat
                    const float* out_coef, int stride, float* dqkv, float* qkv_partials, float* rel_partials,
                    float* gate_partials, hipStream_t s);
 
+
+// ---- axial_bwd.hip: the single-sweep backward of the position-encoded layers (gp <= 4, L in {32, 64, 128}) --------------
+struct SweepPlan {
+    int LS, nw, S_T;        // lanes per sequence, waves per workgroup, sequences per workgroup tile
+    int tiles, nparts;      // tiles per BN group, (persistent) workgroups per BN group
+    int fparts;             // 256-position parts per BN group of the fix kernel
+    int npg_floats;         // per-position / per-sequence Gram record: Gq pairs | Sq | Gk pairs | Sk
+    size_t lds;
+};
+bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p);
+// sliding-window sums of the relative table (sim_tables.h layout) for the fix kernel
+int axial_bwd_tables(const AxialGeom& g, const float* relative, float* tables, hipStream_t s);
+// the sweep: dqkv (e-terms of dq | dk, final dv), bn_qkv partial rows [0, nparts) of every group (v channels),
+// part_sb [group][nparts][G][4], rel_part [G * groups * nparts][2gp * TL], pg_part [same blocks][L * npg_floats],
+// gram [B*][G][npg_floats], gate_raw [same blocks][4] (NULL: no gate gradients)
+int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, BnStats sim,
+                         const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
+                         const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
+                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s);
+// u / w terms of dq | dk (apply != 0: training mode) and the bn_qkv partial rows [nparts, nparts + fparts) (q | k channels)
+int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
+                       const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,
+                       int qb_rpg, hipStream_t s);
+// u / w terms of the table gradients -> rel_rows [groups * G][2gp * TL]; gate gradients -> gate_rows [groups * G][4]
+int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* relative, const float* sim_coef, BnStats sim,
+                          GatePtrs gates, const float* pg_part, const float* gate_raw, int training, float eps,
+                          float* rel_rows, float* gate_rows, hipStream_t s);
+
 }  // namespace medt

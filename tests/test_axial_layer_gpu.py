@@ -98,6 +98,16 @@ CASES = [
     ("gateddata", 32, 32, False, 2, 2, 32),
     ("gateddata", 128, 8, True, 1, 2, 8),
     ("dynamic", 16, 24, True, 1, 2, 5),         # non power-of-two length, ragged tile
+    # the single-sweep backward (csrc/axial_bwd.hip: gp <= 4, L in {32, 64, 128}) on both axes, ragged tiles, stride 2,
+    # with (dynamic: GATES variant) and without (plain) gate gradients
+    ("dynamic", 32, 64, False, 1, 2, 20),
+    ("dynamic", 32, 64, True, 2, 2, 64),
+    ("dynamic", 16, 32, True, 1, 3, 5),
+    ("dynamic", 16, 32, False, 2, 2, 32),
+    ("dynamic", 16, 128, False, 1, 1, 6),
+    ("plain", 16, 64, True, 2, 2, 64),
+    ("plain", 16, 64, False, 1, 3, 7),
+    ("plain", 32, 64, False, 1, 1, 64),
     ("wopos", 16, 12, False, 1, 3, 7),
 ]
 
@@ -121,7 +131,8 @@ def test_layer_vs_oracle(case, training, device):
 
 
 @pytest.mark.parametrize("kind,C,L,width,stride", [("wopos", 16, 16, False, 1), ("wopos", 32, 8, True, 2),
-                                                   ("dynamic", 16, 16, True, 1)])
+                                                   ("dynamic", 16, 16, True, 1), ("dynamic", 16, 32, True, 1),
+                                                   ("plain", 32, 32, False, 2)])
 def test_layer_bn_groups(kind, C, L, width, stride, device):
     """Batched LoGo patches: 4 BN groups on the batch dim == 4 sequential calls."""
     layer = make_layer(kind, C, L, width, stride, device)
@@ -284,3 +295,37 @@ def test_layer_by_layer_fallback_of_small_layers(device):
                         os.path.join(root, "tests", "test_axial_layer_gpu.py"), os.path.join(root, "tests", "test_ops_gpu.py"),
                         "-k", "wopos or test_conv_block"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+
+
+@pytest.mark.parametrize("case", [("dynamic", 16, 64, True, 1, 4, 64), ("dynamic", 32, 32, False, 2, 4, 32),
+                                  ("dynamic", 64, 16, True, 1, 2, 16)],
+                         ids=lambda c: "-".join(str(v) for v in c))
+def test_layer_backward_is_bit_reproducible(case, device):
+    """Two runs of the same layer backward give bit-identical gradients -- every one, the relative tables included (the
+    reference's index_select backward is deterministic on the CPU; the table gradients are accumulated along lane-private
+    diagonals / per-wave LDS rows and reduced in a fixed order, no float atomics).  The third case (gp = 8) runs the generic
+    two-pass kernels, whose table gradients still go through LDS float atomics: held to 1e-6 instead."""
+    kind, C, L, width, stride, N, other = case
+    layer = make_layer(kind, C, L, width, stride, device)
+    st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 300 + C)
+    g = torch.Generator().manual_seed(11)
+    shape = (N, C, other, L) if width else (N, C, L, other)
+    x = torch.randn(shape, generator=g)
+    dout = torch.randn((N, C, shape[2] // stride, shape[3] // stride), generator=g)
+    runs = []
+    for _ in range(2):
+        layer.load_state_dict(st)
+        for p in layer.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        layer.train(True)
+        xg = x.to(device).requires_grad_(True)
+        (layer(xg) * dout.to(device)).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({"dx": xg.grad.clone(), **{k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}})
+    exact = C // 8 <= 4
+    for k in runs[0]:
+        if exact:
+            assert torch.equal(runs[0][k], runs[1][k]), k
+        else:
+            assert H.rel_err(runs[1][k], runs[0][k]) < 1e-6, k
