@@ -33,6 +33,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef MEDT_ABL
+#define MEDT_ABL 0            // timing experiments only (scripts/r3_ablate.sh): 0 = the real kernel
+#endif
+
 namespace medt {
 
 namespace {
@@ -51,6 +55,8 @@ struct Sw {
     static constexpr int RS = L * RREC + 8;
     static_assert(L % LS == 0 && (LS == 8 || LS == 16), "lanes per sequence");
 };
+
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ float dpp(float old, float src) {
@@ -98,9 +104,29 @@ __device__ __forceinline__ float chain_shift0(float x, bool head) {
 template <int LS>
 __device__ __forceinline__ float seqs_sum(float v) {
     if (LS == 8) v += dppv<0x128>(v);                        // row_ror:8
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    // gfx950 lane swaps (VALU, no LDS crossbar round trip): row 1 <-> row 0 / row 3 <-> row 2, then the wave halves
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(h[0]) + __uint_as_float(h[1]);
+}
+
+// v[k] -> LDS word (addr + k * STRIDE_BYTES), k < 4, from the lanes in `mask` only.  EXEC is narrowed inside the statement, so
+// there is no branch: the row steps of an iteration stay one scheduling region, and the LDS pipe sees 4 lanes instead of 64.
+template <int STRIDE_BYTES>
+__device__ __forceinline__ void lds_store4_masked(unsigned addr, float v0, float v1, float v2, float v3, unsigned long long mask) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_and_b64 exec, exec, %1\n\t"
+                 "ds_write_b32 %2, %3 offset:%7\n\t"
+                 "ds_write_b32 %2, %4 offset:%8\n\t"
+                 "ds_write_b32 %2, %5 offset:%9\n\t"
+                 "ds_write_b32 %2, %6 offset:%10\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "s"(mask), "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(0), "n"(STRIDE_BYTES), "n"(2 * STRIDE_BYTES),
+                   "n"(3 * STRIDE_BYTES)
+                 : "scc");
 }
 
 struct SweepArgs {
@@ -148,11 +174,11 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
     float* wacc = tab + (TL + 1) * TREC;
     float* pg = wacc + nw * 2 * NT * L;
     float* red = pg + nw * L * NPG;                           // [4 * 32]
-    float* dump = red + 128 + threadIdx.x * CREC;             // [threads][CREC] write-only slots of the branch-free exit stores
     const int grp = blockIdx.x / a.nparts, part = blockIdx.x - grp * a.nparts, hg = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sg = lane / LS, cb = lane % LS;                 // sequence of the wave, column block of the sequence
     const bool head = cb == 0;
+    const unsigned long long tail_mask = LS == 16 ? 0x8000800080008000ull : 0x8080808080808080ull;   // last lane of every sequence
     const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr), f_sve = gate(a.gates.f_sve), f_sv = gate(a.gates.f_sv);
     const float e_qk = a.ss.scale[grp * g.SC + hg], e_qr = a.ss.scale[grp * g.SC + g.G + hg],
                 e_kr = a.ss.scale[grp * g.SC + 2 * g.G + hg];
@@ -178,7 +204,7 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
         vmean[c] = a.qs.mean[grp * 2 * g.C + hg * NCH + GP + c];
         vrstd[c] = a.qs.rstd[grp * 2 * g.C + hg * NCH + GP + c];
     }
-    // sums over everything this workgroup sees.  T_qk / T_qr are accumulated by all LS lanes of a sequence (scaled at the end)
+    // sums over everything this workgroup sees
     float T_qk = 0.f, T_qr = 0.f, T_kr = 0.f, g_pe = 0.f, g_pv = 0.f;
     float vst[2 * GP];                                        // bn_qkv backward partials of the v channels
 #pragma unroll
@@ -203,73 +229,97 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
         w = g.axis == 1 ? i : sq;
         return ok;
     };
+    // Tile staging in two halves: `issue` = the tile's global loads into registers (unconditional: clamped offsets), `commit`
+    // = bn_qkv / bn_output-backward arithmetic + the LDS records.  With TPF the loads of tile u+1 are issued before the sweep
+    // of tile u and committed after it: their HBM latency hides under the sweep (44 registers at gp = 2; gp = 4 has no room).
+    constexpr bool QA_REC = RREC - (HQ + 2 * GP + 2) >= HQ;   // room in the row record for q * s_qk (one multiply less per row)
+    // (measured on the C=16 L=64 B*=16384 shape: 0.87 ms with the tile prefetch against 0.72 ms without -- kept off)
+    constexpr bool TPF = false && GP == 2 && D <= 4;
+    struct TileRegs { float raw[D][NCH], stk[D][NCH], dyv[D][GP], lse[D]; };
+    auto issue_t = [&](int tile_, TileRegs& r, auto bf) {
+        constexpr bool BF = decltype(bf)::value;              // (compile-time storage type: no branch per load)
+        constexpr unsigned ES = BF ? 2u : 4u;
+        const int seq0_ = tile_ * S_T, nseq_ = min(S_T, g.spg - seq0_);
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            int ls, i, n, h, w;
+            const bool ok = locate(kk, seq0_, nseq_, ls, i, n, h, w);
+            const int pix = ok ? h * g.W + w : 0;
+            const unsigned qoff = ((unsigned)n * 2u * g.C * g.HW + pix) * ES;
+            const int ho = min(h / a.pool, Ho - 1), wo = min(w / a.pool, Wo - 1);
+            const unsigned doff = ok ? (((unsigned)n * g.C * Ho + ho) * Wo + wo) * 4u : 0u;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const unsigned o = qoff + (unsigned)(ch * g.HW) * ES;
+                if (BF) {
+                    r.raw[kk][ch] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(qbase + o));
+                    r.stk[kk][ch] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(sbase + o));
+                } else {
+                    r.raw[kk][ch] = *reinterpret_cast<const float*>(qbase + o);
+                    r.stk[kk][ch] = *reinterpret_cast<const float*>(sbase + o);               // OC == 2C: same layout
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < GP; ++c)
+                r.dyv[kk][c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dybase) + doff + (unsigned)(c * Ho * Wo) * 4u);
+            r.lse[kk] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lbase) + ((unsigned)n * g.G * g.HW + pix) * 4u);
+        }
+    };
+    auto issue = [&](int tile_, TileRegs& r) {
+        if (g.bf16) issue_t(tile_, r, std::true_type{}); else issue_t(tile_, r, std::false_type{});
+    };
+    auto commit = [&](int tile_, const TileRegs& r) {
+        const int seq0_ = tile_ * S_T, nseq_ = min(S_T, g.spg - seq0_);
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            int ls, i, n, h, w;
+            const bool ok = locate(kk, seq0_, nseq_, ls, i, n, h, w);
+            const bool in = h / a.pool < Ho && w / a.pool < Wo;
+            float rbuf[RREC], cbuf[CREC];
+#pragma unroll
+            for (int k = 0; k < RREC; ++k) rbuf[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < CREC; ++k) cbuf[k] = 0.f;
+            float delta = 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) rbuf[c] = fmaf(r.raw[kk][c], sc[c], sh[c]);
+#pragma unroll
+            for (int c = 0; c < HQ + GP; ++c) cbuf[c] = fmaf(r.raw[kk][HQ + c], sc[HQ + c], sh[HQ + c]);
+#pragma unroll
+            for (int k2 = 0; k2 < NCH; ++k2) {                // gradient wrt the stacked sv | sve values (bn_output backward)
+                const float d0 = in ? r.dyv[kk][k2 >> 1] : 0.f;
+                const float ds = fmaf(cf[k2][0], d0, fmaf(cf[k2][1], r.stk[kk][k2], cf[k2][2]));
+                delta = fmaf(ds, r.stk[kk][k2], delta);
+                rbuf[HQ + (k2 & 1) * GP + (k2 >> 1)] = GATES ? ds : ds * ((k2 & 1) ? f_sve : f_sv);
+            }
+            rbuf[HQ + 2 * GP] = r.lse[kk];
+            rbuf[HQ + 2 * GP + 1] = delta;
+            if (QA_REC)
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) rbuf[HQ + 2 * GP + 2 + c] = rbuf[c] * s_qk;
+            if (!ok) {                                        // (idle sequences of a ragged tile get all-zero records)
+#pragma unroll
+                for (int k = 0; k < RREC; ++k) rbuf[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < CREC; ++k) cbuf[k] = 0.f;
+            }
+            f4* rr = reinterpret_cast<f4*>(rowrec + ls * RS + i * RREC);             // 16-byte records: vector stores
+            f4* cr = reinterpret_cast<f4*>(colrec + (ls * L + i) * CREC);
+#pragma unroll
+            for (int k = 0; k < RREC / 4; ++k) rr[k] = f4{rbuf[4 * k], rbuf[4 * k + 1], rbuf[4 * k + 2], rbuf[4 * k + 3]};
+#pragma unroll
+            for (int k = 0; k < CREC / 4; ++k) cr[k] = f4{cbuf[4 * k], cbuf[4 * k + 1], cbuf[4 * k + 2], cbuf[4 * k + 3]};
+        }
+    };
+    TileRegs pf;
+    if (TPF && part < a.tiles) issue(part, pf);
     for (int tile = part; tile < a.tiles; tile += a.nparts) {
         const int seq0 = tile * S_T, nseq = min(S_T, g.spg - seq0);
         __syncthreads();                                      // the previous tile's outputs have been read
-        // ---- stage the tile: one (sequence, position) per thread and step, lanes along the contiguous NCHW direction
-        auto stage = [&](auto bf) {
-            constexpr bool BF = decltype(bf)::value;
-            constexpr unsigned ES = BF ? 2u : 4u;
-#pragma unroll
-            for (int kk = 0; kk < D; ++kk) {
-                int ls, i, n, h, w;
-                const bool ok = locate(kk, seq0, nseq, ls, i, n, h, w);
-                float q[HQ], kv[HQ + GP], dsv[GP], dse[GP], lse = 0.f, delta = 0.f;
-#pragma unroll
-                for (int c = 0; c < HQ; ++c) q[c] = 0.f;
-#pragma unroll
-                for (int c = 0; c < HQ + GP; ++c) kv[c] = 0.f;
-#pragma unroll
-                for (int c = 0; c < GP; ++c) { dsv[c] = 0.f; dse[c] = 0.f; }
-                if (ok) {                                     // (idle sequences of a ragged tile get all-zero records)
-                    const int pix = h * g.W + w;
-                    const unsigned qoff = ((unsigned)n * 2u * g.C * g.HW + pix) * ES;
-                    const int ho = h / a.pool, wo = w / a.pool;
-                    const bool in = ho < Ho && wo < Wo;
-                    const unsigned doff = (((unsigned)n * g.C * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1)) * 4u;
-                    float raw[NCH], stk[NCH], dyv[GP];
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) {
-                        const unsigned o = qoff + (unsigned)(ch * g.HW) * ES;
-                        if (BF) {
-                            raw[ch] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(qbase + o));
-                            stk[ch] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(sbase + o));
-                        } else {
-                            raw[ch] = *reinterpret_cast<const float*>(qbase + o);
-                            stk[ch] = *reinterpret_cast<const float*>(sbase + o);           // OC == 2C: same layout
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < GP; ++c)
-                        dyv[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dybase) + doff + (unsigned)(c * Ho * Wo) * 4u);
-                    lse = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lbase) + ((unsigned)n * g.G * g.HW + pix) * 4u);
-                    MEDT_SCHED_FENCE();
-#pragma unroll
-                    for (int c = 0; c < HQ; ++c) q[c] = fmaf(raw[c], sc[c], sh[c]);
-#pragma unroll
-                    for (int c = 0; c < HQ + GP; ++c) kv[c] = fmaf(raw[HQ + c], sc[HQ + c], sh[HQ + c]);
-#pragma unroll
-                    for (int k2 = 0; k2 < NCH; ++k2) {        // gradient wrt the stacked sv | sve values (bn_output backward)
-                        const float d0 = in ? dyv[k2 >> 1] : 0.f;
-                        const float ds = fmaf(cf[k2][0], d0, fmaf(cf[k2][1], stk[k2], cf[k2][2]));
-                        delta = fmaf(ds, stk[k2], delta);
-                        if (k2 & 1) dse[k2 >> 1] = GATES ? ds : ds * f_sve; else dsv[k2 >> 1] = GATES ? ds : ds * f_sv;
-                    }
-                }
-                float* rr = rowrec + ls * RS + i * RREC;
-                float* cr = colrec + (ls * L + i) * CREC;
-#pragma unroll
-                for (int c = 0; c < HQ; ++c) rr[c] = q[c];
-#pragma unroll
-                for (int c = 0; c < GP; ++c) { rr[HQ + c] = dsv[c]; rr[HQ + GP + c] = dse[c]; }
-                rr[HQ + 2 * GP] = lse;
-                rr[HQ + 2 * GP + 1] = delta;
-#pragma unroll
-                for (int c = 0; c < HQ + GP; ++c) cr[c] = kv[c];
-            }
-        };
-        if (g.bf16) stage(std::true_type{}); else stage(std::false_type{});
+        if (!TPF) issue(tile, pf);
+        commit(tile, pf);
         __syncthreads();
+        if (TPF && tile + a.nparts < a.tiles) issue(tile + a.nparts, pf);          // in flight during the sweep below
         // ---- the sweep ----------------------------------------------------------------------------------------------
         const int ls = wave * SPW + sg;                       // this lane's sequence of the tile
         const float* rrow = rowrec + ls * RS;
@@ -334,24 +384,40 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
                 }
         }
         float* waccw = wacc + wave * 2 * NT * L + cb;
+        const unsigned park_addr = (unsigned)(size_t)crow;     // LDS byte address (low half of the flat pointer)
         // the row record (and the table entry that enters the chain behind it) of row i + 1 is fetched while row i is
         // computed: the loads sit in front of the row's exit store, whose address the compiler cannot tell apart
+        constexpr bool PREFETCH = GP == 2 && MEDT_ABL != 5;                   // (gp = 4: the 20 extra registers spill)
         float nrec[RREC], nfr[TREC];
 #pragma unroll
         for (int k = 0; k < RREC; ++k) nrec[k] = rrow[k];
 #pragma unroll
         for (int k = 0; k < TREC; ++k) nfr[k] = tab[L * TREC + k];
 #pragma unroll 1
-        for (int it = 0; it < LS; ++it) {
+        for (int it = 0; it < (MEDT_ABL == 6 ? 0 : LS); ++it) {
             const bool owner = cb == it;                      // this lane's columns are the rows of this iteration
 #pragma unroll
             for (int t = 0; t < D; ++t) {
                 float rec[RREC], fr[TREC];
+                if (MEDT_ABL == 8) {
 #pragma unroll
-                for (int k = 0; k < RREC; ++k) rec[k] = nrec[k];
+                    for (int k = 0; k < RREC; ++k) rec[k] = 0.01f * k + 1e-3f * it;
 #pragma unroll
-                for (int k = 0; k < TREC; ++k) fr[k] = nfr[k];
-                {
+                    for (int k = 0; k < TREC; ++k) fr[k] = 0.02f * k;
+                } else if (PREFETCH) {
+#pragma unroll
+                    for (int k = 0; k < RREC; ++k) rec[k] = nrec[k];
+#pragma unroll
+                    for (int k = 0; k < TREC; ++k) fr[k] = nfr[k];
+                } else {
+                    const float* rr = rrow + (it * D + t) * RREC;
+                    const float* tf = tab + (it * D + t + L) * TREC;
+#pragma unroll
+                    for (int k = 0; k < RREC; ++k) rec[k] = rr[k];
+#pragma unroll
+                    for (int k = 0; k < TREC; ++k) fr[k] = tf[k];
+                }
+                if (PREFETCH && MEDT_ABL != 8) {
                     const int inext = min(it * D + t + 1, L - 1);
                     const float* rr = rrow + inext * RREC;
                     const float* tf = tab + (inext + L) * TREC;
@@ -362,7 +428,7 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
                 }
                 float q[HQ], qa[HQ], qb[HQ], dsv[GP], dse[GP], Dqk[HQ], Dqr[HQ];
 #pragma unroll
-                for (int c = 0; c < HQ; ++c) { q[c] = rec[c]; qa[c] = q[c] * s_qk; qb[c] = q[c] * s_qr; Dqk[c] = 0.f; Dqr[c] = 0.f; }
+                for (int c = 0; c < HQ; ++c) { q[c] = rec[c]; qa[c] = QA_REC ? rec[HQ + 2 * GP + 2 + c] : q[c] * s_qk; qb[c] = q[c] * s_qr; Dqk[c] = 0.f; Dqr[c] = 0.f; }
 #pragma unroll
                 for (int c = 0; c < GP; ++c) { dsv[c] = rec[HQ + c]; dse[c] = rec[HQ + GP + c]; }
                 const float nlse = -rec[HQ + 2 * GP], ndelta = -rec[HQ + 2 * GP + 1];
@@ -372,7 +438,7 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
                     float z = nlse;
 #pragma unroll
                     for (int c = 0; c < HQ; ++c) z = fmaf(qa[c], kc[s][c], fmaf(qb[c], tq[p][c], fmaf(kb[s][c], tk[p][c], z)));
-                    const float P = __builtin_amdgcn_exp2f(z);
+                    const float P = MEDT_ABL == 4 ? z : __builtin_amdgcn_exp2f(z);
                     float dZ;
                     if (GATES) {
                         float tvv = 0.f, tee = 0.f;
@@ -405,25 +471,32 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
                 // row totals over the LS lanes of the sequence; the lane that owns column j = i keeps dq of the row
 #pragma unroll
                 for (int c = 0; c < HQ; ++c) {
-                    const float a0 = seq_allsum<LS>(Dqk[c]), a1 = seq_allsum<LS>(Dqr[c]);
-                    T_qk = fmaf(q[c], a0, T_qk);
-                    T_qr = fmaf(q[c], a1, T_qr);
-                    const float dqv = fmaf(e_qk, a0, (f_qr * e_qr) * a1);
+                    T_qk = fmaf(q[c], Dqk[c], T_qk);            // (this lane's columns only: the lanes are summed at the end)
+                    T_qr = fmaf(q[c], Dqr[c], T_qr);
+                    const float dq0 = fmaf(e_qk, Dqk[c], (f_qr * e_qr) * Dqr[c]);
+                    const float dqv = MEDT_ABL == 3 ? dq0 : seq_allsum<LS>(dq0);
                     dq_own[t][c] = owner ? dqv : dq_own[t][c];
                 }
                 // the diagonal in slot D-1 leaves the lane: the last lane's is complete (d = i) and is parked in the column
                 // record of position i of its sequence (dead between the initial column loads and the out records); every
                 // other one moves to the next lane, lane 0 of the sequence takes the next table entry
                 const int px = (2 * D - 1 - t) % D;
-                if (t < D - 1 || it < LS - 1) {
-                    {   // (no branch: the row steps of an iteration stay one scheduling region; the other lanes store to a
-                        //  private dump slot)
-                        float* ex = cb == LS - 1 ? crow + (it * D + t) * CREC : dump;
+                if ((t < D - 1 || it < LS - 1) && MEDT_ABL != 7) {
+                    if (MEDT_ABL != 1 && MEDT_ABL != 8) {
+                        // value-major parking: parked[m][i] -- the fold below reads consecutive words from consecutive lanes
+                        float ev[TREC];
 #pragma unroll
-                        for (int c = 0; c < HQ; ++c) { ex[c] = aq[px][c]; ex[HQ + c] = ak[px][c]; }
+                        for (int m = 0; m < TREC; ++m) ev[m] = 0.f;
 #pragma unroll
-                        for (int c = 0; c < GP; ++c) ex[GP + c] = av[px][c];
+                        for (int c = 0; c < HQ; ++c) { ev[c] = aq[px][c]; ev[HQ + c] = ak[px][c]; }
+#pragma unroll
+                        for (int c = 0; c < GP; ++c) ev[GP + c] = av[px][c];
+                        const unsigned pa = park_addr + (unsigned)(it * D + t) * 4u;
+#pragma unroll
+                        for (int m0 = 0; m0 < NT; m0 += 4)
+                            lds_store4_masked<L * 4>(pa + m0 * L * 4, ev[m0], ev[m0 + 1], ev[m0 + 2], ev[m0 + 3], tail_mask);
                     }
+                    if (MEDT_ABL != 2)
 #pragma unroll
                     for (int c = 0; c < HQ; ++c) {
                         tq[px][c] = chain_shift<LS>(tq[px][c], fr[c], head);
@@ -431,6 +504,7 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
                         aq[px][c] = chain_shift0<LS>(aq[px][c], head);
                         ak[px][c] = chain_shift0<LS>(ak[px][c], head);
                     }
+                    if (MEDT_ABL != 2)
 #pragma unroll
                     for (int c = 0; c < GP; ++c) {
                         tv[px][c] = chain_shift<LS>(tv[px][c], fr[GP + c], head);
@@ -439,6 +513,7 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
                 }
             }
         }
+        asm volatile("" ::: "memory");                         // (the parked values below were stored by asm statements)
         // ---- table gradients of the tile -> the wave's accumulators: the diagonals parked by the last lanes (d = 0 .. L-2,
         // this lane folds d = its own D positions) and the ones still in the chain (d = 2L-2-j; slot s sits in physical
         // (s + 1) % D after the last row); the sequences of the wave are summed lane-wise, sequence 0's lanes accumulate
@@ -446,10 +521,13 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
         for (int s = 0; s < D; ++s) {
             const int p = (s + 1) % D;
             const int j = cb * D + s;
-            const float* pk = crow + j * CREC;
+            const float* pk = crow + j;                           // parked[m][j]
             float ex[NT], ch[NT];
 #pragma unroll
-            for (int m = 0; m < NT; ++m) ex[m] = seqs_sum<LS>(j < L - 1 ? pk[m] : 0.f);
+            for (int m = 0; m < NT; ++m) ex[m] = j < L - 1 ? pk[m * L] : 0.f;
+            MEDT_SCHED_FENCE();                                  // (every parked value is read before the out records overwrite them)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ex[m] = seqs_sum<LS>(ex[m]);
 #pragma unroll
             for (int c = 0; c < HQ; ++c) { ch[c] = seqs_sum<LS>(aq[p][c]); ch[HQ + c] = seqs_sum<LS>(ak[p][c]); }
 #pragma unroll
@@ -522,9 +600,8 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
             pp[e] = s;
         }
     }
-    const float inv_ls = 1.f / (float)LS;                     // (T_qk, T_qr: every lane of a sequence saw the same rows)
     {
-        float v[4] = {0.f, T_qk * inv_ls, f_qr * T_qr * inv_ls, f_kr * T_kr};     // sum dZ * {1, S_qk, S_qr, S_kr}
+        float v[4] = {0.f, T_qk, f_qr * T_qr, f_kr * T_kr};     // sum dZ * {1, S_qk, S_qr, S_kr}
         wg_sum<4>(v, red, a.part_sb + ((size_t)blockIdx.x * g.G + hg) * 4, nw);
     }
     {
@@ -535,7 +612,7 @@ __global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_k
         wg_sum<2 * GP>(vst, red, dst + 2 * GP, nw);
     }
     if (GATES) {
-        float v[4] = {T_qr * inv_ls, T_kr, g_pe, g_pv};       // sum dZ rq, sum dZ rk (ungated), sum P dPe, sum P dPv
+        float v[4] = {T_qr, T_kr, g_pe, g_pv};                // sum dZ rq, sum dZ rk (ungated), sum P dPe, sum P dPv
         wg_sum<4>(v, red, a.gate_raw + blk * 4, nw);
     }
 }
@@ -739,7 +816,7 @@ size_t sweep_lds_bytes(int nw) {
     using C = Sw<GP, L, LS>;
     const int S_T = nw * C::SPW;
     return ((size_t)S_T * (C::RS + L * C::CREC) + (size_t)(C::TL + 1) * C::TREC + (size_t)nw * (2 * C::NT * L + L * C::NPG) +
-            128 + (size_t)nw * 64 * C::CREC) * sizeof(float);
+            128) * sizeof(float);
 }
 
 static bool sweep_enabled() {
