@@ -127,13 +127,25 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
             "train_fwd_core": {"bytes_per_launch": bytes_main + 2 * bytes_stats,
                                "achieved": (bytes_main + 2 * bytes_stats) / (t_main + t_stats) / 1e9,
                                "frac": (bytes_main + 2 * bytes_stats) / (t_main + t_stats) / 1e9 / HBM_PEAK_GBPS},
-            "bwd_core": {"kernels": "attn_bwd_stats_kernel + attn_bwd_kernel", "bytes_per_launch": 10 * C * e * M,
+            # backward core = everything between bn_output's and bn_qkv's backward: the single sweep (attn_bwd_sweep_kernel) +
+            # its closed-form bn_similarity corrections (attn_bwd_fix_kernel, attn_bwd_relfix_kernel, table sums, finalize);
+            # gp > 4 / other lengths: the two generic passes (attn_bwd_stats_kernel + attn_bwd_kernel)
+            "bwd_core": {"kernels": ("attn_bwd_sweep_kernel + attn_bwd_fix_kernel + attn_bwd_relfix_kernel + bwd_tables_kernel + "
+                                     "sim_bwd_finalize_kernel" if C // 8 <= 4 and L in (32, 64, 128) and not (C // 8 == 4 and L == 128)
+                                     else "attn_bwd_stats_kernel + attn_bwd_kernel"),
+                         "bytes_per_launch": 10 * C * e * M,
                          "achieved": 10 * C * e * M / t_bwd / 1e9, "frac": 10 * C * e * M / t_bwd / 1e9 / HBM_PEAK_GBPS,
                          "launch_ms": t_bwd * 1e3}}
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tf) and (C, L) == (16, 64) and e == 4:
+    if os.path.exists(tf) and (C, L, images) == (16, 64, 256) and e == 4:
         try:
-            roof["traffic"] = json.load(open(tf)).get("attn_fwd_bytes_per_launch")
+            tj = json.load(open(tf))
+            roof["traffic"] = tj.get("attn_fwd_bytes_per_launch")
+            # NOT measured by this run: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) of the same
+            # command, collected by scripts/collect_profiles.sh and committed
+            roof["traffic_source"] = "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only`, not this run)"
+            if "attn_bwd_bytes_per_launch" in tj:
+                roof["bwd_core"]["traffic"] = tj["attn_bwd_bytes_per_launch"]
         except Exception:
             pass
     return roof
@@ -255,27 +267,34 @@ def main():
     for _ in range(args.warmup):
         step()
     log("warm-up done; timing")
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    # EXACTLY --steps steps per timed window, barrier + synchronize on both sides, MAX over ranks.  The window is ~50 ms at
+    # this step time, so one scheduler hiccup moves it by several percent: MEDT_BENCH_WINDOWS (default 5) back-to-back
+    # windows are timed and the MEDIAN window is the one reported (ms_per_step x steps == that window's wall time).
+    windows = []
+    for _ in range(max(1, int(os.environ.get("MEDT_BENCH_WINDOWS", "5")))):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        windows.append(el)
+    elapsed = sorted(windows)[len(windows) // 2]
     final_loss = loss.item()
-    log(f"{args.steps} steps in {elapsed:.3f}s")
+    log(f"{args.steps} steps per window; windows (ms): {[round(w * 1e3, 2) for w in windows]}; median {elapsed * 1e3:.2f}")
 
     result = {
-        "metric": "training images/sec (MedT, 3x128x128)", "value": world * args.batch * args.steps / elapsed,
+        "metric": f"training images/sec ({args.model}, 3x{args.imgsize}x{args.imgsize})", "value": world * args.batch * args.steps / elapsed,
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / args.steps * 1e3, "windows_ms": [round(w * 1e3, 3) for w in windows], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} imgsize={args.imgsize} bs={args.batch}/GPU train step (fwd+CE+bwd+Adam), "
                                f"BASELINE.json {baseline_config(args)}" + ("" if world == 1 else f" x{world} data-parallel, flat-bucket all-reduce"),
@@ -284,8 +303,10 @@ def main():
                       "bf16 storage of the position-encoded attention layers' qkv / sv|sve activations, f32 arithmetic, "
                       "statistics, layer inputs/outputs and gradients"),
         "final_loss": final_loss, "hip_graph": not args.eager,
-        "collective": (f"{dist.get_backend()} all_reduce(SUM) of the flat gradient bucket, outside the graph"
-                       if distributed else None),
+        "collective": (f"{dist.get_backend()} all_reduce(SUM) of the flat gradient bucket, "
+                       + ("captured in the hipGraph (with the Adam launch behind it)" if getattr(train_step, "collective_in_graph", False)
+                          else "outside the graph") if distributed else None),
+        "collective_in_graph": bool(getattr(train_step, "collective_in_graph", False)) if distributed else None,
     }
     if rank == 0 and world == 1:
         model.eval()
@@ -304,6 +325,14 @@ def main():
             # SURVEY.md 8(d)'s second scaled shape (256-px inputs: C=32, gp=4, L=128), reported beside the headline one
             other = roofline_leg(device, C=32, L=128, images=128, iters=10)
             result["roofline"]["also"] = [{k: other[k] for k in ("kernel", "shape", "achieved", "frac", "launch_ms", "valu_tflops")}]
+            # the same layer at the size the timed step runs it (MedT layer1: 4 images, 256 sequences): different kernel
+            # variants are dispatched there (attn_fwd3_kernel<2,AXIS,64,EXACT=true>; the scaled shape above runs the
+            # 4-rows-per-lane bound-referenced attn_fwd4r_kernel) and the launch is latency-, not bandwidth-bound
+            small = roofline_leg(device, C=16, L=64, images=args.batch, iters=50)
+            result["roofline"]["in_model_shape"] = {
+                "shape": small["shape"], "fwd_kernel": "attn_fwd3_kernel<GP=2,AXIS=1,L=64,EXACT=true>",
+                "fwd_launch_us": small["launch_ms"] * 1e3, "stats_launch_us": small["stats_kernel"]["launch_ms"] * 1e3,
+                "bwd_core_launch_us": small["bwd_core"]["launch_ms"] * 1e3, "fwd_frac": small["frac"]}
             log("roofline leg done")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg()

@@ -6,9 +6,11 @@ At BASELINE.json's batch sizes every kernel of the step moves a few MB at most, 
 launch latency, not by HBM or MFMA.  The whole forward + loss + backward + gradient packing
 (+ the fused Adam when single-GPU) is therefore captured once into a hipGraph (torch.cuda.CUDAGraph drives
 hipStreamBeginCapture; the kernels are enqueued by libmedt_hip.so on the capturing stream) and replayed per
-step.  With several ranks the flat-bucket all-reduce runs between the replay and the Adam launch.
+step.  With several ranks the flat-bucket all-reduce (RCCL) and the Adam launch behind it are graph nodes too.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -40,6 +42,7 @@ class TrainStep:
         self._graphs = {}          # signature -> (graph, static_x, static_y, static_loss, single)
         self._queue = None         # deferred, grouped launches (medt_amd.defer); created on first use (needs the GPU library)
         self._ce_out = None        # [loss, counted pixels, out-of-range targets] of the last step (medt cross_entropy)
+        self.collective_in_graph = False                      # set by capture: the all-reduce + Adam are graph nodes
 
     # ---- eager ------------------------------------------------------------
     def _fwd_bwd(self, x, y):
@@ -119,15 +122,39 @@ class TrainStep:
                 self._eager(static_x, static_y)
             self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
         single = not _distributed()
-        # thread_local: runtime calls of OTHER host threads (a data-loader / pin-memory thread of the caller's own) do
-        # not invalidate this capture; the prefetcher of medt_amd.data additionally holds GPU_CAPTURE_LOCK
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            loss = self._fwd_bwd(static_x, static_y)
-            if single:
-                self.opt.apply(1)
-        return graph, static_x, static_y, loss.detach(), single, getattr(loss, "_medt_ce_out", None)
+        # Data parallel: the flat-bucket all-reduce (RCCL through torch's process group -- its kernels are capturable once
+        # the communicator exists, which the eager warm-up steps above guarantee) and the Adam launch behind it are captured
+        # INTO the graph: one replay per step, no host round trip between backward, collective and update.
+        # MEDT_GRAPH_COLLECTIVE=0, or a process group whose collectives cannot be captured (gloo), leaves them outside.
+        in_graph = single or (os.environ.get("MEDT_GRAPH_COLLECTIVE", "1") != "0" and self._collective_capturable())
+        for attempt in (0, 1):
+            graph = torch.cuda.CUDAGraph()
+            try:
+                # thread_local: runtime calls of OTHER host threads (a data-loader / pin-memory thread of the caller's own)
+                # do not invalidate this capture; the prefetcher of medt_amd.data additionally holds GPU_CAPTURE_LOCK
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    loss = self._fwd_bwd(static_x, static_y)
+                    if in_graph:
+                        if not single:
+                            self.opt.allreduce()
+                        self.opt.apply(_world())
+                break
+            except RuntimeError:
+                if single or not in_graph or attempt:
+                    raise
+                in_graph = False                              # the collective refused capture: keep it outside the graph
+                torch.cuda.synchronize()
+                self._restore(snap)
+        self.collective_in_graph = in_graph and not single
+        return graph, static_x, static_y, loss.detach(), in_graph, getattr(loss, "_medt_ce_out", None)
+
+    @staticmethod
+    def _collective_capturable():
+        try:
+            return dist.get_backend() == "nccl"               # RCCL on ROCm
+        except Exception:
+            return False
 
     def __call__(self, x, y):
         if not self.use_graph:
