@@ -716,32 +716,43 @@ struct RelfixArgs {
     float eps;
 };
 
+constexpr int RELFIX_THREADS = 1024, RELFIX_SLICES = 4;      // the partial rows are summed by 4 slices of 256 threads
+
 template <int HQ>
-__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_relfix_kernel(RelfixArgs a) {
-    constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ);
-    extern __shared__ float pgs[];                              // [L][NPG]
+__global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixArgs a) {
+    constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), MEDT_RT = RELFIX_THREADS;
+    extern __shared__ float pgs[];                              // [L][NPG], then [RELFIX_SLICES - 1][L][NPG] slice sums
     const AxialGeom& g = a.g;
     const int L = g.L, TL = 2 * L - 1;
     const int grp = blockIdx.x / g.G, hg = blockIdx.x - grp * g.G;
     const size_t blk0 = (size_t)hg * a.sweep_gridx + (size_t)grp * a.nparts;
-    for (int e = threadIdx.x; e < L * NPG; e += MEDT_THREADS) {
-        const float* src = a.pg_part + blk0 * L * NPG + e;
-        float s = 0.f;
-        int p = 0;
-        for (; p + 8 <= a.nparts; p += 8) {                   // eight loads in flight, fixed summation order
-            float v[8];
+    {   // per-position Gram sums of this (group, head): slice q sums the parts [q * per, (q + 1) * per), eight loads in
+        // flight, then the slices are added in fixed order
+        const int slice = threadIdx.x / MEDT_THREADS, t0 = threadIdx.x - slice * MEDT_THREADS;
+        const int per = (a.nparts + RELFIX_SLICES - 1) / RELFIX_SLICES;
+        const int p0 = slice * per, p1 = min(a.nparts, p0 + per);
+        for (int e = t0; e < L * NPG; e += MEDT_THREADS) {
+            const float* src = a.pg_part + blk0 * L * NPG + e;
+            float s = 0.f;
+            int p = p0;
+            for (; p + 8 <= p1; p += 8) {
+                float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(p + k) * L * NPG];
+                for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(p + k) * L * NPG];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += v[k];
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
+            for (; p < p1; ++p) s += src[(size_t)p * L * NPG];
+            pgs[slice * L * NPG + e] = s;
         }
-        for (; p < a.nparts; ++p) s += src[(size_t)p * L * NPG];
-        pgs[e] = s;
+        __syncthreads();
+        for (int e = threadIdx.x; e < L * NPG; e += MEDT_RT)
+            pgs[e] = (pgs[e] + pgs[L * NPG + e]) + (pgs[2 * L * NPG + e] + pgs[3 * L * NPG + e]);
     }
-    __shared__ double gred[MEDT_WAVES][4];
+    __shared__ double gred[MEDT_RT / 64][4];
     double graw[4] = {0.0, 0.0, 0.0, 0.0};
     if (a.gate_rows) {                                        // gate sums of this (group, head): parts over the threads
-        for (int p = threadIdx.x; p < a.nparts; p += MEDT_THREADS) {
+        for (int p = threadIdx.x; p < a.nparts; p += MEDT_RT) {
             const float* q = a.gate_raw + (blk0 + p) * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) graw[k] += q[k];
@@ -758,7 +769,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_relfix_kernel(RelfixArg
     const float* cr = a.sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
     const float* ck = a.sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
     float* out = a.rel_rows + (size_t)blockIdx.x * NCH * TL;
-    for (int e = threadIdx.x; e < NCH * TL; e += MEDT_THREADS) {
+    for (int e = threadIdx.x; e < NCH * TL; e += MEDT_RT) {
         const int r = e / TL, d = e - r * TL;
         float res = 0.f;
         if (r < GP && a.training) {
@@ -788,8 +799,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_relfix_kernel(RelfixArg
         out[e] = res;
     }
     if (a.gate_rows && threadIdx.x == 0) {
-        const double t_qr = (gred[0][0] + gred[1][0]) + (gred[2][0] + gred[3][0]), t_kr = (gred[0][1] + gred[1][1]) + (gred[2][1] + gred[3][1]);
-        const double pe = (gred[0][2] + gred[1][2]) + (gred[2][2] + gred[3][2]), pv = (gred[0][3] + gred[1][3]) + (gred[2][3] + gred[3][3]);
+        double t_qr = 0.0, t_kr = 0.0, pe = 0.0, pv = 0.0;
+        for (int w = 0; w < MEDT_RT / 64; ++w) { t_qr += gred[w][0]; t_kr += gred[w][1]; pe += gred[w][2]; pv += gred[w][3]; }
         double gq = (double)cr[0] * t_qr, gk = (double)ck[0] * t_kr;
         if (a.training) {
             const double count = g.sim_count;
@@ -909,8 +920,8 @@ int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* r
     a.g = g; a.relative = relative; a.sim_coef = sim_coef; a.pg_part = pg_part; a.gate_raw = gate_raw; a.ss = sim;
     a.gates = gates; a.rel_rows = rel_rows; a.gate_rows = gate_raw ? gate_rows : nullptr; a.nparts = p.nparts;
     a.sweep_gridx = g.groups * p.nparts; a.training = training; a.eps = eps;
-    const size_t lds = (size_t)g.L * p.npg_floats * sizeof(float);
-    const dim3 grid(g.groups * g.G), block(MEDT_THREADS);
+    const size_t lds = (size_t)RELFIX_SLICES * g.L * p.npg_floats * sizeof(float);
+    const dim3 grid(g.groups * g.G), block(RELFIX_THREADS);
     if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, lds, s, a);
     return launch_status("attn_bwd_relfix_kernel");

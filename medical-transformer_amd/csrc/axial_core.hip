@@ -17,6 +17,7 @@
 // consecutive addresses).  All tensors stay NCHW: the reference's permute+contiguous copies
 // (:143-148, :181-184) become address arithmetic.
 #include "axial_tiles.h"
+#include "sim_tables.h"
 #include <stdlib.h>
 
 namespace medt {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd_kernel(AxialGeom g, con
         float v[2 * OCG];
 #pragma unroll
         for (int k = 0; k < OCG; ++k) { v[2 * k] = outv[k]; v[2 * k + 1] = outv[k] * outv[k]; }
-        block_sum<2 * OCG>(v, red, out_partials + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
+        block_sum_d<2 * OCG>(v, red, reinterpret_cast<double*>(out_partials) + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
     }
 }
 
@@ -468,7 +469,12 @@ __global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __res
                                                               int G, int SC, double count, BnStats ss,
                                                               const float* __restrict__ weight, int training,
                                                               float* __restrict__ coef, float* __restrict__ dweight,
-                                                              float* __restrict__ dbias) {
+                                                              float* __restrict__ dbias, TablesJob tj) {
+    if ((int)blockIdx.x >= SC) {         // appended blocks: sliding-window table sums for the fix kernel of axial_bwd.hip
+        __shared__ float lds[512];
+        sim_tables_block(blockIdx.x - SC, tj.relative, tj.tables, tj.HQ, tj.L, lds);
+        return;
+    }
     const int ch = blockIdx.x, lane = threadIdx.x;          // ch = x*G + hg
     const int x = ch / G, hg = ch - x * G;
     double dg = 0.0, db = 0.0;
@@ -512,9 +518,10 @@ __global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __res
 }
 
 int axial_sim_bwd_finalize(const AxialGeom& g, const float* partials, BnStats sim, const float* weight, int training,
-                           float* coef, float* dweight, float* dbias, hipStream_t s) {
-    hipLaunchKernelGGL(sim_bwd_finalize_kernel, dim3(g.SC), dim3(64), 0, s, partials, g.tpg, g.groups, g.G, g.SC,
-                       g.sim_count, sim, weight, training, coef, dweight, dbias);
+                           float* coef, float* dweight, float* dbias, hipStream_t s, const TablesJob* tables) {
+    const TablesJob tj = tables ? *tables : TablesJob{nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(sim_bwd_finalize_kernel, dim3(g.SC + tj.blocks), dim3(64), 0, s, partials, g.tpg, g.groups, g.G, g.SC,
+                       g.sim_count, sim, weight, training, coef, dweight, dbias, tj);
     return launch_status("sim_bwd_finalize");
 }
 

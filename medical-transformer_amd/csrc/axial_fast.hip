@@ -166,7 +166,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
         float v[2 * OCG];
 #pragma unroll
         for (int k = 0; k < OCG; ++k) { v[2 * k] = outv[k]; v[2 * k + 1] = outv[k] * outv[k]; }
-        block_sum<2 * OCG>(v, red, out_partials + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
+        block_sum_d<2 * OCG>(v, red, reinterpret_cast<double*>(out_partials) + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
     }
 }
 
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 #pragma unroll
         for (int k = 0; k < OCG; ++k) { v[2 * k] = st_sum[k]; v[2 * k + 1] = st_sq[k]; }
         __syncthreads();
-        block_sum<2 * OCG>(v, red, out_partials + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
+        block_sum_d<2 * OCG>(v, red, reinterpret_cast<double*>(out_partials) + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
     }
 }
 
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
 #pragma unroll
         for (int k = 0; k < OCG; ++k) { v[2 * k] = st_sum[k]; v[2 * k + 1] = st_sq[k]; }
         __syncthreads();
-        block_sum<2 * OCG>(v, red, out_partials + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
+        block_sum_d<2 * OCG>(v, red, reinterpret_cast<double*>(out_partials) + ((size_t)blockIdx.x * g.OC + hg * OCG) * 2);
     }
 }
 

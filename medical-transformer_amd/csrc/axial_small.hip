@@ -27,12 +27,12 @@ struct SmallFwdArgs {
 };
 
 // scale/shift of one channel, bit-identical to bn_finalize_kernel (pointwise.hip) given the same float sums
-__device__ __forceinline__ void small_scale_shift(float s, float ss, double count, const medt_bn_ptrs& bn, int ch, float eps,
+__device__ __forceinline__ void small_scale_shift(double s, double ss, double count, const medt_bn_ptrs& bn, int ch, float eps,
                                                   int training, float& scale, float& shift) {
     const float g = bn.weight[ch], b = bn.bias[ch];
     if (training) {
-        const double mean = (double)s / count;
-        double var = (double)ss / count - mean * mean;
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         scale = (float)(g * rstd);
@@ -47,12 +47,12 @@ __device__ __forceinline__ void small_scale_shift(float s, float ss, double coun
 
 // The same from per-channel parameters that were prefetched into LDS at kernel start (prm[4]: weight, bias, running mean,
 // running variance): the lane that finalises a BatchNorm does not start a dependent global round trip in mid-kernel.
-__device__ __forceinline__ void small_scale_shift_p(float s, float ss, double count, const float* prm, float eps, int training,
+__device__ __forceinline__ void small_scale_shift_p(double s, double ss, double count, const float* prm, float eps, int training,
                                                     float& scale, float& shift) {
     const float g = prm[0], b = prm[1];
     if (training) {
-        const double mean = (double)s / count;
-        double var = (double)ss / count - mean * mean;
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         scale = (float)(g * rstd);
@@ -225,12 +225,13 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     // 2. bn_qkv: batch statistics over the group's positions (one wave per channel)      (:228)
     for (int oc = wave; oc < NCH; oc += NW) {
         float s = 0.f, ss = 0.f;
-        for (int q = lane; q < P; q += 64) {
-            const float v = Q[oc * P + q];
-            s += v;
-            ss = fmaf(v, v, ss);
-        }
+        for (int q = lane; q < P; q += 64) s += Q[oc * P + q];
         s = wave_sum(s);
+        const float m = s * (1.f / (float)P);           // second pass: squares about the mean (centered_to_raw, medt_common.h)
+        for (int q = lane; q < P; q += 64) {
+            const float dv = Q[oc * P + q] - m;
+            ss = fmaf(dv, dv, ss);
+        }
         ss = wave_sum(ss);
         if (lane == 0) {
             red[oc * 2] = s;
@@ -240,11 +241,13 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     __syncthreads();
     if (tid < NCH) {                                   // the double-precision finalisations side by side, not one per wave turn
         const int ch = hg * NCH + tid;
-        const float s = red[tid * 2], ss = red[tid * 2 + 1];
+        double s, ss;
+        centered_to_raw(red[tid * 2], red[tid * 2 + 1], red[tid * 2] * (1.f / (float)P), (double)P, s, ss);
         small_scale_shift_p(s, ss, (double)P, prm + tid * 4, a.eps, a.training, sc[tid], sh[tid]);
-        if (a.training) {
-            a.part_q[((size_t)grp * 2 * C + ch) * 2] = s;
-            a.part_q[((size_t)grp * 2 * C + ch) * 2 + 1] = ss;
+        if (a.training) {                              // doubles, like every forward BatchNorm partial
+            double* dp = reinterpret_cast<double*>(a.part_q) + ((size_t)grp * 2 * C + ch) * 2;
+            dp[0] = s;
+            dp[1] = ss;
         }
     }
     __syncthreads();
@@ -283,11 +286,12 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     small_block_sum<2>(v, red, red + 32, NW);
     if (tid == 0) {
         float scale, shift;
-        small_scale_shift_p(red[32], red[33], (double)P * L, prm + NCH * 4, a.eps, a.training, scale, shift);
+        small_scale_shift_p((double)red[32], (double)red[33], (double)P * L, prm + NCH * 4, a.eps, a.training, scale, shift);
         red[40] = scale;
         if (a.training) {
-            a.part_s[((size_t)grp * a.G + hg) * 2] = red[32];
-            a.part_s[((size_t)grp * a.G + hg) * 2 + 1] = red[33];
+            double* dp = reinterpret_cast<double*>(a.part_s) + ((size_t)grp * a.G + hg) * 2;
+            dp[0] = (double)red[32];
+            dp[1] = (double)red[33];
         }
     }
     __syncthreads();
@@ -325,12 +329,13 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     // 5. bn_output statistics                                                             (:242)
     for (int c = wave; c < GP; c += NW) {
         float s = 0.f, ss = 0.f;
-        for (int q = lane; q < P; q += 64) {
-            const float x = S[c * P + q];
-            s += x;
-            ss = fmaf(x, x, ss);
-        }
+        for (int q = lane; q < P; q += 64) s += S[c * P + q];
         s = wave_sum(s);
+        const float m = s * (1.f / (float)P);
+        for (int q = lane; q < P; q += 64) {
+            const float dv = S[c * P + q] - m;
+            ss = fmaf(dv, dv, ss);
+        }
         ss = wave_sum(ss);
         if (lane == 0) {
             red[c * 2] = s;
@@ -340,11 +345,13 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     __syncthreads();
     if (tid < GP) {
         const int ch = hg * GP + tid;
-        const float s = red[tid * 2], ss = red[tid * 2 + 1];
+        double s, ss;
+        centered_to_raw(red[tid * 2], red[tid * 2 + 1], red[tid * 2] * (1.f / (float)P), (double)P, s, ss);
         small_scale_shift_p(s, ss, (double)P, prm + (NCH + 1 + tid) * 4, a.eps, a.training, sc[tid], sh[tid]);
         if (a.training) {
-            a.part_o[((size_t)grp * C + ch) * 2] = s;
-            a.part_o[((size_t)grp * C + ch) * 2 + 1] = ss;
+            double* dp = reinterpret_cast<double*>(a.part_o) + ((size_t)grp * C + ch) * 2;
+            dp[0] = s;
+            dp[1] = ss;
         }
     }
     __syncthreads();

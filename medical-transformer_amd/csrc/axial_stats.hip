@@ -181,16 +181,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
     acc[4] = f_kr * r1k;
     acc[5] = f_kr * f_kr * r2k;
     constexpr int NA = POS ? 6 : 2;
+    // (double from the cross-lane tree on, like every forward BatchNorm statistic: block_sum_d in medt_common.h)
+    double* redd = reinterpret_cast<double*>(red);              // [4][8] doubles (64-float region at an even offset)
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const float s = wave_sum(acc[k]);
-        if (lane == 0) red[slice * 8 + k] = s;
+        const double s = wave_sum_d((double)acc[k]);
+        if (lane == 0) redd[slice * 8 + k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NA) {                                      // partial layout [grp][part][SC][2], channel x*G + hg
+    if (threadIdx.x < NA) {                                      // partial layout [grp][part][SC][2] doubles, channel x*G + hg
         const int k = threadIdx.x;
-        const float s = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
-        partials[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
+        const double s = (redd[k] + redd[8 + k]) + (redd[16 + k] + redd[24 + k]);
+        reinterpret_cast<double*>(partials)[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
     }
 }
 
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom 
                                                                       GatePtrs gates, float* __restrict__ partials,
                                                                       int sparts) {
     constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NCH = 4 * HQ, L = 16 * V;
-    __shared__ float red[MEDT_WAVES * 8];
+    __shared__ double red[MEDT_WAVES * 8];
     const int grp = blockIdx.x / sparts, tile = blockIdx.x - grp * sparts, hg = blockIdx.y;
     const int seq0 = tile * 64, nseq = min(64, g.spg - seq0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, p0 = (lane & 15) * V;
@@ -332,14 +334,14 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom 
     constexpr int NA = POS ? 6 : 2;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const float t = wave_sum(acc[k]);
+        const double t = wave_sum_d((double)acc[k]);
         if (lane == 0) red[wave * 8 + k] = t;
     }
     __syncthreads();
     if (threadIdx.x < NA) {
         const int k = threadIdx.x;
-        const float t = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
-        partials[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = t;
+        const double t = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
+        reinterpret_cast<double*>(partials)[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = t;
     }
 }
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
     int npg, int y_bf16) {
     constexpr int KK = K * K;
-    __shared__ float red[MEDT_WAVES * OT * 2];
+    __shared__ float red[MEDT_WAVES * OT * 2 * 2];
     const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * OT;
     const int q = part * MEDT_THREADS + threadIdx.x;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
             v[2 * o] = a;
             v[2 * o + 1] = a * a;
         }
-        block_sum<2 * OT>(v, red, partials + ((size_t)blockIdx.x * Cout + o0) * 2);
+        block_sum_d<2 * OT>(v, red, reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o0) * 2);
     }
 }
 

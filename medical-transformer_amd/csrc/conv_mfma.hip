@@ -137,12 +137,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     if (partials) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = s1[r], b = s2[r];
+            double a = s1[r], b = s2[r];                       // (double from the cross-lane tree on: block_sum_d, medt_common.h)
 #pragma unroll
             for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
             const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
             if ((lane & 15) == 0 && o < Cout) {
-                float* dst = partials + ((size_t)blockIdx.x * Cout + o) * 2;
+                double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
                 dst[0] = a;
                 dst[1] = b;
             }
@@ -264,12 +264,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
     if (partials) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = s1[r], b = s2[r];
+            double a = s1[r], b = s2[r];                       // (double from the cross-lane tree on: block_sum_d, medt_common.h)
 #pragma unroll
             for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
             const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
             if ((lane & 15) == 0 && o < Cout) {
-                float* dst = partials + ((size_t)blockIdx.x * Cout + o) * 2;
+                double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
                 dst[0] = a;
                 dst[1] = b;
             }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(
 __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
     const float* __restrict__ slices, int nslices, size_t slice_stride, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ partials, int Cout, int HoWo, int npg, int ppg64, int relu) {
-    __shared__ float red[MEDT_WAVES * 2];
+    __shared__ float red[MEDT_WAVES * 2 * 2];
     const int per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o = blockIdx.y;
     const int q = part * MEDT_THREADS + threadIdx.x;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
         v[0] = a;
         v[1] = a * a;
     }
-    if (partials) block_sum<2>(v, red, partials + ((size_t)blockIdx.x * Cout + o) * 2);
+    if (partials) block_sum_d<2>(v, red, reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2);
 }
 
 // number of K slices for a problem with `tiles` output tiles (1 = no split)

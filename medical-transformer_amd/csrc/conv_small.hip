@@ -24,12 +24,12 @@ struct SmallConvArgs {
 };
 
 // identical arithmetic to bn_finalize_kernel (pointwise.hip) given the same float sums
-__device__ __forceinline__ void conv_small_scale_shift(float s, float ss, double count, const medt_bn_ptrs& bn, int ch,
+__device__ __forceinline__ void conv_small_scale_shift(double s, double ss, double count, const medt_bn_ptrs& bn, int ch,
                                                        float eps, int training, float& scale, float& shift) {
     const float g = bn.weight[ch], b = bn.bias[ch];
     if (training) {
-        const double mean = (double)s / count;
-        double var = (double)ss / count - mean * mean;
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         scale = (float)(g * rstd);
@@ -43,12 +43,12 @@ __device__ __forceinline__ void conv_small_scale_shift(float s, float ss, double
 }
 
 // The same from parameters prefetched into LDS at kernel start (prm[4]: weight, bias, running mean, running variance)
-__device__ __forceinline__ void conv_small_scale_shift_p(float s, float ss, double count, const float* prm, float eps,
+__device__ __forceinline__ void conv_small_scale_shift_p(double s, double ss, double count, const float* prm, float eps,
                                                          int training, float& scale, float& shift) {
     const float g = prm[0], b = prm[1];
     if (training) {
-        const double mean = (double)s / count;
-        double var = (double)ss / count - mean * mean;
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         scale = (float)(g * rstd);
@@ -205,12 +205,13 @@ __global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a
     __syncthreads();
     for (int oc = wave; oc < SC_NOC; oc += NW) {
         float s = 0.f, ss = 0.f;
-        for (int qq = lane; qq < P; qq += 64) {
-            const float v = Z[oc * P + qq];
-            s += v;
-            ss = fmaf(v, v, ss);
-        }
+        for (int qq = lane; qq < P; qq += 64) s += Z[oc * P + qq];
         s = wave_sum(s);
+        const float m = s * (1.f / (float)P);           // second pass: squares about the mean (centered_to_raw, medt_common.h)
+        for (int qq = lane; qq < P; qq += 64) {
+            const float dv = Z[oc * P + qq] - m;
+            ss = fmaf(dv, dv, ss);
+        }
         ss = wave_sum(ss);
         if (lane == 0) {
             sums[oc * 2] = s;
@@ -220,11 +221,13 @@ __global__ __launch_bounds__(T) void conv1x1_bn_small_fwd_kernel(SmallConvArgs a
     __syncthreads();
     if (tid < SC_NOC) {                               // the double-precision finalisation of the 16 channels side by side
         const int ch = oc0 + tid;
-        const float s = sums[tid * 2], ss = sums[tid * 2 + 1];
+        double s, ss;
+        centered_to_raw(sums[tid * 2], sums[tid * 2 + 1], sums[tid * 2] * (1.f / (float)P), (double)P, s, ss);
         conv_small_scale_shift_p(s, ss, (double)P, prm + tid * 4, a.eps, a.training, sc[tid], sh[tid]);
-        if (a.training) {
-            a.partials[((size_t)grp * a.Cout + ch) * 2] = s;
-            a.partials[((size_t)grp * a.Cout + ch) * 2 + 1] = ss;
+        if (a.training) {                             // [groups][Cout][2] doubles, like every forward BatchNorm partial
+            double* dp = reinterpret_cast<double*>(a.partials) + ((size_t)grp * a.Cout + ch) * 2;
+            dp[0] = s;
+            dp[1] = ss;
         }
     }
     __syncthreads();

@@ -43,10 +43,11 @@ struct FwdWs {
         const size_t kq = conv2d_fwd_scratch_floats(g.N, g.groups, g.C, g.H, g.W, 2 * g.C, 1, 1, 0);
         qkv_ksplit = c.take<float>(kq);
         if (!kq) qkv_ksplit = nullptr;
-        part_qkv = c.take<float>((size_t)g.groups * conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1) * 2 * g.C * 2);
-        part_sim = c.take<float>((size_t)g.groups * sim_stats_parts(g) * g.SC * 2);
+        // forward statistics partials are [..][CH][2] DOUBLES (block_sum_d, medt_common.h): twice the floats
+        part_qkv = c.take<float>((size_t)g.groups * conv_parts_per_group(g.N, g.groups, g.HW, g.C, 2 * g.C, 1, 1) * 2 * g.C * 2 * 2);
+        part_sim = c.take<float>((size_t)g.groups * sim_stats_parts(g) * g.SC * 2 * 2);
         tables = c.take<float>(sim_tables_floats(g));
-        part_out = c.take<float>((size_t)g.groups * g.tpg * g.OC * 2);
+        part_out = c.take<float>((size_t)g.groups * g.tpg * g.OC * 2 * 2);
     }
 };
 
@@ -97,13 +98,14 @@ static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, cons
     const int tr = d->training ? 1 : 0;
     int rc;
     if (w.sweep) {
-        if (tr && (rc = axial_bwd_tables(g, p->relative, w.tables, s))) return rc;
         if ((rc = axial_attn_bwd_sweep(g, w.plan, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out,
                                        d->stride, w.dqkv, w.part_qb, w.qb_rpg, w.part_sb, w.rel_part, w.pg_part, w.gram,
                                        want_gates ? w.gate_raw : nullptr, s))) return rc;
         AxialGeom gs = g;
         gs.tpg = w.plan.nparts;                               // part_sb rows per group
-        if ((rc = axial_sim_bwd_finalize(gs, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, d_sim_w, d_sim_b, s)))
+        // (+ the sliding-window table sums of the fix kernel as extra blocks of this launch)
+        const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
+        if ((rc = axial_sim_bwd_finalize(gs, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, d_sim_w, d_sim_b, s, &tj)))
             return rc;
         if ((rc = axial_attn_bwd_fix(g, w.plan, qkv_raw, st.qkv, w.coef_sim, w.tables, w.gram, gates, tr, w.dqkv, w.part_qb,
                                      w.qb_rpg, s))) return rc;
@@ -408,7 +410,8 @@ struct ConvWs {
         if (!(kf > 0 || kb > 0)) ksplit = nullptr;
         ksplit_fwd = kf > 0 ? ksplit : nullptr;
         ksplit_bwd = kb > 0 ? ksplit : nullptr;
-        partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * (g.ppg > g.ppg_bwd ? g.ppg : g.ppg_bwd) * d->Cout * 2 : 0);
+        // (forward: [..][Cout][2] doubles; backward: [..][Cout][2] floats)
+        partials = c.take<float>(d->has_bn ? (size_t)d->bn_groups * (2 * g.ppg > g.ppg_bwd ? 2 * g.ppg : g.ppg_bwd) * d->Cout * 2 : 0);
         coef = c.take<float>(d->has_bn ? (size_t)d->bn_groups * d->Cout * 3 : 0);
         bias_scratch = c.take<float>((size_t)16 * d->Cout);
         gbuf = c.take<float>(g.out_elems);

@@ -86,4 +86,52 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float* red, float* dst,
     __syncthreads();
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Forward BatchNorm statistics.  The partial sums [sum x, sum x^2] every producer kernel hands to bn_finalize are
+// DOUBLES, reduced in double from the per-thread float values on: the batch variance is finalised as E[x^2] - E[x]^2, and a
+// float32 reduction tree rounds sum x^2 at ~1e-7 relative -- 1e-7 * (1 + mean^2 / var) of the variance, visibly above the
+// noise of the reference, whose nn.BatchNorm accumulates in double on the CPU (bn_output of the attention layers has
+// mean^2 / var ~ 100).  With double partials only the single rounding of each x * x is left (random, averages out).
+// `red`: MEDT_WAVES * min(K, 32) * 2 floats of LDS (the doubles are stored as two words: no 8-byte alignment needed).
+// (sum x, sum (x - m)^2 about a float shift m) -> (sum x, sum x^2) in double: the exact identity
+// sum (x - m)^2 = sum x^2 - 2 m sum x + n m^2, whatever m is.  The kernels that hold a BatchNorm group's values in LDS
+// (conv_small.hip, axial_small.hip) sum the squares about m = sum / n (second pass), where a float32 sum is harmless.
+__device__ __forceinline__ void centered_to_raw(float s, float m2, float m, double count, double& sum, double& sumsq) {
+    sum = (double)s;
+    sumsq = (double)m2 + 2.0 * (double)m * sum - count * (double)m * (double)m;
+}
+
+template <int K>
+__device__ __forceinline__ void block_sum_d(const float (&v)[K], float* red, double* dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int CH = K < 32 ? K : 32;
+    int* ri = reinterpret_cast<int*>(red);
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += CH) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (k0 + k < K) {
+                const double s = wave_sum_d((double)v[k0 + k]);
+                if (lane == 0) {
+                    ri[(wave * CH + k) * 2] = __double2loint(s);
+                    ri[(wave * CH + k) * 2 + 1] = __double2hiint(s);
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < CH && k0 + k < K; k += MEDT_THREADS) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < MEDT_WAVES; ++w) s += __hiloint2double(ri[(w * CH + k) * 2 + 1], ri[(w * CH + k) * 2]);
+            dst[k0 + k] = s;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace medt

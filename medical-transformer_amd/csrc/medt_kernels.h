@@ -188,8 +188,10 @@ int axial_attn_bwd_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, 
                          GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* partials, hipStream_t s);
 // sim backward coefficients [group][SC][3] (e,u,w) + dweight/dbias of bn_similarity
+// tables (optional): sim_tables_blocks() extra blocks build the sliding-window table sums the single-sweep backward's fix
+// kernel reads (no launch of their own)
 int axial_sim_bwd_finalize(const AxialGeom& g, const float* partials, BnStats sim, const float* weight, int training,
-                           float* coef, float* dweight, float* dbias, hipStream_t s);
+                           float* coef, float* dweight, float* dbias, hipStream_t s, const TablesJob* tables = nullptr);
 // backward pass B: dqkv (wrt normalised qkv), bn_qkv bwd partials [group][tile][2C][2],
 // relative-table partials [blocks][2gp*(2L-1)], gate partials [blocks][4]
 int axial_attn_bwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* sim_coef,

@@ -17,7 +17,7 @@ template <int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ partials,
     int Cin, int Cout, int HW) {
-    __shared__ float red[MEDT_WAVES * OT * 2];
+    __shared__ float red[MEDT_WAVES * OT * 2 * 2];
     const int  p  = blockIdx.x * MEDT_THREADS + threadIdx.x;
     const int  n  = blockIdx.y;
     const int  o0 = blockIdx.z * OT;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_fwd_kernel(
         float v[2 * OT];
 #pragma unroll
         for (int o = 0; o < OT; ++o) { v[2 * o] = acc[o]; v[2 * o + 1] = acc[o] * acc[o]; }
-        block_sum<2 * OT>(v, red, partials + ((size_t)(n * gridDim.x + blockIdx.x) * Cout + o0) * 2);
+        block_sum_d<2 * OT>(v, red, reinterpret_cast<double*>(partials) + ((size_t)(n * gridDim.x + blockIdx.x) * Cout + o0) * 2);
     }
 }
 
@@ -315,17 +315,12 @@ int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s) {
 // --------------------------------------------------------------------------- //
 // BatchNorm statistics finalisation.  One wave per channel; double accumulation.
 // --------------------------------------------------------------------------- //
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 
 // Per-group sums of NV interleaved partial values.  With `groups` a power of two <= 64 the 64 lanes split into
 // groups x (64/groups) slots, every lane streams its slot's parts and a butterfly over the slot bits leaves the
 // group total in every lane of that group (lane % groups == g) -- no serial dependent loads over the groups.
-template <int NV>
-__device__ __forceinline__ bool group_sums(const float* __restrict__ partials, int ppg, int groups, int CH, int ch,
+template <int NV, class T = float>
+__device__ __forceinline__ bool group_sums(const T* __restrict__ partials, int ppg, int groups, int CH, int ch,
                                            int stride, const int (&which)[NV], double (&out)[NV]) {
     const int lane = threadIdx.x;
     if (groups > 64 || (groups & (groups - 1))) return false;
@@ -333,7 +328,7 @@ __device__ __forceinline__ bool group_sums(const float* __restrict__ partials, i
 #pragma unroll
     for (int k = 0; k < NV; ++k) out[k] = 0.0;
     for (int p = slot; p < ppg; p += slots) {
-        const float* q = partials + ((size_t)(g * ppg + p) * CH + ch) * stride;
+        const T* q = partials + ((size_t)(g * ppg + p) * CH + ch) * stride;
 #pragma unroll
         for (int k = 0; k < NV; ++k) out[k] += (double)q[which[k]];
     }
@@ -343,12 +338,14 @@ __device__ __forceinline__ bool group_sums(const float* __restrict__ partials, i
     return true;
 }
 
-__device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict__ partials, int ppg, int groups, int CH,
+// partials: [group][part][CH][2] DOUBLES (sum x, sum x^2) -- see block_sum_d in medt_common.h
+__device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict__ partials_f, int ppg, int groups, int CH,
                                                  double count, const float* __restrict__ weight,
                                                  const float* __restrict__ bias, float* running_mean,
                                                  float* running_var, int64_t* nbt, float momentum, float eps,
                                                  int training, BnStats out) {
     const int lane = threadIdx.x;
+    const double* partials = reinterpret_cast<const double*>(partials_f);
     const float g = weight[ch], b = bias[ch];
     if (!training) {
         const float  mean = running_mean[ch];
@@ -364,7 +361,7 @@ __device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict
     double rm = running_mean ? (double)running_mean[ch] : 0.0, rv = running_var ? (double)running_var[ch] : 0.0;
     double sums[2];
     const int which[2] = {0, 1};
-    if (group_sums<2>(partials, ppg, groups, CH, ch, 2, which, sums)) {
+    if (group_sums<2, double>(partials, ppg, groups, CH, ch, 2, which, sums)) {
         const double mean = sums[0] / count;
         double var = sums[1] / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -384,9 +381,9 @@ __device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict
         for (int grp = 0; grp < groups; ++grp) {
             double s = 0.0, ss = 0.0;
             for (int p = lane; p < ppg; p += 64) {
-                const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
-                s += (double)q[0];
-                ss += (double)q[1];
+                const double* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
+                s += q[0];
+                ss += q[1];
             }
             s = wave_sum_d(s);
             ss = wave_sum_d(ss);

@@ -233,6 +233,51 @@ def test_large_batch_property(device):
     assert H.rel_err(y2, y) < 1e-5
 
 
+@pytest.mark.parametrize("width", [True, False], ids=["w", "h"])
+def test_dispatch_scale_variants_vs_oracle(width, device):
+    """The kernels that only dispatch on big problems -- attn_fwd4r (four rows per lane), the bound-referenced softmax with its
+    repair pass behind, the persistent multi-tile loops of the forward and of the backward sweep, the 4-wave workgroups --
+    UNFORCED at their own dispatch scale: N = 64 images of (16, 64, 64), i.e. 4096 sequences, 134M logits per launch.
+    The batch is 16 replicas of a 4-image batch, so its BatchNorm batch statistics equal the 4-image batch's exactly:
+      * train mode: output, dx and every parameter gradient against the fp64 oracle ON THE 4-IMAGE BATCH (parameter gradients
+        of the big batch are 16x the small batch's, running statistics and dx per image are the same);
+      * every replica's output / dx must equal replica 0's bit for bit (tile- and workgroup-independent arithmetic)."""
+    C, L, R = 16, 64, 16
+    layer = make_layer("dynamic", C, L, width, 1, device)
+    st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 77)
+    g = torch.Generator().manual_seed(5)
+    x4 = torch.randn((4, C, L, L), generator=g)
+    d4 = torch.randn((4, C, L, L), generator=g)
+    x, dout = x4.repeat(R, 1, 1, 1), d4.repeat(R, 1, 1, 1)
+    layer.load_state_dict(st)
+    for p in layer.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    layer.train()
+    xg = x.to(device).requires_grad_(True)
+    y = layer(xg)
+    (y * dout.to(device)).sum().backward()
+    torch.cuda.synchronize()
+    for r in range(1, R):
+        assert torch.equal(y[4 * r:4 * r + 4], y[:4]), r
+        assert torch.equal(xg.grad[4 * r:4 * r + 4], xg.grad[:4]), r
+    ost = O.clone_state({("m." + k): v for k, v in st.items()}, torch.float64, requires_grad=True)
+    xo = x4.double().requires_grad_(True)
+    yo = O.axial_attention(xo, ost, "m", width, 1, True)
+    (yo * d4.double()).sum().backward()
+    got = {"y": y[:4].detach(), "dx": xg.grad[:4]}
+    want = {"y": yo.detach(), "dx": xo.grad}
+    for k, p in layer.named_parameters():
+        got["grad/" + k] = p.grad / R
+        want["grad/" + k] = ost["m." + k].grad
+    for k, b in layer.state_dict().items():
+        if "running" in k:
+            got["buf/" + k] = b.clone()
+            want["buf/" + k] = ost["m." + k]
+    # (the unbiased running variance divides by count - 1: 16x the population moves it by < 1e-5 relative)
+    compare(got, want)
+
+
 def _run_layer_subprocess(env_extra):
     import subprocess
     import sys

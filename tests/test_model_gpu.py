@@ -12,7 +12,9 @@ from oracle import medt_oracle as O
 pytestmark = pytest.mark.gpu
 MODEL_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(H.GOLDEN, "model_*.npz")))
 TOL = 1e-3
-KNOISE = 5.0        # training-mode gradients: product error <= KNOISE x the reference's own measured fp32 noise
+KNOISE = 2.0        # training-mode gradients: product error <= KNOISE x the reference's own measured fp32 noise
+                    # (max over EIGHT float32 runs of the reference per tensor -- make_golden.py; observed on the MI355X:
+                    #  max ratio 0.65 - 0.91 over the four training fixtures, median 0.07 - 0.20)
 
 
 def build(name, S, device, chan=3):
@@ -25,10 +27,10 @@ def build(name, S, device, chan=3):
 @pytest.mark.parametrize("fn", MODEL_FILES)
 def test_model_vs_reference_fixture(fn, device):
     """Tolerances.  eval / evalgrad (running statistics): 1e-3 relative, everything.
-    train (batch statistics): logits 1e-3 or 3x the reference's own fp32-vs-fp64 discrepancy, whichever
+    train (batch statistics): logits 1e-3 or 1.5x the reference's own fp32-vs-fp64 discrepancy, whichever
     is larger; every gradient tensor within KNOISE x the reference's own fp32 noise on THAT tensor (the
-    maximum over three fp32 runs of the reference with different summation orders, stored per tensor by
-    make_golden.py) -- the whole-network training-mode backward is ill-conditioned in fp32 for the
+    maximum over eight fp32 runs of the reference -- other summation orders, inputs / parameters moved by one
+    unit in the last place -- stored per tensor by make_golden.py) -- the whole-network training-mode backward is ill-conditioned in fp32 for the
     reference itself (DESIGN.md 'parity floor').  The ratio product-error / reference-noise is printed.
     The exact backward wiring is pinned by the evalgrad fixtures and by the layer-level tests at 1e-3."""
     fx = H.load_golden(fn)
@@ -48,7 +50,7 @@ def test_model_vs_reference_fixture(fn, device):
         out = model(x.to(device))
     want = torch.from_numpy(fx["logits"])
     err = H.rel_err(out, want)
-    ltol = max(TOL, 3 * float(fx["logits_noise"][0])) if mode == "train" else TOL
+    ltol = max(TOL, 1.5 * float(fx["logits_noise"][0])) if mode == "train" else TOL
     assert err < ltol, err
     if mode != "train":
         # label maps (reference thresholds logits at 0.5, train.py:144-145) and argmax: bit-exact away from ties
