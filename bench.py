@@ -105,7 +105,23 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
                                       ctypes.byref(saved), dx.data_ptr(), ctypes.byref(grads), ws.data_ptr(), ws_bytes,
                                       stream), "layer_bwd")
     torch.cuda.synchronize()
-    t_bwd = timed(lambda: ML.check(lib.medt_axial_core_bwd(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
+    # with the gates' gradients (the reference makes them trainable from epoch 10 on, train.py:169-171) ...
+    t_bwd_gates = timed(lambda: ML.check(lib.medt_axial_core_bwd(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(saved),
+                                                                 dy.data_ptr(), ws.data_ptr(), ws_bytes, stream), "core_bwd"))
+    # ... and without (requires_grad=False, axialnet.py:124-127: the state the timed training step is in): the same
+    # layer without gate parameters (AxialAttention: gates == 1 in forward and backward) runs the instruction stream of the
+    # frozen-gate step -- no gate-gradient accumulators in the sweep
+    plain = droplib.models.axialnet.AxialAttention(C, C, groups=8, kernel_size=L, stride=1, width=width).to(device)
+    plain.train()
+    cfg_ng = AxialConfig(8, 1 if width else 0, True, 1, plain.bn_qkv, plain.bn_similarity, plain.bn_output)
+    params_ng = _params(cfg_ng, plain.qkv_transform.weight, plain.relative, None, True)
+    ML.check(lib.medt_axial_layer_fwd(ctypes.byref(desc), ctypes.byref(params_ng), x.data_ptr(), y.data_ptr(),
+                                      ctypes.byref(saved), ws.data_ptr(), ws_bytes, stream), "layer_fwd")
+    ML.check(lib.medt_axial_layer_bwd(ctypes.byref(desc), ctypes.byref(params_ng), x.data_ptr(), None, dy.data_ptr(),
+                                      ctypes.byref(saved), dx.data_ptr(), ctypes.byref(grads), ws.data_ptr(), ws_bytes,
+                                      stream), "layer_bwd")
+    torch.cuda.synchronize()
+    t_bwd = timed(lambda: ML.check(lib.medt_axial_core_bwd(ctypes.byref(desc), ctypes.byref(params_ng), ctypes.byref(saved),
                                                            dy.data_ptr(), ws.data_ptr(), ws_bytes, stream), "core_bwd"))
     M = N * H * W
     bytes_main = 4 * C * e * M
@@ -135,7 +151,9 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
                                      else "attn_bwd_stats_kernel + attn_bwd_kernel"),
                          "bytes_per_launch": 10 * C * e * M,
                          "achieved": 10 * C * e * M / t_bwd / 1e9, "frac": 10 * C * e * M / t_bwd / 1e9 / HBM_PEAK_GBPS,
-                         "launch_ms": t_bwd * 1e3}}
+                         "launch_ms": t_bwd * 1e3, "gates": "frozen (as in the timed step)",
+                         "with_gate_gradients": {"launch_ms": t_bwd_gates * 1e3,
+                                                 "frac": 10 * C * e * M / t_bwd_gates / 1e9 / HBM_PEAK_GBPS}}}
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tf) and (C, L, images) == (16, 64, 256) and e == 4:
         try:

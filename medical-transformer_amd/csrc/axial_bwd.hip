@@ -630,6 +630,8 @@ struct FixArgs {
     int fparts, qb_rpg, qb_row0, apply;
 };
 
+constexpr int FIX_PPT = 4;
+
 template <int HQ>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
     constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), NR = HQ + NP;
@@ -637,10 +639,14 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
     const AxialGeom& g = a.g;
     const int grp = blockIdx.x / a.fparts, part = blockIdx.x - grp * a.fparts, hg = blockIdx.y;
     const int per_group = g.npg * g.HW;
-    const int qpos = part * MEDT_THREADS + threadIdx.x;
     float v[4 * HQ];
 #pragma unroll
     for (int k = 0; k < 4 * HQ; ++k) v[k] = 0.f;
+    // FIX_PPT positions per thread (a thread's positions are 256 apart: every load instruction stays coalesced, four
+    // independent chains of loads are in flight per lane)
+#pragma unroll
+    for (int pp = 0; pp < FIX_PPT; ++pp) {
+    const int qpos = (part * FIX_PPT + pp) * MEDT_THREADS + threadIdx.x;
     if (qpos < per_group) {
         const int ni = qpos / g.HW, pix = qpos - ni * g.HW, n = grp * g.npg + ni;
         const int h = pix / g.W, w = pix - h * g.W;
@@ -693,9 +699,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < GP; ++c) {
-            v[2 * c] = d[c];
-            v[2 * c + 1] = d[c] * ((raw[c] - a.qs.mean[cbase + c]) * a.qs.rstd[cbase + c]);
+            v[2 * c] += d[c];
+            v[2 * c + 1] = fmaf(d[c], (raw[c] - a.qs.mean[cbase + c]) * a.qs.rstd[cbase + c], v[2 * c + 1]);
         }
+    }
     }
     float* dst = a.part_qb + ((size_t)(grp * a.qb_rpg + a.qb_row0 + part) * 2 * g.C + hg * NCH) * 2;
     if (threadIdx.x < 2 * GP) dst[2 * GP + threadIdx.x] = 0.f;            // (the sweep's rows carry the v channels)
@@ -859,7 +866,7 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     int cap = env_cap / (g.groups * g.G);
     if (cap < 1) cap = 1;
     p->nparts = p->tiles < cap ? p->tiles : cap;
-    p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS);
+    p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS * FIX_PPT);
     const int hq = g.hq, np = hq * (hq + 1) / 2;
     p->npg_floats = 2 * (np + hq);
     if (g.gp == 2) p->lds = g.L == 32 ? sweep_lds_bytes<2, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<2, 64, 16>(nw) : sweep_lds_bytes<2, 128, 16>(nw));
