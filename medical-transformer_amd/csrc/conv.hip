@@ -551,11 +551,18 @@ static int wgrad_chunk(int Cout, int Ktot, long NP) {
     return QS;
 }
 
-// recorded (grouped) launches: ~32 position chunks per job, at most 64 partial slabs
+// recorded (grouped) launches: ~64 position chunks of at most 256 positions per job, at most 64 partial slabs.  A flush is
+// a few thousand workgroups over all its layers, so the launch's time is the serial latency of ONE workgroup's chunk
+// (~4 us per 64 positions): short chunks, many workgroups (measured on the MedT step: 32 chunks / 512 positions 2.54 ms,
+// 64 / 256: 2.49 ms, 128 slabs of 128: 2.53 ms -- the slab reduction starts to cost what the shorter chunks save)
 static int wgrad_chunk_grouped(long NP) {
+    static const int target = [] { const char* e = getenv("MEDT_WG_CHUNKS"); return e ? atoi(e) : 64; }();
+    static const int qmax = [] { const char* e = getenv("MEDT_WG_QMAX"); return e ? atoi(e) : 256; }();
     int QS = 64;
-    while (QS < 512 && (NP + QS - 1) / QS > 32) QS <<= 1;
-    while ((NP + QS - 1) / QS > 64) QS <<= 1;
+    while (QS < qmax && (NP + QS - 1) / QS > target) QS <<= 1;
+    static const int smax = [] { const char* e = getenv("MEDT_WG_SLABS"); return e ? atoi(e) : 64; }();
+    static const int smax_big = [] { const char* e = getenv("MEDT_WG_SLABS_BIG"); return e ? atoi(e) : 64; }();
+    while ((NP + QS - 1) / QS > (NP >= 65536 ? smax_big : smax)) QS <<= 1;
     return QS;
 }
 

@@ -13,6 +13,8 @@
 // MFMA fragment maps (cdna_hip_programming.md section 3): A: lane l = A[l&15][l>>4]; B: lane l = B[l>>4][l&15];
 // D: reg r of lane l = D[(l>>4)*4 + r][l&15].
 #include "defer.h"
+#include <algorithm>
+#include <vector>
 #include <stdlib.h>
 
 namespace medt {
@@ -476,16 +478,16 @@ template <int K>
 __device__ __forceinline__ void conv_wgrad_mfma_body(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
-    int stride, int pad, int QS, int npg, int bx, int by, int bz) {
+    int stride, int pad, int QS, int npg, int bx, int by, int bz, float (*A)[65], float (*B)[65]) {
     constexpr int KK = K * K;
-    __shared__ float A[64][65];
-    __shared__ float B[64][65];
     const int Ktot = Cin * KK, HoWo = Ho * Wo;
     const int o0 = bx * 64, k0 = by * 64;
     const long NP = (long)N * HoWo;
     const long q_begin = (long)bz * QS;
     const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave index as an SGPR: rows (o, k) are then wave-uniform, so their channel / tap decomposition, the bounds
+    // tests on them and the BatchNorm coefficient loads run on the scalar unit instead of once per lane
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane, r0 = wv;
     f32x4 acc[4];
 #pragma unroll
@@ -500,26 +502,39 @@ __device__ __forceinline__ void conv_wgrad_mfma_body(
         const int hb = ho * stride - pad, wb = wo * stride - pad;
         const float* dyp = dy + (size_t)n * Cout * HoWo + p;
         const float* rawp = raw ? raw + (size_t)n * Cout * HoWo + p : nullptr;
-        const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
-        const float* xp = x + (size_t)n * Cin * H * W;
+        const float* xp = x + (size_t)n * Cin * H * W + (long)hb * W + wb;
+        // BatchNorm group of the 64 positions: one group in all but the step that straddles a group boundary
+        const long qlast = q0 + 63 < q_end ? q0 + 63 : q_end - 1;
+        const int g_first = (int)(q0 / HoWo) / npg, g_last = (int)(qlast / HoWo) / npg;
+        const bool one_group = g_first == g_last;
+        const float* cfu = coef ? coef + (size_t)g_first * Cout * 3 : nullptr;
+        const float* cfl = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = r0 + 4 * i;
             float a = 0.f, b = 0.f;
             const int o = o0 + r, k = k0 + r;
-            if (qok && o < Cout) {
-                a = dyp[(size_t)o * HoWo];
-                if (cf) a = fmaf(cf[o * 3], a, fmaf(cf[o * 3 + 1], rawp[(size_t)o * HoWo], cf[o * 3 + 2]));
+            if (o < Cout) {
+                if (qok) a = dyp[(size_t)o * HoWo];
+                if (coef) {
+                    const float rw = qok ? rawp[(size_t)o * HoWo] : 0.f;
+                    if (one_group) a = fmaf(cfu[o * 3], a, fmaf(cfu[o * 3 + 1], rw, cfu[o * 3 + 2]));
+                    else a = fmaf(cfl[o * 3], a, fmaf(cfl[o * 3 + 1], rw, cfl[o * 3 + 2]));
+                    if (!qok) a = 0.f;
+                }
             }
-            if (qok && k < Ktot) {
+            if (k < Ktot) {
                 const int c = k / KK, t = k - c * KK;
-                const int h = hb + t / K, w = wb + t % K;
-                if (h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + h) * W + w];
+                const int dh = t / K, dw = t % K;
+                const int h = hb + dh, w = wb + dw;
+                if (qok && h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + dh) * W + dw];
             }
             ra[i] = a;
             rb[i] = b;
         }
     };
+    const bool wave_rows = o0 + 16 * wv < Cout;
+    const int tcols = Ktot - k0 >= 64 ? 4 : (Ktot - k0 + 15) / 16;
     if (q_begin < q_end) fetch(q_begin);
     for (long q0 = q_begin; q0 < q_end; q0 += 64) {
 #pragma unroll
@@ -529,13 +544,19 @@ __device__ __forceinline__ void conv_wgrad_mfma_body(
         }
         __syncthreads();
         if (q0 + 64 < q_end) fetch(q0 + 64);
+        // most recorded layers are narrower than the tile (Cout 16-32, Ktot 16-64): a wave whose 16 output rows lie
+        // beyond Cout has nothing to multiply, and 16-column blocks beyond Ktot are skipped (both wave-uniform)
+        if (wave_rows) {
 #pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const float a = A[16 * wv + (lane & 15)][ks * 4 + (lane >> 4)];
+            for (int ks = 0; ks < 16; ++ks) {
+                const float a = A[16 * wv + (lane & 15)][ks * 4 + (lane >> 4)];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float b = B[t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    if (t < tcols) {
+                        const float b = B[t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -555,51 +576,76 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
     int stride, int pad, int QS, int npg) {
+    __shared__ float A[64][65];
+    __shared__ float B[64][65];
     conv_wgrad_mfma_body<K>(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, blockIdx.x,
-                            blockIdx.y, blockIdx.z);
+                            blockIdx.y, blockIdx.z, A, B);
 }
 
-// The recorded weight gradients of many layers in one launch per kernel size (defer.h): 64 x 64 tiles on the matrix
-// cores for every layer -- a launch holds thousands of workgroups across the layers, so the per-layer tile sizing of the
-// immediate VALU kernel (which exists to give ONE layer enough workgroups) is not needed, and per FMA the MFMA tile
-// reads 16x fewer LDS bytes than the 4x4 register tile (profiles/r02_wgrad_ab.json).
-using WBatch = JobBatch<WJob, 36>;
-template <int K>
+// The recorded weight gradients of many layers -- all kernel sizes -- in ONE launch (defer.h): 64 x 64 tiles on the
+// matrix cores for every layer.  Per FMA the MFMA tile reads 16x fewer LDS bytes than the 4x4 register tile
+// (profiles/r02_wgrad_ab.json).  A flush holds 20-40 layers and 1-3 thousand workgroups; issued per kernel size the
+// launches ran back to back, most of them with fewer workgroups than the chip has slots (the 7x7 stem: 96), so their
+// time was the serial latency of one workgroup's position chunk three times over.  One launch overlaps them, and the
+// jobs are ordered longest chunk first so the long workgroups start first.
+struct WJobP {                       // WJob packed for the kernel-argument block (< 4 KB): 44 jobs per launch
+    const float *dy, *raw, *coef, *x;
+    float* scratch;
+    int N, Cin, H, W, Cout, Ho, Wo, QS, npg, gz;
+    unsigned char stride, pad, K, unused;
+};
+using WBatch = JobBatch<WJobP, 42>;
+static_assert(sizeof(WBatch) <= 4000, "job table must fit the kernel-argument block");
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(WBatch b) {
+    __shared__ float A[64][65];
+    __shared__ float B[64][65];
     const int j = find_job(b, blockIdx.x);
-    const WJob& w = b.job[j];
+    const WJobP& w = b.job[j];
     const int local = blockIdx.x - b.start[j];
-    const int bx = local % w.gx, t = local / w.gx, by = t % w.gy, bz = t / w.gy;
-    conv_wgrad_mfma_body<K>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride,
-                            w.pad, w.QS, w.npg, bx, by, bz);
+    const int gx = (w.Cout + 63) / 64, gy = (w.Cin * w.K * w.K + 63) / 64;
+    const int bx = local % gx, t = local / gx, by = t % gy, bz = t / gy;
+#define MEDT_WG_BODY(KV)                                                                                              \
+    conv_wgrad_mfma_body<KV>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, \
+                             w.pad, w.QS, w.npg, bx, by, bz, A, B)
+    if (w.K == 1) MEDT_WG_BODY(1);
+    else if (w.K == 3) MEDT_WG_BODY(3);
+    else MEDT_WG_BODY(7);
+#undef MEDT_WG_BODY
 }
 
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
     if (valu) return conv_wgrad_grouped_valu(jobs, n, s);            // A/B switch: the 4x4-register-tile VALU body
-    static const int KS[3] = {1, 3, 7};
-    for (int K : KS) {
-        WBatch b;
+    static const bool debug = getenv("MEDT_WG_DEBUG") != nullptr;
+    // longest workgroups first: steps of 64 positions per chunk, weighted by the taps a step gathers
+    std::vector<int> order(n);
+    for (int j = 0; j < n; ++j) order[j] = j;
+    auto cost = [&](int j) { return (long)((jobs[j].QS + 63) / 64) * (jobs[j].K == 1 ? 2 : 3); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    WBatch b;
+    b.n = 0;
+    int blocks = 0;
+    auto launch = [&]() -> int {
+        b.start[b.n] = blocks;
+        if (debug) fprintf(stderr, "wgrad grouped: %d jobs, %d blocks\n", b.n, blocks);
+        hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
         b.n = 0;
-        int blocks = 0;
-        auto launch = [&]() -> int {
-            b.start[b.n] = blocks;
-            if (K == 1) hipLaunchKernelGGL((conv_wgrad_mfma_grouped_kernel<1>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-            else if (K == 3) hipLaunchKernelGGL((conv_wgrad_mfma_grouped_kernel<3>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-            else hipLaunchKernelGGL((conv_wgrad_mfma_grouped_kernel<7>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-            b.n = 0;
-            blocks = 0;
-            return launch_status("conv_wgrad_mfma_grouped");
-        };
-        for (int j = 0; j < n; ++j) {
-            if (jobs[j].K != K) continue;
-            b.job[b.n] = jobs[j];
-            b.start[b.n] = blocks;
-            blocks += jobs[j].gx * jobs[j].gy * jobs[j].gz;
-            if (++b.n == 36) { int rc = launch(); if (rc) return rc; }
-        }
-        if (b.n) { int rc = launch(); if (rc) return rc; }
+        blocks = 0;
+        return launch_status("conv_wgrad_mfma_grouped");
+    };
+    for (int i = 0; i < n; ++i) {
+        const WJob& w = jobs[order[i]];
+        if (w.K != 1 && w.K != 3 && w.K != 7) { set_error("conv2d: kernel size %d unsupported (1, 3, 7)", w.K); return MEDT_EUNSUPPORTED; }
+        if (debug)
+            fprintf(stderr, "  wjob K%d Cout %d Cin %d HoWo %dx%d N %d QS %d grid %dx%dx%d\n", w.K, w.Cout, w.Cin, w.Ho, w.Wo,
+                    w.N, w.QS, w.gx, w.gy, w.gz);
+        b.job[b.n] = WJobP{w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.QS, w.npg, w.gz,
+                           (unsigned char)w.stride, (unsigned char)w.pad, (unsigned char)w.K, 0};
+        b.start[b.n] = blocks;
+        blocks += w.gx * w.gy * w.gz;
+        if (++b.n == 42) { int rc = launch(); if (rc) return rc; }
     }
+    if (b.n) { int rc = launch(); if (rc) return rc; }
     return MEDT_OK;
 }
 

@@ -145,7 +145,7 @@ class AxialAttentionFn(torch.autograd.Function):
         for k in range(8):
             if sizes[k] == 0:
                 continue
-            slot = ctx.slots[k]
+            slot = OPT.live(ctx.slots[k])
             if slot is not None and ctx.needs_input_grad[k + 1]:
                 dst[k], direct = OPT.claim(slot)
                 if not direct:
@@ -156,7 +156,7 @@ class AxialAttentionFn(torch.autograd.Function):
         gate_direct = False
         n_gate = f_qr.numel() if (ctx.has_gates and cfg.gate_mode == 2) else 4     # per-sequence gates: a (B*, 4) tensor
         if want_gates and cfg.gate_mode != 2:
-            gs = ctx.gate_slots
+            gs = tuple(OPT.live(g_) for g_ in ctx.gate_slots)
             if all(g_ is not None for g_ in gs) and all(ctx.needs_input_grad[9:13]) and \
                     all(gs[i + 1].view.data_ptr() == gs[i].view.data_ptr() + 4 for i in range(3)) and \
                     all(g_.stamp != g_.owner.stamp for g_ in gs):
@@ -171,7 +171,7 @@ class AxialAttentionFn(torch.autograd.Function):
                 if ctx.needs_input_grad[k + 1]:
                     ret[k] = part.view(shapes[k]) if shapes[k] is not None else part
         if want_gates:
-            gate_ptr = ctx.gate_slots[0].view.data_ptr() if gate_direct else parts[-1].data_ptr()
+            gate_ptr = gs[0].view.data_ptr() if gate_direct else parts[-1].data_ptr()
         else:
             gate_ptr = None
         dx = torch.empty_like(x)

@@ -124,14 +124,15 @@ class ConvBlockFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_dx else None
         # fan-in of the input's gradient (GradSink): add what the other consumers deposited in this dgrad's epilogue
         xs = cfg.x_sink if need_dx else None
-        dx_add = xs.take() if (xs is not None and w.shape[2] == 1) else None
+        dep = xs.take() if xs is not None else None
+        dx_add = dep if (dep is not None and w.shape[2] == 1) else None       # the dgrad epilogue add exists for 1x1 only
         present = (True, ctx.has_bias, has_bn, has_bn)
         shapes = (w.shape, (Cout,), (Cout,), (Cout,))
         dst, ret, pend = [None] * 4, [None] * 4, []
         for k in range(4):
             if not present[k]:
                 continue
-            slot = ctx.slots[k]
+            slot = OPT.live(ctx.slots[k])
             if slot is not None and ctx.needs_input_grad[k + 1]:
                 dst[k], direct = OPT.claim(slot)
                 if not direct:
@@ -154,6 +155,8 @@ class ConvBlockFn(torch.autograd.Function):
             q.hold(ws, x, dy, stats, dres, *dst)
         for slot, tmp in pend:
             OPT.accumulate(slot, tmp)
+        if dep is not None and dx_add is None:         # a wider consumer: the deposit is added explicitly, never dropped
+            dx.add_(dep)
         if xs is not None:
             if cfg.x_role == "final":
                 xs.closed = True

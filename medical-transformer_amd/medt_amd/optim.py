@@ -43,11 +43,21 @@ class GradSlot:
 
 
 def grad_slot(p):
-    """The live slot of parameter `p`, or None (not adopted by a FlatAdam / frozen / not a leaf)."""
+    """The slot of parameter `p` (looked up in forward), or None (not adopted by a FlatAdam / frozen / not a leaf)."""
     s = getattr(p, "_medt_gslot", None)
     if s is None or not p.requires_grad:
         return None
     return s
+
+
+def live(slot):
+    """The slot if its owner has a step open, else None (asked in backward).
+
+    Protocol: slots are written only between FlatAdam.zero_grad() and FlatAdam.pack_gradients() (the first thing
+    FlatAdam.step() does).  A backward outside that window -- torch.autograd.grad, model.zero_grad() followed by a
+    hand-written loop, a second optimizer -- gets None here, and its parameter gradients travel through autograd's
+    ordinary `.grad` accumulation exactly as they would without a FlatAdam."""
+    return slot if (slot is not None and slot.owner.step_open) else None
 
 
 def claim(slot: GradSlot):
@@ -97,12 +107,14 @@ class FlatAdam:
         self.groups: List[_Group] = []
         self._member = set()
         self.stamp = 0
+        self.step_open = False         # True between zero_grad() and pack_gradients(): see grad_slot
 
     # ---- gradient bookkeeping ------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
         """Start a new step: `.grad` of every parameter is reset to None, as torch.optim does.  The slot-aware backward
         kernels write into the slots; pack_gradients() then points `.grad` back at them."""
         self.stamp += 1
+        self.step_open = True
         for p in self.params:
             p.grad = None
 
@@ -122,6 +134,7 @@ class FlatAdam:
         parameters that received their first gradient are adopted into a new group; gradients that arrived through
         plain autograd (a module that is not slot-aware) are copied into their slot."""
         self._adopt_new()
+        self.step_open = False
         for g in self.groups:
             src, dst = [], []
             for p in g.params:
@@ -136,7 +149,10 @@ class FlatAdam:
                 elif p.requires_grad:
                     raise L.MedtError("FlatAdam: a parameter that used to receive gradients did not this step")
                 else:
-                    s.view.zero_()
+                    # torch.optim.Adam skips a parameter without a gradient entirely (no decay, no momentum step); the
+                    # single flat kernel cannot skip a range, and the reference never freezes a trained parameter
+                    # (train.py:169-171 only ever unfreezes the gates)
+                    raise L.MedtError("FlatAdam: a parameter was frozen after it had been trained; rebuild the optimizer")
                 p.grad = s.view
             if src:
                 torch._foreach_copy_(dst, src)

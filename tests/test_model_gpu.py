@@ -200,39 +200,57 @@ def test_baseline_batch_sizes_evalgrad_vs_oracle(name, S, N, bf16, device):
 def test_training_trajectory_vs_oracle(device):
     """Three optimisation steps of the reference's loop (train.py:140,156-161: forward, LogNLLLoss, backward, Adam with
     lr 1e-3 / weight_decay 1e-5) through the hipGraph-replayed product step against the fp64 oracle driving
-    oracle.adam_step: the loss of every step and the BatchNorm running statistics after the last one.  (Weights are not
-    compared element-wise: Adam turns the rounding noise of a near-zero gradient into a +-lr step.)"""
+    oracle.adam_step: the loss of every step -- measured in units of what float32 oracle runs of the same loop deviate by
+    -- and the BatchNorm running statistics after the last one.  (Weights are not compared element-wise: Adam turns the
+    rounding noise of a near-zero gradient into a +-lr step.)"""
     import medt_amd
     from medt_amd.optim import FlatAdam
     from medt_amd.trainer import TrainStep
     name, S, N, STEPS = "gatedaxialunet", 64, 2, 3
+    torch.manual_seed(80)                                    # the factory's own initialisation, reproducibly
     model = build(name, S, device)
     model.train()
-    st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}        # the factory's own initialisation
+    st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     x, y = H.seeded_input(81, N, 3, S)
     opt = FlatAdam(list(model.parameters()), lr=1e-3, weight_decay=1e-5)
     step = TrainStep(model, opt, medt_amd.cross_entropy, use_graph=True, warmup=2)
     losses = [step(x.to(device), y.to(device)).item() for _ in range(STEPS)]
-    # oracle: same loop in float64; parameters that receive a gradient are updated, the frozen gates are not
-    ost = O.clone_state(st, torch.float64)
     train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
-    mom = {}
-    want = []
-    for t in range(1, STEPS + 1):
-        leaf = {k: (v.clone().requires_grad_(True) if k in train_keys else v) for k, v in ost.items()}
-        out = O.forward(name, x.double(), leaf, True)
-        loss = O.log_nll_loss(out, y)
-        loss.backward()
-        want.append(loss.item())
-        for k in ost:
-            if k in train_keys and leaf[k].grad is not None:
-                m, v = mom.get(k, (torch.zeros_like(ost[k]), torch.zeros_like(ost[k])))
-                pnew, m, v = O.adam_step(ost[k], leaf[k].grad, m, v, t)
-                ost[k], mom[k] = pnew.detach(), (m, v)
-            else:
-                ost[k] = leaf[k].detach()                    # buffers (running statistics) as updated by the forward
-    for a, b in zip(losses, want):
-        assert abs(a - b) <= 2e-3 * abs(b), (losses, want)
+
+    def oracle_run(dtype, ulp_seed=None):
+        """The same loop on the CPU oracle; parameters that receive a gradient are updated, the frozen gates are not.
+        ulp_seed: the initial weights and the input moved by one float32 ulp in random directions first."""
+        ost, xin = O.clone_state(st, dtype), x.to(dtype)
+        if ulp_seed is not None:
+            g = torch.Generator().manual_seed(ulp_seed)
+            nudge = lambda t: torch.nextafter(t, torch.where(torch.rand(t.shape, generator=g) < 0.5, -1.0, 1.0) * float("inf"))
+            ost = {k: (nudge(v) if (v.is_floating_point() and k in train_keys) else v) for k, v in ost.items()}
+            xin = nudge(xin)
+        mom, out_losses = {}, []
+        for t in range(1, STEPS + 1):
+            leaf = {k: (v.clone().requires_grad_(True) if k in train_keys else v) for k, v in ost.items()}
+            loss = O.log_nll_loss(O.forward(name, xin, leaf, True), y)
+            loss.backward()
+            out_losses.append(loss.item())
+            for k in ost:
+                if k in train_keys and leaf[k].grad is not None:
+                    m, v = mom.get(k, (torch.zeros_like(ost[k]), torch.zeros_like(ost[k])))
+                    pnew, m, v = O.adam_step(ost[k], leaf[k].grad, m, v, t)
+                    ost[k], mom[k] = pnew.detach(), (m, v)
+                else:
+                    ost[k] = leaf[k].detach()                    # buffers (running statistics) as updated by the forward
+        return out_losses, ost
+
+    want, ost = oracle_run(torch.float64)
+    # Adam turns the rounding noise of every near-zero gradient into a +-lr step, so from the second step on the loss of
+    # ANY float32 run leaves the float64 trajectory by far more than float32 rounding.  The yardstick is therefore the
+    # reference's own arithmetic: three float32 oracle trajectories (as is, and from 1-ulp-perturbed starts).
+    f32_runs = [oracle_run(torch.float32, sd_)[0] for sd_ in (None, 811, 812)]
+    for t, (a, b) in enumerate(zip(losses, want)):
+        noise = max(abs(r[t] - b) for r in f32_runs)
+        assert abs(a - b) <= 2.0 * noise + 2e-6 * abs(b), (t, losses, want, f32_runs)
+        assert abs(a - b) <= 1e-2 * abs(b), (t, losses, want)          # and never more than a percent
+    print(f"trajectory: product {losses} | f64 oracle {want} | f32 oracle runs {f32_runs}")
     sd = model.state_dict()
     # (shallow layers only: the deep ones normalise over 32-value populations whose statistics follow every rounding)
     for k in ("bn1.running_mean", "bn2.running_var", "layer1.0.hight_block.bn_similarity.running_var",
@@ -241,7 +259,6 @@ def test_training_trajectory_vs_oracle(device):
         #  3.2e-2 observed on bn1.running_mean in 1 of ~10 runs; a wrong momentum or count is a > 10 % error)
         assert H.rel_err(sd[k], ost[k]) < 8e-2, k
     assert int(sd["bn1.num_batches_tracked"].item()) == STEPS
-    print(f"trajectory: product losses {losses} vs oracle {want}")
 
 
 def test_graphed_train_step_equals_eager(device):
@@ -424,6 +441,24 @@ def test_flat_adam_slots_are_written_directly(device):
             assert lo <= p.grad.data_ptr() < hi, k
             # (bit-equal except where LDS float atomics decide the summation order: the relative tables)
             assert H.rel_err(p.grad, want[k]) < 1e-5, k
+    # outside the zero_grad() .. pack_gradients() window the slots are not touched: a second backward accumulates into
+    # `.grad` the way plain autograd does (here: doubles it), instead of silently overwriting or double counting
+    medt_amd.cross_entropy(model(x), y).backward()
+    for k, p in model.named_parameters():
+        if k in want:
+            assert H.rel_err(p.grad, 2 * want[k]) < 1e-5, k
+    # torch.autograd.grad works too and leaves the buckets alone
+    before = flat.clone()
+    w0 = next(model.parameters())
+    (g0,) = torch.autograd.grad(medt_amd.cross_entropy(model(x), y), [w0])
+    assert torch.equal(flat, before)
+    assert H.rel_err(g0, want[next(iter(want))]) < 1e-5
+    # freezing a parameter that has been trained is refused (torch.optim.Adam would skip it; the flat kernel cannot)
+    opt.zero_grad()
+    w0.requires_grad_(False)
+    medt_amd.cross_entropy(model(x), y).backward()
+    with pytest.raises(medt_amd.MedtError):
+        opt.pack_gradients()
 
 
 def test_medt_256_train_vs_oracle(device):

@@ -272,3 +272,29 @@ def test_single_value_training_batchnorm_is_refused(device):
     with pytest.raises(medt_amd.MedtError):
         ops.conv_block(torch.randn(1, 3, 1, 1, device=device), conv, bn, training=True)
     ops.conv_block(torch.randn(1, 3, 1, 1, device=device), conv, bn, training=False)      # eval: fine
+
+
+@pytest.mark.parametrize("k_final", [1, 3])
+def test_gradient_fan_in_through_sink(k_final, device):
+    """Two consumers of one tensor share a GradSink (medt_amd.ops): the later-created one deposits its input gradient,
+    the earlier-created one adds it -- in the epilogue of its dgrad kernel when it is 1x1, with an explicit add when it
+    is wider -- and returns the sum.  Either way the tensor's gradient equals autograd's plain sum."""
+    from medt_amd import ops
+    torch.manual_seed(5)
+    a = nn.Conv2d(8, 12, k_final, padding=k_final // 2, bias=True).to(device)
+    b = nn.Conv2d(8, 6, 1, bias=True).to(device)
+    x0 = torch.randn(2, 8, 16, 16, device=device)
+    ga, gb = torch.randn(2, 12, 16, 16, device=device), torch.randn(2, 6, 16, 16, device=device)
+
+    def run(shared):
+        x = (x0 * 1.0).requires_grad_(True)                  # a non-leaf producer output, like a layer's x1..x3
+        x.retain_grad()
+        s = ops.sink_of(x) if shared else None
+        ya = ops.conv_block(x, a, x_sink=s, x_role="final" if shared else None)
+        yb = ops.conv_block(x, b, x_sink=s, x_role="deposit" if shared else None)
+        ((ya * ga).sum() + (yb * gb).sum()).backward()
+        if shared:
+            assert s.pending is None                          # nothing stranded
+        return x.grad.clone()
+
+    _cmp(run(True), run(False), 1e-6, "fan-in")
