@@ -344,6 +344,102 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_small_kernel(SmallBnB
     }
 }
 
+// The same for any convolution whose BatchNorm population fits one workgroup's registers: one WORKGROUP per (group,
+// channel), 16 values per thread read once (float4), the two sums reduced over the block, dz written from registers.
+// Replaces bn_act_bwd_stats -> bn_bwd_finalize -> bn_bwd_apply (three dependent launches of ~5 us each, whatever the
+// tensor size) on the layer chain; the parameter gradients are produced off the chain by the recorded finalisation.
+template <int TT>
+__global__ __launch_bounds__(TT) void bn_act_bwd_chan_kernel(SmallBnBwdArgs a) {
+    __shared__ float red[2 * (TT / 64)];
+    const int grp = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int HW = a.HW, P = a.npg * HW, gc = grp * a.C + c;
+    const float mean = a.st.mean[gc], rstd = a.st.rstd[gc];
+    float4 dv[4], zv[4];
+    size_t at[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 4 * (tid + k * TT);
+        dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        zv[k] = dv[k];
+        at[k] = 0;
+        if (q < P) {
+            const int ni = q / HW, p = q - ni * HW;                 // HW % 4 == 0: the four values share a plane
+            const size_t idx = ((size_t)(grp * a.npg + ni) * a.C + c) * HW + p;
+            at[k] = idx;
+            float4 d = *reinterpret_cast<const float4*>(a.dy + idx);
+            if (a.relu) {
+                const float4 yv = *reinterpret_cast<const float4*>(a.y + idx);
+                if (!(yv.x > 0.f)) d.x = 0.f;
+                if (!(yv.y > 0.f)) d.y = 0.f;
+                if (!(yv.z > 0.f)) d.z = 0.f;
+                if (!(yv.w > 0.f)) d.w = 0.f;
+            }
+            if (a.g) *reinterpret_cast<float4*>(a.g + idx) = d;
+            const float4 zz = *reinterpret_cast<const float4*>(a.z + idx);
+            dv[k] = d;
+            zv[k] = zz;
+            s1 += (d.x + d.y) + (d.z + d.w);
+            s2 = fmaf(d.x, (zz.x - mean) * rstd, s2);
+            s2 = fmaf(d.y, (zz.y - mean) * rstd, s2);
+            s2 = fmaf(d.z, (zz.z - mean) * rstd, s2);
+            s2 = fmaf(d.w, (zz.w - mean) * rstd, s2);
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s1; red[(tid >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    s1 = 0.f;
+    s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < TT / 64; ++w) { s1 += red[w * 2]; s2 += red[w * 2 + 1]; }       // fixed order, every thread
+    if (tid == 0) {
+        a.partials[(size_t)gc * 2] = s1;
+        a.partials[(size_t)gc * 2 + 1] = s2;
+    }
+    // same arithmetic as bn_bwd_coef (pointwise.hip), dscale = 1
+    const double A = (double)a.weight[c] * (double)rstd;
+    float c0 = (float)A, c1 = 0.f, c2 = 0.f;
+    if (a.training) {
+        const double m1 = (double)s1 / (double)P, m2 = (double)s2 / (double)P;
+        c1 = (float)(-A * (double)rstd * m2);
+        c2 = (float)(A * ((double)rstd * (double)mean * m2 - m1));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 4 * (tid + k * TT);
+        if (q < P) {
+            float4 o;
+            o.x = fmaf(c0, dv[k].x, fmaf(c1, zv[k].x, c2));
+            o.y = fmaf(c0, dv[k].y, fmaf(c1, zv[k].y, c2));
+            o.z = fmaf(c0, dv[k].z, fmaf(c1, zv[k].z, c2));
+            o.w = fmaf(c0, dv[k].w, fmaf(c1, zv[k].w, c2));
+            *reinterpret_cast<float4*>(a.dz + at[k]) = o;
+        }
+    }
+}
+
+// one workgroup of 256 (population <= 4096) or 1024 threads (<= 16384) per (group, channel); 0: not applicable
+int bn_chan_threads(const medt_conv_desc& d, int HoWo) {
+    static const int pmax = [] { const char* e = getenv("MEDT_BN_CHAN_MAX"); return e ? atoi(e) : 16384; }();
+    if (!d.has_bn || (HoWo & 3)) return 0;
+    const long P = (long)(d.N / d.bn_groups) * HoWo;
+    if (P > pmax || P > 16384) return 0;
+    return P <= 4096 ? 256 : 1024;
+}
+
+int bn_act_bwd_chan(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
+                    const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s) {
+    SmallBnBwdArgs a;
+    a.dy = dy; a.y = y; a.z = z; a.weight = weight; a.st = st; a.g = g; a.dz = dz; a.partials = partials;
+    a.C = d.Cout; a.HW = HoWo; a.npg = d.N / d.bn_groups; a.relu = d.relu; a.training = d.training ? 1 : 0;
+    const dim3 grid(d.bn_groups, d.Cout);
+    if (bn_chan_threads(d, HoWo) == 256) hipLaunchKernelGGL(bn_act_bwd_chan_kernel<256>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(bn_act_bwd_chan_kernel<1024>, grid, dim3(1024), 0, s, a);
+    return launch_status("bn_act_bwd_chan");
+}
+
 int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
                      const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s) {
     SmallBnBwdArgs a;

@@ -35,6 +35,104 @@ int bn_apply_act(const float* z, BnStats st, const float* res, float* y, int N, 
     return launch_status("bn_apply_act");
 }
 
+// bn_finalize + bn_apply_act in one launch: every workgroup re-derives the statistics of ITS (group, channel) from the
+// convolution's partial sums (ppg pairs of doubles: one round trip) and then normalises its slice of that population;
+// part 0 saves mean / rstd / scale / shift for backward.  What is left of the finalisation -- the running-statistics
+// recurrence over the groups -- is off the layer chain (recorded, or issued right behind when no queue is bound).
+struct BnFinApplyArgs {
+    const float *z, *partials, *weight, *bias, *running_mean, *running_var, *res;
+    float* y;
+    BnStats st;
+    int C, HW, npg, ppg, parts, relu, training;
+    double count;
+    float eps;
+};
+constexpr int BFA_PER_THREAD = 16;
+__global__ __launch_bounds__(MEDT_THREADS) void bn_fin_apply_kernel(BnFinApplyArgs a) {
+    __shared__ double redd[2 * MEDT_WAVES];
+    const int grp = blockIdx.x / a.parts, part = blockIdx.x - grp * a.parts, c = blockIdx.y, tid = threadIdx.x;
+    const int gc = grp * a.C + c;
+    const float gam = a.weight[c], bet = a.bias[c];
+    float mean_f, rstd_f, scale, shift;
+    if (a.training) {
+        const double* pd = reinterpret_cast<const double*>(a.partials);
+        double s = 0.0, ss = 0.0;
+        for (int p = tid; p < a.ppg; p += MEDT_THREADS) {
+            const double* q = pd + ((size_t)(grp * a.ppg + p) * a.C + c) * 2;
+            s += q[0];
+            ss += q[1];
+        }
+        s = wave_sum_d(s);
+        ss = wave_sum_d(ss);
+        if ((tid & 63) == 0) { redd[(tid >> 6) * 2] = s; redd[(tid >> 6) * 2 + 1] = ss; }
+        __syncthreads();
+        s = 0.0;
+        ss = 0.0;
+#pragma unroll
+        for (int w = 0; w < MEDT_WAVES; ++w) { s += redd[w * 2]; ss += redd[w * 2 + 1]; }
+        const double mean = s / a.count;
+        double var = ss / a.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)a.eps);
+        mean_f = (float)mean;
+        rstd_f = (float)rstd;
+        scale = (float)(gam * rstd);
+        shift = (float)(bet - mean * gam * rstd);
+    } else {
+        mean_f = a.running_mean[c];
+        rstd_f = (float)(1.0 / sqrt((double)a.running_var[c] + (double)a.eps));
+        scale = gam * rstd_f;
+        shift = bet - mean_f * gam * rstd_f;
+    }
+    if (part == 0 && tid == 0) {
+        a.st.mean[gc] = mean_f;
+        a.st.rstd[gc] = rstd_f;
+        a.st.scale[gc] = scale;
+        a.st.shift[gc] = shift;
+    }
+    const int HW = a.HW, P = a.npg * HW;
+    const int q0 = part * (MEDT_THREADS * BFA_PER_THREAD);
+    const int q1 = q0 + MEDT_THREADS * BFA_PER_THREAD < P ? q0 + MEDT_THREADS * BFA_PER_THREAD : P;
+    if ((HW & 3) == 0) {
+        for (int q = q0 + 4 * tid; q < q1; q += 4 * MEDT_THREADS) {
+            const int ni = q / HW, p = q - ni * HW;
+            const size_t idx = ((size_t)(grp * a.npg + ni) * a.C + c) * HW + p;
+            const float4 zz = *reinterpret_cast<const float4*>(a.z + idx);
+            float4 v;
+            v.x = fmaf(zz.x, scale, shift);
+            v.y = fmaf(zz.y, scale, shift);
+            v.z = fmaf(zz.z, scale, shift);
+            v.w = fmaf(zz.w, scale, shift);
+            if (a.res) {
+                const float4 r = *reinterpret_cast<const float4*>(a.res + idx);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(a.y + idx) = v;
+        }
+    } else {
+        for (int q = q0 + tid; q < q1; q += MEDT_THREADS) {
+            const int ni = q / HW, p = q - ni * HW;
+            const size_t idx = ((size_t)(grp * a.npg + ni) * a.C + c) * HW + p;
+            float v = fmaf(a.z[idx], scale, shift);
+            if (a.res) v += a.res[idx];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.y[idx] = v;
+        }
+    }
+}
+
+int bn_fin_apply(const float* z, const float* partials, int ppg, double count, const medt_bn_ptrs& bn, float eps, int training,
+                 BnStats st, const float* res, float* y, int N, int C, int HW, int groups, int relu, hipStream_t s) {
+    BnFinApplyArgs a;
+    a.z = z; a.partials = partials; a.weight = bn.weight; a.bias = bn.bias; a.running_mean = bn.running_mean;
+    a.running_var = bn.running_var; a.res = res; a.y = y; a.st = st; a.C = C; a.HW = HW; a.npg = N / groups; a.ppg = ppg;
+    a.parts = cdiv(a.npg * HW, MEDT_THREADS * BFA_PER_THREAD); a.relu = relu; a.training = training; a.count = count;
+    a.eps = eps;
+    hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(groups * a.parts, C), dim3(MEDT_THREADS), 0, s, a);
+    return launch_status("bn_fin_apply");
+}
+
 // g = dy * (y > 0 if relu) ; partials[group][part][C][2] = [sum g, sum g*zhat]     grid (groups*ppg, C),
 // lanes over the flattened (image, pixel) positions of one group and one channel
 __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_stats_kernel(const float* __restrict__ dy,

@@ -471,9 +471,21 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
     }
     if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, cw.ksplit_fwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
                          d->stride, d->pad, 0, d->bn_groups, s))) return rc;
-    if ((rc = bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout,
-                          (double)(d->N / d->bn_groups) * g.HoWo, *bn, d->momentum, d->eps, tr, st, s))) return rc;
-    return bn_apply_act(z, st, d->has_res ? res : nullptr, y, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s);
+    static const bool fused_fin = [] { const char* e = getenv("MEDT_BN_FIN_APPLY"); return !(e && e[0] == '0'); }();
+    const double count = (double)(d->N / d->bn_groups) * g.HoWo;
+    if (!fused_fin) {
+        if ((rc = bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout, count, *bn, d->momentum, d->eps, tr, st, s))) return rc;
+        return bn_apply_act(z, st, d->has_res ? res : nullptr, y, d->N, d->Cout, g.HoWo, d->bn_groups, d->relu, s);
+    }
+    // statistics + normalise / residual / ReLU in one launch; the running statistics follow off the layer chain
+    if ((rc = bn_fin_apply(z, cw.partials, g.ppg, count, *bn, d->eps, tr, st, d->has_res ? res : nullptr, y, d->N, d->Cout,
+                           g.HoWo, d->bn_groups, d->relu, s))) return rc;
+    if (!tr) return MEDT_OK;
+    if (Queue* q = queue_for(s)) {
+        q->fin.push_back(FinJob{make_fin(cw.partials, g.ppg, d->Cout, count, *bn, st), d->bn_groups, 2, d->momentum, d->eps});
+        return MEDT_OK;
+    }
+    return bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout, count, *bn, d->momentum, d->eps, 2, st, s);
 }
 
 int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w, const medt_bn_ptrs* bn, const float* z,
@@ -493,11 +505,17 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     if (d->has_bn) {
         BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
         float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
-        if (conv_small_ok(*d)) {
-            // one wave per (group, channel): mask, sums, coefficients and dz in one kernel; the finalisation only
-            // produces the parameter gradients (one partial slot per group)
-            if ((rc = bn_act_bwd_small(*d, dy, y, z, st, bn->weight, (d->has_res && dres) ? dres : nullptr, cw.dz,
-                                       cw.partials, g.HoWo, s))) return rc;
+        const bool small = conv_small_ok(*d);
+        if (small || bn_chan_threads(*d, g.HoWo)) {
+            // one wave (small blocks) or one workgroup per (group, channel): mask, sums, coefficients and dz in one
+            // kernel; the finalisation only produces the parameter gradients (one partial slot per group)
+            if (small)
+                rc = bn_act_bwd_small(*d, dy, y, z, st, bn->weight, (d->has_res && dres) ? dres : nullptr, cw.dz,
+                                      cw.partials, g.HoWo, s);
+            else
+                rc = bn_act_bwd_chan(*d, dy, y, z, st, bn->weight, (d->has_res && dres) ? dres : nullptr, cw.dz,
+                                     cw.partials, g.HoWo, s);
+            if (rc) return rc;
             // (only the BatchNorm parameter gradients come out of this one: dz is already final)
             if (Queue* q = queue_for(s))
                 q->bfin.push_back(BfinJob{cw.partials, 1, d->bn_groups, d->Cout, d->training ? 1 : 0,

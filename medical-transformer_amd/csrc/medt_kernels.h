@@ -157,6 +157,11 @@ int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, cons
 int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
                      const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s);
 // axial_small.hip: a whole position-free layer per (BN group, head) workgroup
+int bn_fin_apply(const float* z, const float* partials, int ppg, double count, const medt_bn_ptrs& bn, float eps, int training,
+                 BnStats st, const float* res, float* y, int N, int C, int HW, int groups, int relu, hipStream_t s);
+int bn_chan_threads(const medt_conv_desc& d, int HoWo);       // conv_small.hip: one workgroup per (group, channel); 0 = no
+int bn_act_bwd_chan(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
+                    const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s);
 bool wopos_small_ok(const AxialGeom& g, const medt_axial_desc& d);
 int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* x, float* y,
                     float* qkv_raw, float* stacked, float* lse, float* part_q, float* part_s, float* part_o,

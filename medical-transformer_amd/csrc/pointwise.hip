@@ -358,6 +358,9 @@ __device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict
         }
         return;
     }
+    // training == 2: the statistics were saved by the kernel that applied them (bn_fin_apply); only the running
+    // statistics and the batch counter are left to do
+    const bool save = training != 2;
     double rm = running_mean ? (double)running_mean[ch] : 0.0, rv = running_var ? (double)running_var[ch] : 0.0;
     double sums[2];
     const int which[2] = {0, 1};
@@ -366,7 +369,7 @@ __device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict
         double var = sums[1] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
-        if (lane < groups) {
+        if (lane < groups && save) {
             out.mean[lane * CH + ch]  = (float)mean;
             out.rstd[lane * CH + ch]  = (float)rstd;
             out.scale[lane * CH + ch] = (float)(g * rstd);
@@ -391,7 +394,7 @@ __device__ __forceinline__ void bn_finalize_body(int ch, const float* __restrict
             double var = ss / count - mean * mean;
             if (var < 0.0) var = 0.0;
             const double rstd = 1.0 / sqrt(var + (double)eps);
-            if (lane == 0) {
+            if (lane == 0 && save) {
                 out.mean[grp * CH + ch]  = (float)mean;
                 out.rstd[grp * CH + ch]  = (float)rstd;
                 out.scale[grp * CH + ch] = (float)(g * rstd);
