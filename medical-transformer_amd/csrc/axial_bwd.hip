@@ -30,6 +30,7 @@
 // Per (i, j) pair that is 18 FMAs + 1 exp2 (gp = 2) against ~7 instructions of per-row bookkeeping amortised over D pairs.
 #include "axial_tiles.h"
 #include "sim_tables.h"
+#include "defer.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -713,25 +714,17 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
 // The u / w terms of the relative-table gradient and the gate gradients, one workgroup per (BN group, head):
 // written as one extra row per workgroup of the partial slabs the (deferred) row reductions sum.
 // --------------------------------------------------------------------------- //
-struct RelfixArgs {
-    AxialGeom g;
-    const float *relative, *sim_coef, *pg_part, *gate_raw;
-    BnStats ss;
-    GatePtrs gates;
-    float *rel_rows, *gate_rows;   // [groups * G][2gp * TL], [groups * G][4]
-    int nparts, sweep_gridx, training;
-    float eps;
-};
+using RelfixArgs = RelfixJob;       // defer.h: the same record is what a bound queue stores until the flush
 
 constexpr int RELFIX_THREADS = 1024, RELFIX_SLICES = 4;      // the partial rows are summed by 4 slices of 256 threads
 
 template <int HQ>
-__global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixArgs a) {
+__device__ __forceinline__ void relfix_body(const RelfixArgs& a, const int blk, float* pgs, double (*gred)[4]) {
     constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), MEDT_RT = RELFIX_THREADS;
-    extern __shared__ float pgs[];                              // [L][NPG], then [RELFIX_SLICES - 1][L][NPG] slice sums
-    const AxialGeom& g = a.g;
+    // pgs: [L][NPG], then [RELFIX_SLICES - 1][L][NPG] slice sums
+    const struct { int L, G, SC; double sim_count; } g = {a.L, a.G, a.SC, a.sim_count};
     const int L = g.L, TL = 2 * L - 1;
-    const int grp = blockIdx.x / g.G, hg = blockIdx.x - grp * g.G;
+    const int grp = blk / g.G, hg = blk - grp * g.G;
     const size_t blk0 = (size_t)hg * a.sweep_gridx + (size_t)grp * a.nparts;
     {   // per-position Gram sums of this (group, head): slice q sums the parts [q * per, (q + 1) * per), eight loads in
         // flight, then the slices are added in fixed order
@@ -756,7 +749,6 @@ __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixA
         for (int e = threadIdx.x; e < L * NPG; e += MEDT_RT)
             pgs[e] = (pgs[e] + pgs[L * NPG + e]) + (pgs[2 * L * NPG + e] + pgs[3 * L * NPG + e]);
     }
-    __shared__ double gred[MEDT_RT / 64][4];
     double graw[4] = {0.0, 0.0, 0.0, 0.0};
     if (a.gate_rows) {                                        // gate sums of this (group, head): parts over the threads
         for (int p = threadIdx.x; p < a.nparts; p += MEDT_RT) {
@@ -775,7 +767,7 @@ __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixA
     const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr);
     const float* cr = a.sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
     const float* ck = a.sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
-    float* out = a.rel_rows + (size_t)blockIdx.x * NCH * TL;
+    float* out = a.rel_rows + (size_t)blk * NCH * TL;
     for (int e = threadIdx.x; e < NCH * TL; e += MEDT_RT) {
         const int r = e / TL, d = e - r * TL;
         float res = 0.f;
@@ -818,9 +810,28 @@ __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixA
             if (f_qr != 0.f) gq += ((double)cr[1] * s2q + (double)cr[2] * s1q) / f_qr;
             if (f_kr != 0.f) gk += ((double)ck[1] * s2k + (double)ck[2] * s1k) / f_kr;
         }
-        float* go = a.gate_rows + (size_t)blockIdx.x * 4;
+        float* go = a.gate_rows + (size_t)blk * 4;
         go[0] = (float)gq; go[1] = (float)gk; go[2] = (float)pe; go[3] = (float)pv;
     }
+}
+
+template <int HQ>
+__global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixArgs a) {
+    extern __shared__ float pgs[];
+    __shared__ double gred[RELFIX_THREADS / 64][4];
+    relfix_body<HQ>(a, blockIdx.x, pgs, gred);
+}
+
+// the recorded relfix jobs of many layers in one launch (defer.h)
+using RelfixBatch = JobBatch<RelfixJob, 16>;
+static_assert(sizeof(RelfixBatch) <= 4000, "job table must fit the kernel-argument block");
+__global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_grouped_kernel(RelfixBatch b) {
+    extern __shared__ float pgs[];
+    __shared__ double gred[RELFIX_THREADS / 64][4];
+    const int j = find_job(b, blockIdx.x);
+    const RelfixJob& a = b.job[j];
+    if (a.hq == 1) relfix_body<1>(a, blockIdx.x - b.start[j], pgs, gred);
+    else relfix_body<2>(a, blockIdx.x - b.start[j], pgs, gred);
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void bwd_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
@@ -922,16 +933,42 @@ int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_
 
 int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* relative, const float* sim_coef, BnStats sim,
                           GatePtrs gates, const float* pg_part, const float* gate_raw, int training, float eps,
-                          float* rel_rows, float* gate_rows, hipStream_t s) {
+                          float* rel_rows, float* gate_rows, hipStream_t s, Queue* q) {
     RelfixArgs a;
-    a.g = g; a.relative = relative; a.sim_coef = sim_coef; a.pg_part = pg_part; a.gate_raw = gate_raw; a.ss = sim;
+    a.relative = relative; a.sim_coef = sim_coef; a.pg_part = pg_part; a.gate_raw = gate_raw; a.ss = sim;
     a.gates = gates; a.rel_rows = rel_rows; a.gate_rows = gate_raw ? gate_rows : nullptr; a.nparts = p.nparts;
     a.sweep_gridx = g.groups * p.nparts; a.training = training; a.eps = eps;
-    const size_t lds = (size_t)RELFIX_SLICES * g.L * p.npg_floats * sizeof(float);
-    const dim3 grid(g.groups * g.G), block(RELFIX_THREADS);
-    if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, lds, s, a);
+    a.L = g.L; a.G = g.G; a.SC = g.SC; a.hq = g.hq; a.sim_count = g.sim_count; a.blocks = g.groups * g.G;
+    a.lds = (unsigned)((size_t)RELFIX_SLICES * g.L * p.npg_floats * sizeof(float));
+    // only the (recorded) row reductions read what this writes: with a queue bound it leaves the layer chain
+    // (measured on the MedT step: recording it lengthens the flush tail by more than it shortens the chain, 2.422 vs
+    //  2.412 ms -- on the chain it runs under the other branch's kernels -- so it is off unless MEDT_DEFER_RELFIX=1)
+    static const bool defer_on = [] { const char* e = getenv("MEDT_DEFER_RELFIX"); return e && e[0] == '1'; }();
+    if (q && defer_on) { q->relfix.push_back(a); return MEDT_OK; }
+    const dim3 grid(a.blocks), block(RELFIX_THREADS);
+    if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, a.lds, s, a);
+    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, a.lds, s, a);
     return launch_status("attn_bwd_relfix_kernel");
+}
+
+int axial_attn_bwd_relfix_grouped(const RelfixJob* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        RelfixBatch b;
+        b.n = n - i0 < 16 ? n - i0 : 16;
+        int blocks = 0;
+        unsigned lds = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.job[i] = jobs[i0 + i];
+            b.start[i] = blocks;
+            blocks += jobs[i0 + i].blocks;
+            if (jobs[i0 + i].lds > lds) lds = jobs[i0 + i].lds;
+        }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(attn_bwd_relfix_grouped_kernel, dim3(blocks), dim3(RELFIX_THREADS), lds, s, b);
+        int rc = launch_status("attn_bwd_relfix_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
 }
 
 }  // namespace medt

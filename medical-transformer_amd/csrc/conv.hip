@@ -124,6 +124,7 @@ static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float
 }
 
 int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride) {
+    if (conv_fwd_ws_ok(Cin, Cout, K, stride, (long)N * HoWo)) return cdiv((N / groups) * HoWo, 64);
     if (!conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo)) return conv2d_parts_per_group(N, groups, HoWo);
     if (conv_mfma_scratch_floats(N, groups, HoWo, Cin, Cout, K) > 0) return conv2d_parts_per_group(N, groups, HoWo);
     return conv_mfma_parts_per_group(N, groups, HoWo);
@@ -140,6 +141,135 @@ size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, in
     return conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K);
 }
 
+// Deep contraction, narrow output (conv3 128 -> 8 at 64 x 64, the decoders' 64 -> 32 and 128 -> 64 on small maps): in
+// the kernel above every lane walks all Cin * K * K taps serially -- Cin / 4 dependent global round trips (43 us for
+// conv3's 151 MFLOP).  Here a workgroup owns 64 output positions, its four waves split the channel contraction and
+// combine through LDS in fixed order, and the weight slice of the workgroup's OT output channels sits in LDS.
+// BatchNorm partials: one [sum, sum^2] pair of doubles per (64-position part, channel).
+template <int K, int OT>
+__global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_ws_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
+    int npg, int y_bf16) {
+    constexpr int KK = K * K;
+    __shared__ float red[3][OT][64];
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [OT][Cin][KK]: rows o0 .. o0+OT-1 of w, as stored
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + 63) / 64;
+    const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * OT;
+    {
+        const int nw = OT * Cin * KK;
+        const float* src = w + (size_t)o0 * Cin * KK;
+        for (int e0 = threadIdx.x; e0 < nw; e0 += 8 * MEDT_THREADS) {            // 8 loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * MEDT_THREADS, nw - 1)];
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * MEDT_THREADS < nw) wl[e0 + u * MEDT_THREADS] = v[u];
+        }
+    }
+    const int q = part * 64 + lane;
+    const bool ok = q < per_group;
+    const int ni = ok ? q / HoWo : 0, p = ok ? q - ni * HoWo : 0;
+    const int n = grp * npg + ni;
+    const int ho = p / Wo, wo = p - ho * Wo;
+    const int h0 = ho * stride - pad, w0 = wo * stride - pad;
+    int off[KK];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int h = h0 + kh, ww = w0 + kw;
+            off[kh * K + kw] = (ok && (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W) ? h * W + ww : -1;
+        }
+    float acc[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) acc[o] = 0.f;
+    const float* xn = x + (size_t)n * Cin * H * W;
+    const int HWi = H * W;
+    const int cb = (Cin * wv) / 4, ce = (Cin * (wv + 1)) / 4;
+    __syncthreads();
+    constexpr int U = K == 1 ? 16 : 4;                             // input channels per batch of loads
+    auto taps = [&](auto u_tag, int c) {
+        constexpr int UU = decltype(u_tag)::value;
+        float xr[UU][KK];
+#pragma unroll
+        for (int u = 0; u < UU; ++u)
+#pragma unroll
+            for (int t = 0; t < KK; ++t) xr[u][t] = xn[(size_t)(c + u) * HWi + max(off[t], 0)];
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float xv[KK];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) xv[t] = off[t] >= 0 ? xr[u][t] : 0.f;
+#pragma unroll
+            for (int o = 0; o < OT; ++o) {
+                const float* wp = wl + (o * Cin + c + u) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) acc[o] = fmaf(wp[t], xv[t], acc[o]);
+            }
+        }
+        MEDT_SCHED_FENCE();
+    };
+    int c = cb;
+    for (; c + U <= ce; c += U) taps(std::integral_constant<int, U>{}, c);
+    for (; c < ce; ++c) taps(std::integral_constant<int, 1>{}, c);
+    if (wv > 0) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) red[wv - 1][o][lane] = acc[o];
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const size_t yo = ((size_t)n * Cout + o0) * HoWo + p;
+        double* pd = partials ? reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o0) * 2 : nullptr;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            float v = acc[o] + (red[0][o][lane] + red[1][o][lane]) + red[2][o][lane];
+            if (bias) v += bias[o0 + o];
+            if (ok) st_act(y, yo + (size_t)o * HoWo, relu ? fmaxf(v, 0.f) : v, y_bf16);
+            if (pd) {
+                const float a = ok ? v : 0.f;
+                const double s1 = wave_sum_d((double)a), s2 = wave_sum_d((double)(a * a));
+                if (lane == 0) { pd[2 * o] = s1; pd[2 * o + 1] = s2; }
+            }
+        }
+    }
+}
+
+static int conv_fwd_ws_tile(int Cin, int Cout, int K, long positions) {       // 0: not this kernel
+    int ot = pick_tile(Cout, 8, (positions + 63) / 64);
+    while (ot > 1 && (size_t)ot * Cin * K * K * sizeof(float) > 48 * 1024) ot >>= 1;
+    return (size_t)ot * Cin * K * K * sizeof(float) <= 48 * 1024 ? ot : 0;
+}
+
+bool conv_fwd_ws_ok(int Cin, int Cout, int K, int stride, long positions) {
+    static const bool on = [] { const char* e = getenv("MEDT_FWD_WS"); return !(e && e[0] == '0'); }();
+    return on && K == 3 && Cin * K * K >= 512 && positions <= 16384 && !conv_use_mfma(Cin, Cout, K, stride, positions) &&
+           conv_fwd_ws_tile(Cin, Cout, K, positions) != 0;
+}
+
+static int conv2d_fwd_ws(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin, int H,
+                         int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, int groups, hipStream_t s,
+                         int y_bf16) {
+    const int npg = N / groups, ot = conv_fwd_ws_tile(Cin, Cout, 3, (long)N * Ho * Wo);
+    const unsigned gx = (unsigned)(groups * cdiv(npg * Ho * Wo, 64));
+    const size_t lds = (size_t)ot * Cin * 9 * sizeof(float);
+#define MEDT_LAUNCH_FWS(OT)                                                                                            \
+    hipLaunchKernelGGL((conv2d_fwd_ws_kernel<3, OT>), dim3(gx, Cout / OT), dim3(MEDT_THREADS), lds, s, x, w, bias, y, partials, \
+                       Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg, y_bf16)
+    switch (ot) {
+        case 8: MEDT_LAUNCH_FWS(8); break;
+        case 4: MEDT_LAUNCH_FWS(4); break;
+        case 2: MEDT_LAUNCH_FWS(2); break;
+        default: MEDT_LAUNCH_FWS(1); break;
+    }
+#undef MEDT_LAUNCH_FWS
+    return launch_status("conv2d_fwd_ws");
+}
+
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
                int y_bf16) {
@@ -147,6 +277,8 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
     if (!y_bf16 && conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
         (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
         return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
+    if (conv_fwd_ws_ok(Cin, Cout, K, stride, (long)N * Ho * Wo))
+        return conv2d_fwd_ws(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
     switch (K) {
         case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
         case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
@@ -355,7 +487,10 @@ template <int K>
 static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int Ho,
                              int Wo, int stride, int pad, hipStream_t s, const float* add) {
     if constexpr (K != 7) {
-        if ((long)N * H * W <= 4096 && Cout >= 64 && conv_bwd_data_ws_enabled()) {
+        // (3 x 3 with a deep contraction up to 16384 positions: conv2's 8 <- 128 at 64 x 64 was 58 us in the kernel below)
+        static const long ws_pos3 = [] { const char* e = getenv("MEDT_DGRAD_WS_POS3"); return e ? atol(e) : 16384L; }();
+        const long npos = (long)N * H * W;
+        if ((npos <= 4096 || (K == 3 && Cout * K * K >= 512 && npos <= ws_pos3)) && Cout >= 64 && conv_bwd_data_ws_enabled()) {
             const unsigned g64 = (unsigned)(((long)N * H * W + 63) / 64);
             // images one 64-position workgroup can touch, and their output gradient in floats
             const int imgs = H * W >= 64 ? 2 : 64 / (H * W) + 1;

@@ -34,7 +34,8 @@ bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions) {
     if (off || Cout < 32 || Cin * K * K < 256 || (stride != 1 && stride != 2)) return false;
     if (K == 3 && tiles >= 128) return true;
     // few tiles (2x2 / 4x4 maps of the deep LoGo layers, <= 1024 positions): split-K over workgroups + epilogue
-    return (K == 3 || K == 1) && tiles < 128 && positions <= 2048 && Cin * K * K >= 512;
+    static const long few_pos = [] { const char* e = getenv("MEDT_MFMA_FEWTILE_POS"); return e ? atol(e) : 2048L; }();
+    return (K == 3 || K == 1) && tiles < 128 && positions <= few_pos && Cin * K * K >= 512;
 }
 
 int conv_mfma_parts_per_group(int N, int groups, int HoWo) { return cdiv((N / groups) * HoWo, 64); }

@@ -50,14 +50,26 @@ struct WJob {                        // conv_wgrad_body<K, 64, 64> over a (gx, g
     int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K;
 };
 
+struct RelfixJob {                   // attn_bwd_relfix (axial_bwd.hip): u / w terms of one layer's relative-table and gate gradients
+    const float *relative, *sim_coef, *pg_part, *gate_raw;
+    BnStats ss;
+    GatePtrs gates;
+    float *rel_rows, *gate_rows;     // [groups * G][2gp * TL], [groups * G][4]
+    double sim_count;
+    int L, G, SC, hq, nparts, sweep_gridx, training, blocks;
+    unsigned lds;
+    float eps;
+};
+
 struct Queue {
+    std::vector<RelfixJob> relfix;
     std::vector<FinJob> fin;
     std::vector<BfinJob> bfin;
     std::vector<SmallFinArgs> sfin;
     std::vector<CJob> csum;
     std::vector<WJob> wgrad;
     std::vector<RJob> reduce;
-    size_t pending() const { return fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + reduce.size(); }
+    size_t pending() const { return relfix.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + reduce.size(); }
 };
 
 Queue* queue_for(hipStream_t s);     // the queue bound to this stream, or nullptr (immediate launches)
@@ -70,6 +82,7 @@ int bn_bwd_finalize_grouped(const BfinJob* jobs, int n, hipStream_t s);
 int wopos_small_bwd_finalize_grouped(const SmallFinArgs* jobs, int n, hipStream_t s);
 int reduce_rows_grouped(const RJob* jobs, int n, hipStream_t s);
 int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s);
+int axial_attn_bwd_relfix_grouped(const RelfixJob* jobs, int n, hipStream_t s);
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);            // MFMA tiles (conv_mfma.hip)
 int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s);       // VALU tiles (conv.hip), MEDT_WGRAD_VALU=1
 

@@ -53,20 +53,21 @@ int medt_queue_flush(void* qv, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = MEDT_OK;
     // order: statistics bookkeeping; first-stage sums and weight gradients; then the reductions of their partial slabs
+    if (!rc && !q.relfix.empty()) rc = axial_attn_bwd_relfix_grouped(q.relfix.data(), (int)q.relfix.size(), s);
     if (!rc && !q.fin.empty()) rc = bn_finalize_grouped(q.fin.data(), (int)q.fin.size(), s);
     if (!rc && !q.bfin.empty()) rc = bn_bwd_finalize_grouped(q.bfin.data(), (int)q.bfin.size(), s);
     if (!rc && !q.sfin.empty()) rc = wopos_small_bwd_finalize_grouped(q.sfin.data(), (int)q.sfin.size(), s);
     if (!rc && !q.csum.empty()) rc = channel_sum_grouped(q.csum.data(), (int)q.csum.size(), s);
     if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
-    q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
+    q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
     return rc;
 }
 
 int medt_queue_discard(void* qv) {
     if (!qv) { set_error("queue discard: null queue"); return MEDT_EINVAL; }
     Queue& q = *(Queue*)qv;
-    q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
+    q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
     return MEDT_OK;
 }
 

@@ -94,7 +94,7 @@ struct BwdWs {
 // axial_bwd.hip, or the two generic L x L passes of axial_core.hip.
 static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, const medt_axial_params* p, const BwdWs& w,
                               const float* qkv_raw, const float* stacked, const float* lse, const float* dy, const LayerStats& st,
-                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s) {
+                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s, Queue* q) {
     const int tr = d->training ? 1 : 0;
     int rc;
     if (w.sweep) {
@@ -111,7 +111,7 @@ static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, cons
                                      w.qb_rpg, s))) return rc;
         return axial_attn_bwd_relfix(g, w.plan, p->relative, w.coef_sim, st.sim, gates, w.pg_part,
                                      want_gates ? w.gate_raw : nullptr, tr, d->eps,
-                                     w.rel_part + w.sweep_blocks * 2 * g.gp * (2 * g.L - 1), w.gate_rows, s);
+                                     w.rel_part + w.sweep_blocks * 2 * g.gp * (2 * g.L - 1), w.gate_rows, s, q);
     }
     // bn_similarity backward statistics (pass A), coefficients, attention backward (pass B)
     if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out, d->stride,
@@ -231,7 +231,7 @@ int medt_axial_core_bwd(const medt_axial_desc* d, const medt_axial_params* p, co
     // generic L x L passes; coef_out is whatever the preceding medt_axial_layer_bwd left in the workspace, bn_similarity's
     // parameter gradients land in scratch (part_ob is dead by then)
     return attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, p->f_qr != nullptr, w.part_ob,
-                              w.part_ob + g.SC, s);
+                              w.part_ob + g.SC, s, nullptr);
 }
 
 int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, float* y,
@@ -331,13 +331,25 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         dy = w.dy_masked;
     }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
-    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
-    if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, 1.f / (float)(d->stride * d->stride),
-                              st.out, p->bn_output.weight, tr, w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s)))
-        return rc;
+    const float out_dscale = 1.f / (float)(d->stride * d->stride);
+    if (axial_out_bwd_chan_ok(*d)) {
+        // one workgroup per (group, channel): sums and coefficients in one launch; the parameter gradients follow off the
+        // layer chain (recorded when a queue is bound) from the one partial pair per group
+        if ((rc = axial_out_bwd_chan(*d, stacked, dy, st.out, p->bn_output.weight, w.part_ob, w.coef_out, g.row_count,
+                                     out_dscale, s))) return rc;
+        if (Queue* q = queue_for(s))
+            q->bfin.push_back(BfinJob{w.part_ob, 1, g.groups, g.OC, tr, g.row_count, out_dscale, st.out, p->bn_output.weight,
+                                      w.coef_out, gr->bn_out_weight, gr->bn_out_bias});
+        else if ((rc = bn_bwd_finalize(w.part_ob, 1, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
+                                       w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
+    } else {
+        if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
+        if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
+                                  w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
+    }
     // softmax / bn_similarity / logits backward: dqkv, the partial rows of bn_qkv's backward, of the tables and of the gates
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
-                                 gr->bn_sim_weight, gr->bn_sim_bias, s))) return rc;
+                                 gr->bn_sim_weight, gr->bn_sim_bias, s, queue_for(s)))) return rc;
     // bn_qkv backward, qkv_transform backward
     if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;

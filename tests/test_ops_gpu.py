@@ -54,6 +54,11 @@ CONV_CASES = [
     (32, 64, 3, 2, 1, True, False, False, False, 16, 64, 1),    # stride 2 (forward + weight gradient on MFMA)
     (40, 72, 3, 1, 1, False, True, True, True, 36, 15, 2),      # ragged tiles: Cout % 64 != 0, positions % 64 != 0
     (48, 80, 3, 1, 1, False, True, True, True, 32, 16, 2),      # 16-wide-map kernels with a partial channel tile (fwd / dgrad / wgrad)
+    # deep contraction, narrow side: the wave-split kernels (four waves share the channel loop, 64-position workgroups)
+    (128, 8, 3, 1, 1, False, True, False, True, 4, 64, 1),      # conv3 at BASELINE size (forward wave-split; dgrad wide)
+    (8, 128, 3, 1, 1, False, True, False, True, 4, 64, 1),      # conv2 at BASELINE size (dgrad wave-split at 16384 positions)
+    (64, 32, 3, 1, 1, True, False, False, False, 4, 32, 1),     # decoder4: bias, no BatchNorm
+    (72, 24, 3, 2, 1, False, True, True, True, 6, 18, 3),       # ragged: stride 2, 81-position maps, grouped statistics
 ]
 
 
