@@ -332,21 +332,9 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
     const float out_dscale = 1.f / (float)(d->stride * d->stride);
-    if (axial_out_bwd_chan_ok(*d)) {
-        // one workgroup per (group, channel): sums and coefficients in one launch; the parameter gradients follow off the
-        // layer chain (recorded when a queue is bound) from the one partial pair per group
-        if ((rc = axial_out_bwd_chan(*d, stacked, dy, st.out, p->bn_output.weight, w.part_ob, w.coef_out, g.row_count,
-                                     out_dscale, s))) return rc;
-        if (Queue* q = queue_for(s))
-            q->bfin.push_back(BfinJob{w.part_ob, 1, g.groups, g.OC, tr, g.row_count, out_dscale, st.out, p->bn_output.weight,
-                                      w.coef_out, gr->bn_out_weight, gr->bn_out_bias});
-        else if ((rc = bn_bwd_finalize(w.part_ob, 1, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
-                                       w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
-    } else {
-        if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
-        if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
-                                  w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
-    }
+    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
+    if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
+                              w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
     // softmax / bn_similarity / logits backward: dqkv, the partial rows of bn_qkv's backward, of the tables and of the gates
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
                                  gr->bn_sim_weight, gr->bn_sim_bias, s, queue_for(s)))) return rc;

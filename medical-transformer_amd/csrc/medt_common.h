@@ -134,4 +134,21 @@ __device__ __forceinline__ void block_sum_d(const float (&v)[K], float* red, dou
     }
 }
 
+// Backward finalisation:  dx = A*(d - m1 - xhat*m2), xhat = (x-mean)*rstd, A = weight*rstd
+//   => dx = c0*d_raw + c1*x + c2 with d = dscale*d_raw.
+__device__ __forceinline__ void bn_bwd_coef(double s1, double s2, double count, float dscale, double mean, double rstd,
+                                            double w, int training, float* cf) {
+    const double A = w * rstd;
+    cf[0] = (float)(A * dscale);
+    if (training) {
+        const double m1 = s1 / count, m2 = s2 / count;
+        cf[1] = (float)(-A * rstd * m2);
+        cf[2] = (float)(A * (rstd * mean * m2 - m1));
+    } else {
+        cf[1] = 0.f;
+        cf[2] = 0.f;
+    }
+}
+
+
 }  // namespace medt

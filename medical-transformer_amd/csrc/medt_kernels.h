@@ -159,9 +159,6 @@ int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, c
 // axial_small.hip: a whole position-free layer per (BN group, head) workgroup
 int bn_fin_apply(const float* z, const float* partials, int ppg, double count, const medt_bn_ptrs& bn, float eps, int training,
                  BnStats st, const float* res, float* y, int N, int C, int HW, int groups, int relu, hipStream_t s);
-int axial_out_bwd_chan_ok(const medt_axial_desc& d);          // pointwise.hip: threads per (group, channel) workgroup; 0 = no
-int axial_out_bwd_chan(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, const float* weight,
-                       float* partials, float* coef, double count, float dscale, hipStream_t s);
 bool conv_fwd_ws_ok(int Cin, int Cout, int K, int stride, long positions);      // conv.hip: wave-split forward (64-position parts)
 int bn_chan_threads(const medt_conv_desc& d, int HoWo);       // conv_small.hip: one workgroup per (group, channel); 0 = no
 int bn_act_bwd_chan(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,

@@ -465,22 +465,7 @@ int bn_finalize(const float* partials, int ppg, int groups, int CH, double count
     return launch_status("bn_finalize");
 }
 
-// Backward finalisation:  dx = A*(d - m1 - xhat*m2), xhat = (x-mean)*rstd, A = weight*rstd
-//   => dx = c0*d_raw + c1*x + c2 with d = dscale*d_raw.
-__device__ __forceinline__ void bn_bwd_coef(double s1, double s2, double count, float dscale, double mean, double rstd,
-                                            double w, int training, float* cf) {
-    const double A = w * rstd;
-    cf[0] = (float)(A * dscale);
-    if (training) {
-        const double m1 = s1 / count, m2 = s2 / count;
-        cf[1] = (float)(-A * rstd * m2);
-        cf[2] = (float)(A * (rstd * mean * m2 - m1));
-    } else {
-        cf[1] = 0.f;
-        cf[2] = 0.f;
-    }
-}
-
+// (bn_bwd_coef: medt_common.h)
 __device__ __forceinline__ void bn_bwd_finalize_body(int ch, const float* __restrict__ partials, int ppg, int groups,
                                                      int CH, double count, float dscale, BnStats st,
                                                      const float* __restrict__ weight, int training,
@@ -657,69 +642,6 @@ int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const fl
     hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(d.bn_groups * ppg, OC), dim3(MEDT_THREADS), 0, s, stacked, dy, st,
                        partials, d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype);
     return launch_status("axial_out_bwd_stats");
-}
-
-// The same statistics with one WORKGROUP per (group, channel) for populations <= 16 values per thread: the two sums
-// never leave the block, so the coefficients are written right here and bn_bwd_finalize leaves the layer chain (the
-// BatchNorm parameter gradients are produced by the recorded finalisation from the one partial pair per group).
-template <int TT>
-__global__ __launch_bounds__(TT) void axial_out_bwd_chan_kernel(const float* __restrict__ stk, const float* __restrict__ dy,
-                                                                BnStats st, const float* __restrict__ weight,
-                                                                float* __restrict__ partials, float* __restrict__ coef, int C,
-                                                                int H, int W, int OC, int stride, int npg, int bf16,
-                                                                int training, double count, float dscale) {
-    __shared__ float red[2 * (TT / 64)];
-    const int HW = H * W, Ho = H / stride, Wo = W / stride, per_group = npg * HW;
-    const int grp = blockIdx.x, ch = blockIdx.y, c = ch / (OC / C), tid = threadIdx.x;
-    const float mean = st.mean[grp * OC + ch], rstd = st.rstd[grp * OC + ch];
-    float s1 = 0.f, s2 = 0.f;
-    for (int q = tid; q < per_group; q += TT) {
-        const int ni = q / HW, p = q - ni * HW, n = grp * npg + ni;
-        const int h = p / W, w = p - h * W;
-        const int ho = h / stride, wo = w / stride;
-        if (ho < Ho && wo < Wo) {
-            const float d = dy[((size_t)(n * C + c) * Ho + ho) * Wo + wo];
-            const float xh = (ld_act(stk, ((size_t)n * OC + ch) * HW + p, bf16) - mean) * rstd;
-            s1 += d;
-            s2 = fmaf(d, xh, s2);
-        }
-    }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s1; red[(tid >> 6) * 2 + 1] = s2; }
-    __syncthreads();
-    if (tid == 0) {
-        s1 = 0.f;
-        s2 = 0.f;
-        for (int w = 0; w < TT / 64; ++w) { s1 += red[w * 2]; s2 += red[w * 2 + 1]; }
-        partials[((size_t)grp * OC + ch) * 2] = s1;
-        partials[((size_t)grp * OC + ch) * 2 + 1] = s2;
-        // exactly what bn_bwd_finalize derives from this one partial pair
-        bn_bwd_coef((double)s1 * dscale, (double)s2 * dscale, count, dscale, mean, rstd, weight[ch], training,
-                    coef + ((size_t)grp * OC + ch) * 3);
-    }
-}
-
-int axial_out_bwd_chan_ok(const medt_axial_desc& d) {
-    static const int pmax = [] { const char* e = getenv("MEDT_BN_CHAN_MAX"); return e ? atoi(e) : 16384; }();
-    // (measured on the MedT step: 2.418 ms with it, 2.375 without -- two channels' scalar walks per workgroup lose to the
-    //  two short launches they replace -- so it is off unless MEDT_OUT_CHAN=1)
-    static const bool on = [] { const char* e = getenv("MEDT_OUT_CHAN"); return e && e[0] == '1'; }();
-    const long P = (long)(d.N / d.bn_groups) * d.H * d.W;
-    return (on && P <= pmax && P <= 16384) ? (P <= 4096 ? 256 : 1024) : 0;
-}
-
-int axial_out_bwd_chan(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, const float* weight,
-                       float* partials, float* coef, double count, float dscale, hipStream_t s) {
-    const int OC = d.has_pos ? 2 * d.C : d.C, npg = d.N / d.bn_groups;
-    const dim3 grid(d.bn_groups, OC);
-    if (axial_out_bwd_chan_ok(d) == 256)
-        hipLaunchKernelGGL(axial_out_bwd_chan_kernel<256>, grid, dim3(256), 0, s, stacked, dy, st, weight, partials, coef,
-                           d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype, d.training ? 1 : 0, count, dscale);
-    else
-        hipLaunchKernelGGL(axial_out_bwd_chan_kernel<1024>, grid, dim3(1024), 0, s, stacked, dy, st, weight, partials, coef,
-                           d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype, d.training ? 1 : 0, count, dscale);
-    return launch_status("axial_out_bwd_chan");
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void bn_bwd_apply_raw_bf16_kernel(float* __restrict__ d,
