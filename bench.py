@@ -218,6 +218,23 @@ def cpu_baseline_leg(steps=8):
                       f"(torch CPU, {cores} threads), fwd+CE+backward+Adam", "s_per_step": dt}
 
 
+def box_probe():
+    """Latency of a dependent global load on this box (scripts/ubench/load_latency.hip; built by __graft_entry__.build()).
+    The step is a chain of ~330 small kernels whose workgroups each wait on a few dependent memory round trips, so its
+    time follows this number: boxes of the same SKU and clocks were seen at 2.34 and 3.63 ms/step."""
+    import subprocess
+    exe = os.path.join(ROOT, "scripts", "ubench", "load_latency.bin")
+    src = os.path.join(ROOT, "scripts", "ubench", "load_latency.hip")
+    try:
+        if not os.path.exists(exe):
+            subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", src, "-o", exe],
+                           check=True, capture_output=True, timeout=120)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+    except Exception as e:                                   # a probe, not the product: never fails the bench
+        return {"error": repr(e)[:200]}
+
+
 def baseline_config(args):
     """Which BASELINE.json configuration a (model, imgsize, per-GPU batch, dtype) line corresponds to."""
     key = (args.model, args.imgsize, args.batch, args.dtype)
@@ -326,6 +343,8 @@ def main():
                           else "outside the graph") if distributed else None),
         "collective_in_graph": bool(getattr(train_step, "collective_in_graph", False)) if distributed else None,
     }
+    if rank == 0:
+        result["box_probe"] = box_probe()
     if rank == 0 and world == 1:
         model.eval()
         with torch.no_grad():

@@ -28,7 +28,7 @@ def one(pattern, required=True):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
 def counters(folder):
@@ -106,11 +106,23 @@ def rows_for(st, tag):
 
 kern = {}
 for k in fetch:
-    if any(t in k for t in ("attn_fwd", "sim_stats", "attn_bwd")):
+    if any(t in k for t in ("attn_fwd", "sim_stats", "attn_bwd", "sim_bwd_finalize")):
         kern[k] = {"FETCH_SIZE_KB_avg": fetch[k]["FETCH_SIZE"], "WRITE_SIZE_KB_avg": write.get(k, {}).get("WRITE_SIZE"),
                    "launches": fetch[k]["launches"],
                    "hbm_bytes_per_launch": int((2 * fetch[k]["FETCH_SIZE"] + (write.get(k, {}).get("WRITE_SIZE") or 0)) * 1024)}
 main = max((k for k in kern if "attn_fwd" in k), key=lambda k: kern[k]["FETCH_SIZE_KB_avg"])
+# backward core = the single sweep (frozen gates: the <.., false> instance) + its fix / relfix / finalize launches
+bwd_parts = {}
+for k in kern:
+    if "attn_bwd_sweep" in k and "false" in k:
+        bwd_parts["sweep"] = k
+    elif "attn_bwd_fix" in k:
+        bwd_parts["fix"] = k
+    elif "attn_bwd_relfix" in k:
+        bwd_parts["relfix"] = k
+    elif "sim_bwd_finalize" in k:
+        bwd_parts["finalize"] = k
+bwd_bytes = sum(kern[k]["hbm_bytes_per_launch"] for k in bwd_parts.values()) if "sweep" in bwd_parts else None
 json.dump({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --roofline-only` (scripts/collect_profiles.sh)",
     "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as reported; unit KiB",
@@ -118,6 +130,9 @@ json.dump({
     "attn_fwd_kernel": main,
     "attn_fwd_bytes_per_launch": kern[main]["hbm_bytes_per_launch"],
     "attn_fwd_algorithmic_bytes": alg["attn_fwd"],
+    "attn_bwd_kernels": bwd_parts,
+    "attn_bwd_bytes_per_launch": bwd_bytes,
+    "attn_bwd_algorithmic_bytes": alg["attn_bwd"],
     "note": "attn_fwd traffic = qkv read once + sv|sve written once + row log-sum-exp (excluded from the algorithmic figure by SURVEY.md 8d); "
             "sim_stats reads the q,k half of qkv once and writes a few KB of partials",
 }, open(os.path.join(OUT, "roofline_traffic.json"), "w"), indent=1)
@@ -165,10 +180,13 @@ if os.path.exists(p):
             ab[name] = {"ms_per_step": j["ms_per_step"], "images_per_s": j["value"]}
         except Exception:
             pass
-    json.dump({"what": "`python bench.py --no-cpu-baseline --no-roofline` (MedT 128, 4 images, one hipGraph replay per step) with "
-                       "one switch flipped: MFMA = default (grouped weight gradients on 64x64 MFMA tiles); VALU = "
-                       "MEDT_WGRAD_VALU=1 (4x4 register tiles); IMMEDIATE = MEDT_DEFER=0 (no recorded/grouped launches); "
-                       "ONE_STREAM = MEDT_TWO_STREAMS=0; NO_SINKS = MEDT_GRAD_SINKS=0 (autograd add kernels at the fan-ins)",
+    json.dump({"what": "`python bench.py --no-cpu-baseline --no-roofline` (MedT 128, 4 images, one hipGraph replay per step) on ONE "
+                       "box, back to back, with one switch flipped (scripts/collect_profiles.sh lists the variables): "
+                       "BN_FIN_APPLY_OFF = bn_finalize + bn_apply_act as two launches; BN_CHAN_OFF = bn_act_bwd_stats -> "
+                       "bn_bwd_finalize -> bn_bwd_apply instead of one workgroup per (group, channel); WGRAD_R2_CHUNKS = round 2's "
+                       "32 chunks of <= 512 positions; CONV_WS_OFF = no wave-split forward / 16384-position dgrad; TWO_PASS_BWD = "
+                       "the generic two-pass attention backward; UP2X_SCALAR = one output column per lane; VALU_WGRAD = 4x4 "
+                       "register tiles; IMMEDIATE = no recorded/grouped launches; ONE_STREAM; NO_SPLIT_FLUSH",
                "runs": ab}, open(os.path.join(OUT, TAG + "_step_ab.json"), "w"), indent=1)
 p = os.path.join(RAW, "conv_ab.json")
 if os.path.exists(p) and os.path.getsize(p) > 10:
@@ -186,7 +204,8 @@ if os.path.exists(p):
     json.dump({"what": "cpu_baseline leg of bench.py (oracle, MedT 128 bs 4, fwd+CE+bwd+Adam, 3 steps after 1 warm-up) on the "
                        "GPU box's host cores at MEDT_CPU_THREADS = 8 / 16 / 32 / 64", "threads": sweep},
               open(os.path.join(OUT, TAG + "_cpu_thread_sweep.json"), "w"), indent=1)
-for f, dst in (("parity_report.txt", TAG + "_parity_report.txt"), ("dist_forced_rccl.log", TAG + "_dist_forced_rccl.log")):
+for f, dst in (("parity_report.txt", TAG + "_parity_report.txt"), ("dist_forced_rccl.log", TAG + "_dist_forced_rccl.log"),
+               ("graph_host_cost.txt", TAG + "_graph_host_cost.txt"), ("valu_rate.txt", TAG + "_valu_rate_ubench.txt")):
     p = os.path.join(RAW, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(OUT, dst))
