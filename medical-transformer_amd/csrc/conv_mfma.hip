@@ -572,6 +572,106 @@ __device__ __forceinline__ void conv_wgrad_mfma_body(
         }
 }
 
+// The same with a 32(o) x 64(k) tile for the recorded (grouped) launches: most recorded layers have 16-32 output
+// channels, so the 64-row tile left two or three of the four waves without a row block and spent half of its LDS on zero
+// rows.  Here wave w owns row block (w & 1) and the two column blocks 2*(w >> 1), +1; the A stage is 32 x 65 floats
+// (25 KB of LDS per workgroup instead of 33: six resident workgroups per CU instead of four -- the kernel waits on
+// global loads for half of its wave cycles, profiles/r03_step_pmc.json, so residency is what it needs).
+template <int K>
+__device__ __forceinline__ void conv_wgrad_mfma_body32(
+    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
+    const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+    int stride, int pad, int QS, int npg, int bx, int by, int bz, float (*A)[65], float (*B)[65]) {
+    constexpr int KK = K * K;
+    const int Ktot = Cin * KK, HoWo = Ho * Wo;
+    const int o0 = bx * 32, k0 = by * 64;
+    const long NP = (long)N * HoWo;
+    const long q_begin = (long)bz * QS;
+    const long q_end = q_begin + QS < NP ? q_begin + QS : NP;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (SGPR: see above)
+    const int j = lane, r0 = wv;
+    f32x4 acc[2];
+    acc[0] = (f32x4)(0.f);
+    acc[1] = (f32x4)(0.f);
+    float ra[8], rb[16];
+    auto fetch = [&](long q0) {
+        const long q = q0 + j;
+        const bool qok = q < q_end;
+        const int n = qok ? (int)(q / HoWo) : 0, p = qok ? (int)(q - (long)n * HoWo) : 0;
+        const int ho = p / Wo, wo = p - ho * Wo;
+        const int hb = ho * stride - pad, wb = wo * stride - pad;
+        const float* dyp = dy + (size_t)n * Cout * HoWo + p;
+        const float* rawp = raw ? raw + (size_t)n * Cout * HoWo + p : nullptr;
+        const float* xp = x + (size_t)n * Cin * H * W + (long)hb * W + wb;
+        const long qlast = q0 + 63 < q_end ? q0 + 63 : q_end - 1;
+        const int g_first = (int)(q0 / HoWo) / npg, g_last = (int)(qlast / HoWo) / npg;
+        const bool one_group = g_first == g_last;
+        const float* cfu = coef ? coef + (size_t)g_first * Cout * 3 : nullptr;
+        const float* cfl = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = o0 + r0 + 4 * i;
+            float a = 0.f;
+            if (o < Cout) {
+                if (qok) a = dyp[(size_t)o * HoWo];
+                if (coef) {
+                    const float rw = qok ? rawp[(size_t)o * HoWo] : 0.f;
+                    if (one_group) a = fmaf(cfu[o * 3], a, fmaf(cfu[o * 3 + 1], rw, cfu[o * 3 + 2]));
+                    else a = fmaf(cfl[o * 3], a, fmaf(cfl[o * 3 + 1], rw, cfl[o * 3 + 2]));
+                    if (!qok) a = 0.f;
+                }
+            }
+            ra[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = k0 + r0 + 4 * i;
+            float b = 0.f;
+            if (k < Ktot) {
+                const int c = k / KK, t = k - c * KK;
+                const int dh = t / K, dw = t % K;
+                const int h = hb + dh, w = wb + dw;
+                if (qok && h >= 0 && h < H && w >= 0 && w < W) b = xp[((size_t)c * H + dh) * W + dw];
+            }
+            rb[i] = b;
+        }
+    };
+    const int rblk = wv & 1, t0 = 2 * (wv >> 1);
+    const bool wave_rows = o0 + 16 * rblk < Cout;
+    const int tcols = Ktot - k0 >= 64 ? 4 : (Ktot - k0 + 15) / 16;
+    if (q_begin < q_end) fetch(q_begin);
+    for (long q0 = q_begin; q0 < q_end; q0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[r0 + 4 * i][j] = ra[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) B[r0 + 4 * i][j] = rb[i];
+        __syncthreads();
+        if (q0 + 64 < q_end) fetch(q0 + 64);
+        if (wave_rows && t0 < tcols) {
+#pragma unroll 4
+            for (int ks = 0; ks < 16; ++ks) {
+                const float a = A[16 * rblk + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (t0 + tt < tcols) {
+                        const float b = B[(t0 + tt) * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)bz * Cout * Ktot;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * rblk + (lane >> 4) * 4 + r, k = k0 + (t0 + tt) * 16 + (lane & 15);
+            if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[tt][r];
+        }
+}
+
 template <int K>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
@@ -597,17 +697,24 @@ struct WJobP {                       // WJob packed for the kernel-argument bloc
 };
 using WBatch = JobBatch<WJobP, 42>;
 static_assert(sizeof(WBatch) <= 4000, "job table must fit the kernel-argument block");
+template <int TO>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(WBatch b) {
-    __shared__ float A[64][65];
+    __shared__ float A[TO][65];
     __shared__ float B[64][65];
     const int j = find_job(b, blockIdx.x);
     const WJobP& w = b.job[j];
     const int local = blockIdx.x - b.start[j];
-    const int gx = (w.Cout + 63) / 64, gy = (w.Cin * w.K * w.K + 63) / 64;
+    const int gx = (w.Cout + TO - 1) / TO, gy = (w.Cin * w.K * w.K + 63) / 64;
     const int bx = local % gx, t = local / gx, by = t % gy, bz = t / gy;
-#define MEDT_WG_BODY(KV)                                                                                              \
-    conv_wgrad_mfma_body<KV>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, \
-                             w.pad, w.QS, w.npg, bx, by, bz, A, B)
+#define MEDT_WG_BODY(KV)                                                                                                 \
+    do {                                                                                                                 \
+        if constexpr (TO == 64)                                                                                          \
+            conv_wgrad_mfma_body<KV>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo,      \
+                                     w.stride, w.pad, w.QS, w.npg, bx, by, bz, A, B);                                    \
+        else                                                                                                             \
+            conv_wgrad_mfma_body32<KV>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo,    \
+                                       w.stride, w.pad, w.QS, w.npg, bx, by, bz, A, B);                                  \
+    } while (0)
     if (w.K == 1) MEDT_WG_BODY(1);
     else if (w.K == 3) MEDT_WG_BODY(3);
     else MEDT_WG_BODY(7);
@@ -618,6 +725,7 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
     if (valu) return conv_wgrad_grouped_valu(jobs, n, s);            // A/B switch: the 4x4-register-tile VALU body
     static const bool debug = getenv("MEDT_WG_DEBUG") != nullptr;
+    static const int to = [] { const char* e = getenv("MEDT_WG_TILE"); return (e && atoi(e) == 64) ? 64 : 32; }();   // o-tile
     // longest workgroups first: steps of 64 positions per chunk, weighted by the taps a step gathers
     std::vector<int> order(n);
     for (int j = 0; j < n; ++j) order[j] = j;
@@ -629,7 +737,8 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     auto launch = [&]() -> int {
         b.start[b.n] = blocks;
         if (debug) fprintf(stderr, "wgrad grouped: %d jobs, %d blocks\n", b.n, blocks);
-        hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        if (to == 32) hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel<32>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        else hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel<64>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
         b.n = 0;
         blocks = 0;
         return launch_status("conv_wgrad_mfma_grouped");
@@ -643,7 +752,7 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
         b.job[b.n] = WJobP{w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.QS, w.npg, w.gz,
                            (unsigned char)w.stride, (unsigned char)w.pad, (unsigned char)w.K, 0};
         b.start[b.n] = blocks;
-        blocks += w.gx * w.gy * w.gz;
+        blocks += cdiv(w.Cout, to) * w.gy * w.gz;
         if (++b.n == 42) { int rc = launch(); if (rc) return rc; }
     }
     if (b.n) { int rc = launch(); if (rc) return rc; }
