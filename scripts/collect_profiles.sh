@@ -20,7 +20,7 @@ timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_AC
 timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2 -- python bench.py --roofline-only > $O/pmc_sq2.log 2>&1
 # one switch flipped per run (the round's changes and the older structural switches)
 for v in "DEFAULT:" "BN_FIN_APPLY_OFF:MEDT_BN_FIN_APPLY=0" "BN_CHAN_OFF:MEDT_BN_CHAN_MAX=0" "WGRAD_R2_CHUNKS:MEDT_WG_CHUNKS=32 MEDT_WG_QMAX=512" \
-         "CONV_WS_OFF:MEDT_FWD_WS=0 MEDT_DGRAD_WS_POS3=4096" "TWO_PASS_BWD:MEDT_BWD_SWEEP=0" "UP2X_SCALAR:MEDT_UP2X_VEC=0" "VALU_WGRAD:MEDT_WGRAD_VALU=1" \
+         "CONV_WS_OFF:MEDT_FWD_WS=0 MEDT_DGRAD_WS_POS3=4096" "TWO_PASS_BWD:MEDT_BWD_SWEEP=0" "UP2X_SCALAR:MEDT_UP2X_VEC=0" "WGRAD_TILE64:MEDT_WG_TILE=64" "VALU_WGRAD:MEDT_WGRAD_VALU=1" \
          "IMMEDIATE:MEDT_DEFER=0" "ONE_STREAM:MEDT_TWO_STREAMS=0" "NO_SPLIT_FLUSH:MEDT_SPLIT_FLUSH=0" "DEFAULT_AGAIN:"; do
   name=${v%%:*}; envs=${v#*:}
   echo -n "$name " >> $O/ab.txt

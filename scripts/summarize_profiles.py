@@ -188,7 +188,8 @@ if os.path.exists(p):
                        "BN_FIN_APPLY_OFF = bn_finalize + bn_apply_act as two launches; BN_CHAN_OFF = bn_act_bwd_stats -> "
                        "bn_bwd_finalize -> bn_bwd_apply instead of one workgroup per (group, channel); WGRAD_R2_CHUNKS = round 2's "
                        "32 chunks of <= 512 positions; CONV_WS_OFF = no wave-split forward / 16384-position dgrad; TWO_PASS_BWD = "
-                       "the generic two-pass attention backward; UP2X_SCALAR = one output column per lane; VALU_WGRAD = 4x4 "
+                       "the generic two-pass attention backward; UP2X_SCALAR = one output column per lane; WGRAD_TILE64 = 64x64 instead "
+                       "of 32x64 tiles for the recorded weight gradients; VALU_WGRAD = 4x4 "
                        "register tiles; IMMEDIATE = no recorded/grouped launches; ONE_STREAM; NO_SPLIT_FLUSH",
                "runs": ab}, open(os.path.join(OUT, TAG + "_step_ab.json"), "w"), indent=1)
 p = os.path.join(RAW, "conv_ab.json")
