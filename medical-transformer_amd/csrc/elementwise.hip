@@ -45,7 +45,7 @@ struct BnFinApplyArgs {
     const float *z, *partials, *weight, *bias, *running_mean, *running_var, *res;
     float* y;
     BnStats st;
-    int C, HW, npg, ppg, parts, relu, training;
+    int C, HW, npg, ppg, parts, relu, training, vec4;     // vec4: HW % 4 == 0 and z / res / y 16-byte aligned
     double count;
     float eps;
 };
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_fin_apply_kernel(BnFinApplyAr
     const int HW = a.HW, P = a.npg * HW;
     const int q0 = part * (MEDT_THREADS * BFA_PER_THREAD);
     const int q1 = q0 + MEDT_THREADS * BFA_PER_THREAD < P ? q0 + MEDT_THREADS * BFA_PER_THREAD : P;
-    if ((HW & 3) == 0) {
+    if (a.vec4) {
         for (int q = q0 + 4 * tid; q < q1; q += 4 * MEDT_THREADS) {
             const int ni = q / HW, p = q - ni * HW;
             const size_t idx = ((size_t)(grp * a.npg + ni) * a.C + c) * HW + p;
@@ -130,6 +130,7 @@ int bn_fin_apply(const float* z, const float* partials, int ppg, double count, c
     a.z = z; a.partials = partials; a.weight = bn.weight; a.bias = bn.bias; a.running_mean = bn.running_mean;
     a.running_var = bn.running_var; a.res = res; a.y = y; a.st = st; a.C = C; a.HW = HW; a.npg = N / groups; a.ppg = ppg;
     a.parts = cdiv(a.npg * HW, MEDT_THREADS * BFA_PER_THREAD); a.relu = relu; a.training = training; a.count = count;
+    a.vec4 = ((HW & 3) == 0 && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)res) & 15) == 0) ? 1 : 0;
     a.eps = eps;
     hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(groups * a.parts, C), dim3(MEDT_THREADS), 0, s, a);
     return launch_status("bn_fin_apply");

@@ -506,7 +506,9 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
         float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
         const bool small = conv_small_ok(*d);
-        if (small || bn_chan_threads(*d, g.HoWo)) {
+        // (the one-workgroup kernel moves float4s: 16-byte aligned tensors only)
+        const bool aligned = ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dres | (uintptr_t)cw.dz) & 15) == 0);
+        if (small || (aligned && bn_chan_threads(*d, g.HoWo))) {
             // one wave (small blocks) or one workgroup per (group, channel): mask, sums, coefficients and dz in one
             // kernel; the finalisation only produces the parameter gradients (one partial slot per group)
             if (small)
