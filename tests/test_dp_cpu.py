@@ -151,3 +151,43 @@ def test_flatadam_refuses_cpu_update_loudly():
     (p * 2).sum().backward()
     with pytest.raises(MedtError):
         opt.step()
+
+
+def test_flatadam_slot_window_and_frozen_parameters():
+    """Host-side protocol of the flat gradient slots (medt_amd/optim.py): slots are live only between zero_grad() and
+    pack_gradients(); a parameter that has been trained cannot be frozen behind the optimizer's back (torch.optim.Adam
+    would skip it, the single flat kernel cannot); one that was never trained stays excluded."""
+    import pytest
+    from medt_amd import MedtError
+    from medt_amd import optim as OPT
+    a, b, never = (torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2)), torch.nn.Parameter(torch.ones(4)))
+    never.requires_grad_(False)
+    opt = OPT.FlatAdam([a, b, never])
+    assert not opt.step_open
+    opt.zero_grad()
+    assert opt.step_open
+    (a.sum() * 2 + b.sum() * 3).backward()
+    opt.pack_gradients()                                   # adopts a and b (their first gradients came through autograd)
+    assert not opt.step_open and [g.numel for g in opt.groups] == [5]
+    sa = OPT.grad_slot(a)
+    assert sa is not None and OPT.grad_slot(never) is None
+    assert OPT.live(sa) is None                            # window closed: a backward now must go through autograd
+    opt.zero_grad()
+    assert OPT.live(sa) is sa
+    view, direct = OPT.claim(sa)                           # what a slot-aware backward does: write the slot directly ...
+    assert direct and view.data_ptr() == opt.groups[0].flat_g.data_ptr()
+    view.fill_(7.0)
+    tmp, direct2 = OPT.claim(sa)                           # ... and a second use of the parameter accumulates
+    assert not direct2
+    tmp.fill_(1.0)
+    OPT.accumulate(sa, tmp)
+    (b.sum() * 3).backward()                               # b through plain autograd in the same step
+    opt.pack_gradients()
+    assert torch.equal(a.grad, torch.full((3,), 8.0)) and torch.equal(b.grad, torch.full((2,), 3.0))
+    assert a.grad.data_ptr() == opt.groups[0].flat_g.data_ptr()
+    # freezing a trained parameter
+    opt.zero_grad()
+    b.requires_grad_(False)
+    (a.sum()).backward()
+    with pytest.raises(MedtError):
+        opt.pack_gradients()
