@@ -16,6 +16,18 @@
 
 namespace medt {
 
+// -DMEDT_STAMPS (scripts/phase_stamps.sh builds a second library with it): thread 0 of workgroup (0, 0) of the fused
+// forward kernel records the 100 MHz wall clock at its phase boundaries; medt_debug_stamps() copies them out.
+#ifdef MEDT_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define MEDT_STAMP(i)                                                                          \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); \
+    } while (0)
+#else
+#define MEDT_STAMP(i) do { } while (0)
+#endif
+
 struct SmallFwdArgs {
     const float* x;                     // (N, C, H, W)
     const float* w;                     // (2C, C)
@@ -104,6 +116,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     float* red = sh + 32;               // [64] reduction scratch
     float* Wl = red + 64;               // [C][NCH] qkv_transform rows of this head, transposed
     float* prm = Wl + C * NCH;          // [NCH + 1 + GP][4] BatchNorm parameters of this head's channels (bn_qkv | sim | out)
+    MEDT_STAMP(0);
     if (tid < NCH + 1 + GP) {
         const medt_bn_ptrs& bn = tid < NCH ? a.bq : (tid == NCH ? a.bs : a.bo);
         const int ch = tid < NCH ? hg * NCH + tid : (tid == NCH ? hg : hg * GP + (tid - NCH - 1));
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
             store_w(base);
         }
         __syncthreads();
+        MEDT_STAMP(1);                                          // weights in LDS, first input batch in registers
         for (int r = 0; r < nitems; ++r) {
             if (r) locate(r, act, ks, q, xp);
             float acc[NCH];
@@ -222,6 +236,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(2);                                              // projection done, q | k | v rows in LDS
     // 2. bn_qkv: batch statistics over the group's positions (one wave per channel)      (:228)
     for (int oc = wave; oc < NCH; oc += NW) {
         float s = 0.f, ss = 0.f;
@@ -239,6 +254,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(3);                                              // bn_qkv sums
     if (tid < NCH) {                                   // the double-precision finalisations side by side, not one per wave turn
         const int ch = hg * NCH + tid;
         double s, ss;
@@ -251,11 +267,13 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(4);                                              // bn_qkv finalised (double)
     for (int item = tid; item < NCH * P; item += T) {
         const int oc = item / P;
         Q[item] = fmaf(Q[item], sc[oc], sh[oc]);
     }
     __syncthreads();
+    MEDT_STAMP(5);                                              // normalised
     // 3. logits of this thread's rows (position q is query i of its sequence; key j sits at base + j*sj), kept in
     //    registers across the bn_similarity reduction                                     (:232-236)
     constexpr int SJ1 = 1;
@@ -284,6 +302,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     small_block_sum<2>(v, red, red + 32, NW);
+    MEDT_STAMP(6);                                              // logits + their sums
     if (tid == 0) {
         float scale, shift;
         small_scale_shift_p((double)red[32], (double)red[33], (double)P * L, prm + NCH * 4, a.eps, a.training, scale, shift);
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(7);                                              // bn_similarity finalised
     const float a_qk = red[40] * MEDT_LOG2E;     // the shift is constant along a softmax row
     // 4. softmax + P.V per row; sv stays in LDS for the output statistics                 (:237-241)
 #pragma unroll
@@ -326,6 +346,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(8);                                              // softmax + P.V
     // 5. bn_output statistics                                                             (:242)
     for (int c = wave; c < GP; c += NW) {
         float s = 0.f, ss = 0.f;
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(9);                                              // bn_output sums
     if (tid < GP) {
         const int ch = hg * GP + tid;
         double s, ss;
@@ -355,8 +377,24 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     __syncthreads();
+    MEDT_STAMP(10);                                             // bn_output finalised
     // 6. bn_output apply + AvgPool2d(stride) [+ the block's ReLU]                          (:242-253, :381-383)
     const int st = a.stride, Ho = a.H / st, Wo = a.W / st, HoWo = Ho * Wo;
+    if (st == 1) {
+        // no pooling: one position per thread turn, its GP channels in a compile-time loop (the generic loop below spends
+        // its time on three runtime divisions per element: 2.6 of the kernel's 18 us, scripts/phase_stamps.py)
+        for (int q = tid; q < P; q += T) {
+            const int ni = q / HW, p = q - ni * HW;
+            float* dst = a.y + ((size_t)(n0 + ni) * C + hg * GP) * HW + p;
+#pragma unroll
+            for (int c = 0; c < GP; ++c) {
+                const float v = fmaf(sc[c], S[c * P + q], sh[c]);
+                dst[(size_t)c * HW] = a.out_relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+        MEDT_STAMP(11);
+        return;
+    }
     const float pool = 1.f / (float)(st * st);
     for (int item = tid; item < GP * a.npg * HoWo; item += T) {
         const int c = item / (a.npg * HoWo), r = item - c * a.npg * HoWo, ni = r / HoWo, po = r - ni * HoWo;
@@ -368,6 +406,7 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
         acc *= pool;
         a.y[((size_t)(n0 + ni) * C + hg * GP + c) * HoWo + po] = a.out_relu ? fmaxf(acc, 0.f) : acc;
     }
+    MEDT_STAMP(11);
 }
 
 static size_t small_lds_bytes(int gp, int P, int C) {
@@ -892,3 +931,9 @@ int wopos_small_bwd_finalize(const AxialGeom& g, const medt_axial_desc& d, const
 }
 
 }  // namespace medt
+
+#ifdef MEDT_STAMPS
+extern "C" int medt_debug_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(medt::g_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -27,22 +27,26 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str = None, obj_dir: str = "build") -> str:
+    """defines / lib_path / obj_dir: an instrumented second library next to the product one (scripts/phase_stamps.py
+    builds libmedt_stamps.so with -DMEDT_STAMPS and loads it through MEDT_LIB_OVERRIDE)."""
+    if lib_path is None:
+        if not force and not _stale():
+            return LIB_PATH
+        lib_path = LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    os.makedirs(os.path.join(CSRC, obj_dir), exist_ok=True)
     # axial_bwd.hip: the SLP vectorizer pairs the sweep's FMAs into v_pk_fma_f32, which runs at the scalar rate on gfx950
     # and costs a third of the loop in v_mov register shuffles to line the operand pairs up
     units = [(s, s.replace(".hip", ".o"), ["-fno-slp-vectorize"] if s == "axial_bwd.hip" else []) for s in SOURCES]
     # the bandwidth-tuned attention kernels once more with bfloat16 storage as a compile-time constant
     units.append(("axial_fast.hip", "axial_fast_bf16.o", ["-DMEDT_FAST_BF16=1"]))
     for s, oname, extra in units:          # one hipcc per translation unit, in parallel
-        o = os.path.join(CSRC, "build", oname)
+        o = os.path.join(CSRC, obj_dir, oname)
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, "-I", os.path.join(REPO_ROOT, "include"),
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, *defines, "-I", os.path.join(REPO_ROOT, "include"),
                "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -50,11 +54,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
