@@ -268,9 +268,9 @@ __global__ __launch_bounds__(512) void wopos_small_fwd_kernel(SmallFwdArgs a) {
     }
     __syncthreads();
     MEDT_STAMP(4);                                              // bn_qkv finalised (double)
-    for (int item = tid; item < NCH * P; item += T) {
-        const int oc = item / P;
-        Q[item] = fmaf(Q[item], sc[oc], sh[oc]);
+    for (int q = tid; q < P; q += T) {
+#pragma unroll
+        for (int oc = 0; oc < NCH; ++oc) Q[oc * P + q] = fmaf(Q[oc * P + q], sc[oc], sh[oc]);
     }
     __syncthreads();
     MEDT_STAMP(5);                                              // normalised
