@@ -112,6 +112,9 @@ __device__ __forceinline__ float seqs_sum(float v) {
     return __uint_as_float(h[0]) + __uint_as_float(h[1]);
 }
 
+// The parked records are WAVE-PRIVATE: written by the tail lanes of a wave's own sequences into those sequences' column
+// records and read back (the fold after the row loop) by lanes of the same wave -- same-wave LDS operations complete in order,
+// no barrier or s_waitcnt is needed between the store and that read.  A consumer in another wave would need both.
 // v[k] -> LDS word (addr + k * STRIDE_BYTES), k < 4, from the lanes in `mask` only.  EXEC is narrowed inside the statement, so
 // there is no branch: the row steps of an iteration stay one scheduling region, and the LDS pipe sees 4 lanes instead of 64.
 template <int STRIDE_BYTES>
@@ -127,7 +130,7 @@ __device__ __forceinline__ void lds_store4_masked(unsigned addr, float v0, float
                  : "=&s"(save)
                  : "s"(mask), "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(0), "n"(STRIDE_BYTES), "n"(2 * STRIDE_BYTES),
                    "n"(3 * STRIDE_BYTES)
-                 : "scc");
+                 : "scc", "memory");                              // (LDS stores the compiler must not move loads across)
 }
 
 struct SweepArgs {
@@ -807,6 +810,9 @@ __device__ __forceinline__ void relfix_body(const RelfixArgs& a, const int blk, 
             const double mq = a.ss.mean[cq], rq = a.ss.rstd[cq], mk = a.ss.mean[ckk], rk = a.ss.rstd[ckk];
             const double s1q = count * mq, s2q = count * (1.0 / (rq * rq) - (double)a.eps + mq * mq);
             const double s1k = count * mk, s2k = count * (1.0 / (rk * rk) - (double)a.eps + mk * mk);
+            // d f = e T + (u S2 + w S1) / f with S1, S2 the sums of the GATED logits from the saved statistics.  At f == 0 the
+            // gated logits are identically 0: mean(dY xhat) = 0 and mean(dY) = 0 (softmax rows), so u = w = 0 EXACTLY and e T is
+            // the whole gradient -- the skipped term is 0, not an approximation (tests: test_layer_zero_gate_gradients).
             if (f_qr != 0.f) gq += ((double)cr[1] * s2q + (double)cr[2] * s1q) / f_qr;
             if (f_kr != 0.f) gk += ((double)ck[1] * s2k + (double)ck[2] * s1k) / f_kr;
         }
@@ -863,6 +869,9 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     if (g.gp == 2 && (g.L == 32 || g.L == 64 || g.L == 128)) ls = g.L == 32 ? 8 : 16;
     else if (g.gp == 4 && (g.L == 32 || g.L == 64)) ls = g.L == 32 ? 8 : 16;
     if (!ls) return false;
+    // the sweep / fix kernels address qkv_raw, stacked and dqkv with 32-bit byte offsets (saddr + voffset): tensors of 4 GiB
+    // and more take the generic kernels (size_t arithmetic)
+    if ((size_t)g.N * 2 * g.C * g.HW * 4 > 0xffffffffull) return false;
     static const int env_nw = [] { const char* e = getenv("MEDT_BWD_NW"); return e ? atoi(e) : 0; }();
     static const int env_cap = [] { const char* e = getenv("MEDT_BWD_CAP"); return e ? atoi(e) : 2048; }();
     const int spw = 64 / ls;

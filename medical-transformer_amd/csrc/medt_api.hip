@@ -336,8 +336,11 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
                               w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
     // softmax / bn_similarity / logits backward: dqkv, the partial rows of bn_qkv's backward, of the tables and of the gates
+    // (sigmoid gates: the gate reduction + sigmoid backward below run immediately and read what the relfix kernel writes,
+    //  so that kernel must not be recorded for the flush -- MEDT_DEFER_RELFIX=1 -- in that mode)
+    Queue* relfix_q = (d->gate_mode == 1 && p->f_qr && gr->gates) ? nullptr : queue_for(s);
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
-                                 gr->bn_sim_weight, gr->bn_sim_bias, s, queue_for(s)))) return rc;
+                                 gr->bn_sim_weight, gr->bn_sim_bias, s, relfix_q))) return rc;
     // bn_qkv backward, qkv_transform backward
     if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                               w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;

@@ -133,6 +133,12 @@ class FlatAdam:
         Parameters whose backward kernel wrote its slot directly need nothing (the normal case: zero launches);
         parameters that received their first gradient are adopted into a new group; gradients that arrived through
         plain autograd (a module that is not slot-aware) are copied into their slot."""
+        if not self.step_open:
+            # No FlatAdam.zero_grad() since the last pack: the backward (if any) ran outside the slot window -- e.g.
+            # model.zero_grad() + a hand-written loop -- so `live()` kept the kernels off the slots and every gradient
+            # travelled through autograd's `.grad`.  The slots still carry the PREVIOUS step's stamp and contents; a new
+            # stamp makes them stale, so a fresh `.grad` tensor below REPLACES the slot instead of being added to it.
+            self.stamp += 1
         self._adopt_new()
         self.step_open = False
         for g in self.groups:
@@ -143,8 +149,9 @@ class FlatAdam:
                     if p.grad is not None and p.grad is not s.view:          # both routes contributed
                         s.view.add_(p.grad)
                 elif p.grad is not None:
-                    dst.append(s.view)
-                    src.append(p.grad)
+                    if p.grad is not s.view:         # (`.grad` still being the slot = autograd accumulated in place)
+                        dst.append(s.view)
+                        src.append(p.grad)
                     s.stamp = self.stamp
                 elif p.requires_grad:
                     raise L.MedtError("FlatAdam: a parameter that used to receive gradients did not this step")

@@ -374,3 +374,22 @@ def test_layer_backward_is_bit_reproducible(case, device):
             assert torch.equal(runs[0][k], runs[1][k]), k
         else:
             assert H.rel_err(runs[1][k], runs[0][k]) < 1e-6, k
+
+
+@pytest.mark.parametrize("zero", ["f_qr", "f_kr", "both"])
+@pytest.mark.parametrize("C,L,width", [(16, 64, True), (32, 32, False), (64, 16, True)], ids=["sweep-gp2", "sweep-gp4", "generic-gp8"])
+def test_layer_zero_gate_gradients(zero, C, L, width, device):
+    """a gate that is exactly 0.  The single-sweep backward forms the gate gradient as e T + (u S2 + w S1) / f
+    from the saved statistics of the GATED logits and skips the second term at f == 0; that term is exactly 0 there (the
+    gated logits are constant, so bn_similarity's backward means vanish), and every gradient -- the zeroed gate's own
+    included -- must still match the oracle, which differentiates through the gate like the reference's autograd."""
+    layer = make_layer("dynamic", C, L, width, 1, device)
+    st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 41 + C)
+    for k in (("f_qr", "f_kr") if zero == "both" else (zero,)):
+        st[k] = torch.zeros_like(st[k])
+    g = torch.Generator().manual_seed(23)
+    shape = (2, C, 6, L) if width else (2, C, L, 6)
+    x = torch.randn(shape, generator=g)
+    dout = torch.randn(shape, generator=g)
+    got, want = run_case(layer, st, x, dout, "dynamic", width, 1, device, True)
+    compare(got, want)

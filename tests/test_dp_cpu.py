@@ -191,3 +191,31 @@ def test_flatadam_slot_window_and_frozen_parameters():
     (a.sum()).backward()
     with pytest.raises(MedtError):
         opt.pack_gradients()
+
+
+def test_flatadam_backward_outside_the_slot_window_replaces_the_bucket():
+    """zero_grad / backward / pack, then `model.zero_grad()` (torch's, not FlatAdam's) + a hand-written
+    backward + pack: the gradients of that second backward arrive as fresh `.grad` tensors while the slots still hold the
+    first step's gradient under the first step's stamp.  The bucket must then hold G_new, not G_prev + G_new; and a backward
+    with NO zero_grad at all must accumulate (torch semantics: `.grad` is the slot, autograd adds in place)."""
+    from medt_amd import optim as OPT
+    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+    opt = OPT.FlatAdam([a, b])
+    opt.zero_grad()
+    (a.sum() * 2 + b.sum() * 3).backward()
+    opt.pack_gradients()
+    flat = opt.groups[0].flat_g
+    assert torch.equal(flat, torch.tensor([2.0, 2, 2, 3, 3]))
+    for p in (a, b):                                        # what nn.Module.zero_grad() does
+        p.grad = None
+    (a.sum() * 5 + b.sum() * 7).backward()
+    opt.pack_gradients()
+    assert torch.equal(flat, torch.tensor([5.0, 5, 5, 7, 7])), flat
+    assert a.grad.data_ptr() == flat.data_ptr()
+    (a.sum() * 1 + b.sum() * 1).backward()                  # no zero_grad of any kind: accumulation, as in torch
+    opt.pack_gradients()
+    assert torch.equal(flat, torch.tensor([6.0, 6, 6, 8, 8])), flat
+    opt.zero_grad()                                         # and the normal protocol still works afterwards
+    (a.sum() * 4 + b.sum() * 4).backward()
+    opt.pack_gradients()
+    assert torch.equal(flat, torch.tensor([4.0, 4, 4, 4, 4])), flat
