@@ -377,7 +377,18 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():
+        # Orderly teardown.  The captured hipGraph holds RCCL kernel nodes that reference the communicator: release the
+        # graphs (and their private memory pool) and drain the device BEFORE the process group is destroyed, instead of
+        # leaving the order to interpreter exit (round 3 saw the torchrun worker SIGABRT at exit about once in ten launches).
+        train_step._graphs.clear()
+        del train_step
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+        log("process group destroyed")
 
 
 if __name__ == "__main__":

@@ -15,8 +15,10 @@ Everything an fixture consumer needs to rebuild the inputs is a (seed, shape)
 pair: tests regenerate x / y / state_dict with the same CPU generators and
 compare against the stored results; a checksum of x guards the RNG contract.
 Full gradients would be ~6 MB per model, so model-level fixtures store, per
-parameter, [L2 norm, <grad, r>] with r a seeded N(0,1) vector, plus the full
-gradient of a few small tensors; layer-level fixtures store everything.
+parameter, the L2 norm and NPROBE = 8 dot products <grad, r_j> with seeded
+N(0,1) vectors r_j, plus the full gradient of every tensor of up to 512
+elements and of the position tables / gates; layer-level fixtures store
+everything.
 """
 from __future__ import annotations
 
@@ -44,6 +46,16 @@ def probe_vector(name: str, numel: int, seed: int) -> torch.Tensor:
     h = (sum(ord(c) * (i + 1) for i, c in enumerate(name)) + seed) % (2 ** 31)
     g = torch.Generator().manual_seed(h)
     return torch.randn(numel, generator=g, dtype=torch.float64)
+
+
+NPROBE = 8           # seeded probe vectors per gradient tensor (round 4: one probe + the norm left norm-preserving errors of the
+                     # big tensors to a single 3-sigma test; eight independent dots pin an 8-dimensional projection of each)
+FULL_GRAD_MAX = 512  # and every gradient tensor up to this size is stored in full (BatchNorm vectors, gates, small kernels)
+
+
+def probe_matrix(name: str, numel: int, seed: int) -> torch.Tensor:
+    """(NPROBE, numel): row 0 is probe_vector(name) (the round-1..3 probe), row j > 0 probe_vector(name + '#j')."""
+    return torch.stack([probe_vector(name if j == 0 else f"{name}#{j}", numel, seed) for j in range(NPROBE)])
 
 
 FULL_GRAD_KEYS = ("relative", "f_qr", "f_kr", "f_sv", "f_sve", "bn_similarity.weight", "adjust.weight", "adjust.bias")
@@ -119,23 +131,27 @@ def model_fixture(model_name, S, N, seed, mode):
         return fx
     fx["loss"] = np.array([loss.item()])
     p32 = dict(ref32.named_parameters())
-    names, summ, noise = [], [], []
+    names, summ, noise, dots, dots_noise = [], [], [], [], []
     for k, p in ref.named_parameters():
         if p.grad is None:
             continue
         g = p.grad.reshape(-1)
         g32 = p32[k].grad.double().reshape(-1)
-        r = probe_vector(k, g.numel(), seed)
+        R = probe_matrix(k, g.numel(), seed)
         names.append(k)
-        summ.append([g.norm().item(), torch.dot(g, r).item()])
+        summ.append([g.norm().item(), torch.dot(g, R[0]).item()])
         gs = [g32] + [px[k].grad.double().reshape(-1) for px in p32x]
-        noise.append([max((gg - g).norm().item() for gg in gs), max(abs(torch.dot(gg - g, r).item()) for gg in gs)])
-        if k.endswith(FULL_GRAD_KEYS) and g.numel() <= 4096:
+        noise.append([max((gg - g).norm().item() for gg in gs), max(abs(torch.dot(gg - g, R[0]).item()) for gg in gs)])
+        dots.append((R @ g).numpy())
+        dots_noise.append(max((R @ (gg - g)).abs().max().item() for gg in gs))
+        if (k.endswith(FULL_GRAD_KEYS) and g.numel() <= 4096) or g.numel() <= FULL_GRAD_MAX:
             fx["grad/" + k] = p.grad.detach().numpy()
             fx["gradnoise/" + k] = np.array([max((gg - g).abs().max().item() for gg in gs)])
     fx["grad_names"] = np.array(names)
     fx["grad_summary"] = np.array(summ)
     fx["grad_noise"] = np.array(noise)
+    fx["grad_dots"] = np.array(dots)                     # (tensors, NPROBE)
+    fx["grad_dots_noise"] = np.array(dots_noise)         # (tensors,): max over probes and float32 runs
     if mode == "train":
         bnames, bsumm, bnoise = [], [], []
         sds = [ref32.state_dict()] + [r[0].state_dict() for r in extra]
@@ -247,6 +263,7 @@ def main():
         ("MedT", 128, 2, 102, "train"),
         ("MedT", 128, 2, 102, "evalgrad"),
         ("MedT", 128, 4, 106, "train"),          # the benchmarked workload itself: BASELINE configs[2], train mode, bs 4
+        ("gatedaxialunet", 128, 8, 107, "train"),    # BASELINE configs[1]'s real mode: gatedaxialunet bs 8, train (fp32 + bf16 storage)
         ("axialunet", 64, 2, 103, "train"),
         ("logo", 128, 1, 104, "evalgrad"),
         ("MedT", 256, 1, 105, "eval"),

@@ -52,6 +52,14 @@ def probe_vector(name: str, numel: int, seed: int) -> torch.Tensor:
     return torch.randn(numel, generator=g, dtype=torch.float64)
 
 
+NPROBE = 8
+
+
+def probe_matrix(name: str, numel: int, seed: int) -> torch.Tensor:
+    """(NPROBE, numel): the probes of tests/golden/make_golden.py (row 0 = probe_vector(name))."""
+    return torch.stack([probe_vector(name if j == 0 else f"{name}#{j}", numel, seed) for j in range(NPROBE)])
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 

@@ -84,6 +84,10 @@ def test_model_oracle_matches_reference_fixture(fn):
         g = st[k].grad.reshape(-1)
         assert abs(g.norm().item() - norm) < 1e-8 * gmax + 1e-9 * norm, k
         assert abs(torch.dot(g, H.probe_vector(k, g.numel(), seed)).item() - dot) < 1e-7 * gmax * g.numel() ** 0.5, k
+    for k, dots in zip(names, fx["grad_dots"]):              # the eight probe dots of every gradient tensor
+        g = st[k].grad.reshape(-1)
+        got = H.probe_matrix(k, g.numel(), seed) @ g
+        assert (got - torch.from_numpy(dots)).abs().max().item() < 1e-7 * gmax * g.numel() ** 0.5, k
     for k in fx:
         if k.startswith("grad/"):
             assert (st[k[5:]].grad - torch.from_numpy(fx[k])).abs().max().item() < 1e-9 * gmax + 1e-12, k
