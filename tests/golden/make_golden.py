@@ -171,6 +171,30 @@ def model_fixture(model_name, S, N, seed, mode):
     return fx
 
 
+def sensitivity_fixture(model_name, S, N, seed):
+    """How far the REFERENCE's own float64 training-mode logits move when its input image is perturbed by one rounding of a
+    given precision (relative +-eps, uniform): the conditioning of the train-mode network (batch-statistic BatchNorm through
+    ~100 layers).  eps = 2^-9 is ONE bfloat16 rounding of the input -- what any bf16 storage inside the network amounts to
+    at the very least; GPU tests of bf16 storage in training mode are judged against this, not against a fixed tolerance."""
+    torch.manual_seed(seed)
+    ref = ref_loader.factory(model_name)(img_size=S, imgchan=3)
+    ref.load_state_dict(O.randomize_state(ref.state_dict(), seed))
+    ref = ref.double()
+    ref.train()
+    x, _ = seeded_input(seed + 1, N, 3, S)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    with torch.no_grad():
+        base = ref(x.double())
+        out = {}
+        for name, eps in (("f32", 2.0 ** -24), ("2^-16", 2.0 ** -16), ("bf16", 2.0 ** -9)):
+            ref.load_state_dict(sd0)                       # (running statistics moved by the previous forward)
+            g = torch.Generator().manual_seed(5)
+            xp = x.double() * (1 + eps * (torch.rand(x.shape, generator=g, dtype=torch.float64) * 2 - 1))
+            out[name] = ((ref(xp) - base).abs().max() / base.abs().max()).item()
+    return {"model": model_name, "S": S, "N": N, "seed": seed, "mode": "train",
+            "logits_rel_change_for_input_rounding": out}
+
+
 def layer_fixture(kind, C, L, width, stride, N, seed):
     """One attention layer of the reference, everything stored in full (float64)."""
     ax = ref_loader.load()
@@ -268,6 +292,11 @@ def main():
         ("logo", 128, 1, 104, "evalgrad"),
         ("MedT", 256, 1, 105, "eval"),
     ]
+    if "sensitivity_gatedaxialunet_S128_N8.json".startswith(only):
+        import json
+        with open(os.path.join(HERE, "sensitivity_gatedaxialunet_S128_N8.json"), "w") as f:
+            json.dump(sensitivity_fixture("gatedaxialunet", 128, 8, 107), f, indent=1)
+        print("wrote sensitivity_gatedaxialunet_S128_N8.json")
     for name, S, N, seed, mode in model_cases:
         fn = f"model_{name}_S{S}_N{N}_{mode}.npz"
         if not fn.startswith(only):
