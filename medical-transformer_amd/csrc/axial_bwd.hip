@@ -904,6 +904,7 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
                          float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s) {
+    if (abl_skip("sweep")) return MEDT_OK;
     SweepArgs a;
     a.g = g;
     a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.relative = relative; a.out_coef = out_coef;

@@ -873,6 +873,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
 
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                    GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
+    if (abl_skip("attn_fwd")) return MEDT_OK;
     if (fast_path_enabled() && gates.stride == 0) {            // (per-sequence gates: generic kernel)
         const int rc = g.bf16 ? axial_attn_fwd_fast_bf16(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s)
                               : axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s);

@@ -434,6 +434,7 @@ bool wopos_small_ok(const AxialGeom& g, const medt_axial_desc& d) {
 int wopos_small_fwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axial_params& p, const float* x, float* y,
                     float* qkv_raw, float* stacked, float* lse, float* part_q, float* part_s, float* part_o,
                     hipStream_t s) {
+    if (abl_skip("wopos_fwd")) return MEDT_OK;
     SmallFwdArgs a;
     a.x = x; a.w = p.w_qkv;
     a.bq = p.bn_qkv; a.bs = p.bn_similarity; a.bo = p.bn_output;
@@ -808,6 +809,7 @@ int wopos_small_bwd(const AxialGeom& g, const medt_axial_desc& d, const medt_axi
                     const float* dy, const float* qkv_raw, const float* stacked, const float* lse, BnStats sq, BnStats ss,
                     BnStats so, float* dqkv, float* part_ob, float* part_sb, float* part_qb, float* coef_qkv,
                     hipStream_t s) {
+    if (abl_skip("wopos_bwd")) return MEDT_OK;
     SmallBwdArgs a;
     a.w_qkv_bn = p.bn_qkv.weight; a.coef_qkv = coef_qkv; a.row_count = g.row_count;
     a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.y = y;

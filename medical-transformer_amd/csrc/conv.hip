@@ -274,6 +274,7 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
                int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
                int y_bf16) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    if (abl_skip(N >= 16 ? (K == 3 ? "conv3_fwd_l" : (K == 1 ? "conv1_fwd_l" : "conv7_fwd_l")) : (K == 3 ? "conv3_fwd_g" : (K == 1 ? "conv1_fwd_g" : "conv7_fwd_g")))) return MEDT_OK;
     if (!y_bf16 && conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
         (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
         return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
@@ -532,6 +533,7 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
                     int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    if (abl_skip(N >= 16 ? (K == 3 ? "conv3_dgrad_l" : "conv1_dgrad_l") : (K == 3 ? "conv3_dgrad_g" : "conv1_dgrad_g"))) return MEDT_OK;
     // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K   (the `add` epilogue is VALU-path only)
     if (!add && wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) &&
         (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K) == 0))

@@ -430,6 +430,7 @@ int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, f
     }
     const dim3 grid((unsigned)qt, cdiv(Cout, 64), ks), block(MEDT_THREADS);
     if (ks == 1 && (N / groups) * Ho * Wo % 64 == 0 && conv_rows16_ok(Cin, H, W, K, stride, pad)) {
+        if (abl_skip("rows16")) return MEDT_OK;
         hipLaunchKernelGGL(conv3x3_rows16_fwd_kernel, dim3((unsigned)qt, cdiv(Cout, 64)), block, 0, s, x, w, bias, y,
                            partials, Cin, H, Cout, relu);
         return launch_status("conv3x3_rows16_fwd");
@@ -763,6 +764,7 @@ int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const 
                     int H, int W, int Cout, int Ho, int Wo, int K, int stride, int pad, int QS, int splits, int npg,
                     hipStream_t s) {
     const dim3 grid(cdiv(Cout, 64), cdiv(Cin * K * K, 64), splits), block(MEDT_THREADS);
+    if (abl_skip(N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
     if (QS % 64 == 0 && Ho == H && Wo == W && conv_rows16_ok(Cin, H, W, K, stride, pad)) {
         hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel, dim3(cdiv(Cout, 64), Cin / 16, splits), block, 0, s, dy, raw, coef,
                            x, scratch, Cin, H, Cout, QS / 64, N * H / 4, npg);

@@ -275,6 +275,7 @@ bool conv_small_ok(const medt_conv_desc& d) {
 
 int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,
                    float* z, float* y, float* partials, hipStream_t s) {
+    if (abl_skip("conv_small_fwd")) return MEDT_OK;
     SmallConvArgs a;
     a.x = x; a.w = w; a.res = d.has_res ? res : nullptr; a.bn = bn; a.z = z; a.y = y; a.partials = partials;
     a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.stride = d.stride; a.npg = d.N / d.bn_groups;
@@ -448,5 +449,239 @@ int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, c
     hipLaunchKernelGGL(bn_act_bwd_small_kernel, dim3(d.bn_groups, cdiv(d.Cout, MEDT_WAVES)), dim3(MEDT_THREADS), 0, s, a);
     return launch_status("bn_act_bwd_small");
 }
+
+// --------------------------------------------------------------------------- //
+// BatchNorm (+ ReLU mask) backward AND the 1x1 backward-data behind it in ONE launch (round 4).
+// On the local branch's backward chain every conv_down / conv_up block was two dependent launches: bn_act_bwd_small
+// (one wave per (group, channel): mask, the two sums, dz) and a 1x1 dgrad (5 + 5..14 us for a few hundred KFLOP).  The
+// BatchNorm population of these blocks is one patch group, so a workgroup can redo the whole group's statistics itself:
+// workgroup (group, tile of CT input channels) reads dy | y | z of ALL Cout channels of its group once (<= 32 values per
+// thread, float4), reduces the two sums per channel over the TPC lanes that share a channel, forms dz = c0*g + c1*z + c2 in
+// registers, parks it in LDS as [Cout][P] and contracts it with its weight slice: dx[ci, q] = sum_o w[o, ci] dz[o, q]
+// (+ the fan-in deposit dx_add).  The statistics are recomputed Cin / CT (= 8) times per group -- a few hundred KB of L2
+// reads -- instead of travelling through a second launch; tile 0 also writes g (= d(res)), dz (the recorded weight
+// gradient reads it) and the per-group partial sums (BatchNorm parameter gradients, recorded finalisation).
+// Same coefficient arithmetic as bn_act_bwd_small_kernel / bn_bwd_coef.
+// --------------------------------------------------------------------------- //
+struct BnDgradArgs {
+    const float *dy, *y, *z, *gamma, *w, *dx_add;
+    BnStats st;
+    float *g, *dz, *partials, *dx;
+    int Cout, Cin, HW, npg, relu, training, E, CT;      // E values per thread (multiple of 4), CT input channels per workgroup
+};
+
+template <int T, int CPT>                               // CPT input channels per thread = CT / (T / P)
+__global__ __launch_bounds__(T) void bn_dgrad1x1_small_kernel(BnDgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int E4MAX = T == 1024 ? 4 : 8;
+    const int grp = blockIdx.x, ci0 = blockIdx.y * a.CT, tid = threadIdx.x;
+    const int Cout = a.Cout, HW = a.HW, P = a.npg * HW, n0 = grp * a.npg, CT = a.CT;
+    const int E4 = a.E >> 2, TPC = P / a.E;             // threads per channel (power of two, <= 64)
+    float* Dz = smem;                                   // [Cout][P]
+    float* Wl = Dz + (size_t)Cout * P;                  // [Cout][CT]
+    const int c = tid / TPC, tq = tid - c * TPC;
+    const int gc = grp * Cout + c;
+    // every global value of the statistics phase in one batch: dy, y, z of this thread's E positions of channel c, the
+    // channel's saved statistics, and the weight slice (consumed last)
+    float4 dv[E4MAX], zv[E4MAX], yv[E4MAX];
+    size_t at[E4MAX];
+#pragma unroll
+    for (int j = 0; j < E4MAX; ++j) {
+        const int q = 4 * (tq + min(j, E4 - 1) * TPC), ni = q / HW, p = q - ni * HW;       // HW % 4 == 0: one plane per float4
+        at[j] = ((size_t)(n0 + ni) * Cout + c) * HW + p;
+        dv[j] = *reinterpret_cast<const float4*>(a.dy + at[j]);
+        zv[j] = *reinterpret_cast<const float4*>(a.z + at[j]);
+        if (a.relu) yv[j] = *reinterpret_cast<const float4*>(a.y + at[j]);
+    }
+    const float mean = a.st.mean[gc], rstd = a.st.rstd[gc], gam = a.gamma[c];
+    constexpr int WB = 8;
+    const int nW = Cout * CT;
+    float wr[WB];
+#pragma unroll
+    for (int k = 0; k < WB; ++k) {
+        const int e = min(tid + k * T, nW - 1), oc = e / CT;
+        wr[k] = a.w[(size_t)oc * a.Cin + ci0 + (e - oc * CT)];
+    }
+    MEDT_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < WB; ++k) {
+        const int e = tid + k * T;
+        if (e < nW) Wl[e] = wr[k];
+    }
+    for (int base = WB * T; base < nW; base += WB * T) {
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int e = min(base + tid + k * T, nW - 1), oc = e / CT;
+            wr[k] = a.w[(size_t)oc * a.Cin + ci0 + (e - oc * CT)];
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int e = base + tid + k * T;
+            if (e < nW) Wl[e] = wr[k];
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < E4MAX; ++j) {
+        if (j < E4) {
+            float4 d = dv[j];
+            if (a.relu) {
+                if (!(yv[j].x > 0.f)) d.x = 0.f;
+                if (!(yv[j].y > 0.f)) d.y = 0.f;
+                if (!(yv[j].z > 0.f)) d.z = 0.f;
+                if (!(yv[j].w > 0.f)) d.w = 0.f;
+            }
+            dv[j] = d;
+            s1 += (d.x + d.y) + (d.z + d.w);
+            s2 = fmaf(d.x, (zv[j].x - mean) * rstd, s2);
+            s2 = fmaf(d.y, (zv[j].y - mean) * rstd, s2);
+            s2 = fmaf(d.z, (zv[j].z - mean) * rstd, s2);
+            s2 = fmaf(d.w, (zv[j].w - mean) * rstd, s2);
+        }
+    }
+    for (int o = TPC >> 1; o > 0; o >>= 1) {            // the TPC lanes of a channel are an aligned run inside one wave
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    // same arithmetic as bn_bwd_coef (medt_common.h), dscale = 1
+    const double A = (double)gam * (double)rstd;
+    float c0 = (float)A, c1 = 0.f, c2 = 0.f;
+    if (a.training) {
+        const double m1 = (double)s1 / (double)P, m2 = (double)s2 / (double)P;
+        c1 = (float)(-A * (double)rstd * m2);
+        c2 = (float)(A * ((double)rstd * (double)mean * m2 - m1));
+    }
+    const bool writer = blockIdx.y == 0;
+    if (writer && tq == 0) {
+        a.partials[(size_t)gc * 2] = s1;
+        a.partials[(size_t)gc * 2 + 1] = s2;
+    }
+#pragma unroll
+    for (int j = 0; j < E4MAX; ++j) {
+        if (j < E4) {
+            float4 o;
+            o.x = fmaf(c0, dv[j].x, fmaf(c1, zv[j].x, c2));
+            o.y = fmaf(c0, dv[j].y, fmaf(c1, zv[j].y, c2));
+            o.z = fmaf(c0, dv[j].z, fmaf(c1, zv[j].z, c2));
+            o.w = fmaf(c0, dv[j].w, fmaf(c1, zv[j].w, c2));
+            *reinterpret_cast<float4*>(Dz + (size_t)c * P + 4 * (tq + j * TPC)) = o;
+            if (writer) {
+                *reinterpret_cast<float4*>(a.dz + at[j]) = o;
+                if (a.g) *reinterpret_cast<float4*>(a.g + at[j]) = dv[j];
+            }
+        }
+    }
+    // the contraction: thread (q, r) owns CPT input channels of position q
+    const int q = tid % P, r = tid / P;                 // P <= T, T / P groups of CPT channels each (= CT)
+    const int ni = q / HW, p = q - ni * HW;
+    const int cl = r * CPT;                             // first local input channel of this thread
+    const bool act = cl < CT;
+    float addv[CPT];
+    if (a.dx_add && act) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) addv[i] = a.dx_add[((size_t)(n0 + ni) * a.Cin + ci0 + cl + i) * HW + p];
+    }
+    __syncthreads();
+    float acc[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) acc[i] = 0.f;
+    if (act) {
+        const float* dzq = Dz + q;
+        const float* wq = Wl + cl;
+#pragma unroll 8
+        for (int o = 0; o < Cout; ++o) {
+            const float v = dzq[(size_t)o * P];
+            if constexpr (CPT == 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wq + o * CT);
+                acc[0] = fmaf(w4.x, v, acc[0]);
+                acc[1] = fmaf(w4.y, v, acc[1]);
+                acc[2] = fmaf(w4.z, v, acc[2]);
+                acc[3] = fmaf(w4.w, v, acc[3]);
+            } else if constexpr (CPT == 2) {
+                const float2 w2 = *reinterpret_cast<const float2*>(wq + o * CT);
+                acc[0] = fmaf(w2.x, v, acc[0]);
+                acc[1] = fmaf(w2.y, v, acc[1]);
+            } else {
+                acc[0] = fmaf(wq[o * CT], v, acc[0]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            float v = acc[i];
+            if (a.dx_add) v += addv[i];
+            a.dx[((size_t)(n0 + ni) * a.Cin + ci0 + cl + i) * HW + p] = v;
+        }
+    }
+}
+
+struct BnDgradPlan { int T, E, CT, CPT; size_t lds; };
+
+static bool bn_dgrad_fused_enabled() {
+    static const bool on = [] { const char* e = getenv("MEDT_BN_DGRAD_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// Applies to the conv_small blocks (1x1, no bias, BatchNorm group <= 1024 positions) with stride 1 whose group tile
+// Cout x P fits 32 values per thread and the workgroup's LDS.
+static bool bn_dgrad1x1_plan(const medt_conv_desc& d, BnDgradPlan* pl) {
+    if (!bn_dgrad_fused_enabled() || !conv_small_ok(d) || d.stride != 1 || d.K != 1) return false;
+    const int HW = d.H * d.W, P = (d.N / d.bn_groups) * HW;
+    if ((HW & 3) || (P & (P - 1))) return false;
+    const long tile = (long)d.Cout * P;
+    int T = 256;
+    while (T < 1024 && tile / T > 32) T <<= 1;
+    const long E = tile / T;
+    if (tile % T || E > (T == 1024 ? 16 : 32) || E < 4 || (E & (E - 1)) || P % E || P / E > 64 || P > T) return false;
+    const int R = T / P;                                // thread groups over the positions
+    int CT = d.Cin / 8 > R ? d.Cin / 8 : R;             // eight tiles per group when the contraction allows it
+    if (CT > 4 * R) CT = 4 * R;
+    if (d.Cin % CT || CT % R) return false;
+    const int CPT = CT / R;
+    if (CPT != 1 && CPT != 2 && CPT != 4) return false;
+    pl->T = T; pl->E = (int)E; pl->CT = CT; pl->CPT = CPT;
+    pl->lds = ((size_t)tile + (size_t)d.Cout * CT) * sizeof(float);
+    return pl->lds <= 150 * 1024;
+}
+
+bool bn_dgrad1x1_small_ok(const medt_conv_desc& d) {
+    BnDgradPlan pl;
+    return bn_dgrad1x1_plan(d, &pl);
+}
+
+int bn_dgrad1x1_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
+                      const float* gamma, const float* w, const float* dx_add, float* g, float* dz, float* partials,
+                      float* dx, hipStream_t s) {
+    BnDgradPlan pl;
+    if (!bn_dgrad1x1_plan(d, &pl)) { set_error("bn_dgrad1x1_small: shape not supported"); return MEDT_EUNSUPPORTED; }
+    if (abl_skip("bn_dgrad")) return MEDT_OK;
+    BnDgradArgs a;
+    a.dy = dy; a.y = y; a.z = z; a.gamma = gamma; a.w = w; a.dx_add = dx_add; a.st = st;
+    a.g = g; a.dz = dz; a.partials = partials; a.dx = dx;
+    a.Cout = d.Cout; a.Cin = d.Cin; a.HW = d.H * d.W; a.npg = d.N / d.bn_groups; a.relu = d.relu;
+    a.training = d.training ? 1 : 0; a.E = pl.E; a.CT = pl.CT;
+    const dim3 grid(d.bn_groups, d.Cin / pl.CT);
+#define MEDT_BND(TT, CP)                                                                                              \
+    do {                                                                                                              \
+        static bool attr = false;                                                                                     \
+        if (!attr) {          /* more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU) */            \
+            (void)hipFuncSetAttribute((const void*)bn_dgrad1x1_small_kernel<TT, CP>,                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+            attr = true;                                                                                              \
+        }                                                                                                             \
+        hipLaunchKernelGGL((bn_dgrad1x1_small_kernel<TT, CP>), grid, dim3(TT), pl.lds, s, a);                         \
+    } while (0)
+#define MEDT_BND_T(TT)                                                                                                \
+    switch (pl.CPT) {                                                                                                 \
+        case 1: MEDT_BND(TT, 1); break;                                                                               \
+        case 2: MEDT_BND(TT, 2); break;                                                                               \
+        default: MEDT_BND(TT, 4); break;                                                                              \
+    }
+    if (pl.T == 256) { MEDT_BND_T(256) } else if (pl.T == 512) { MEDT_BND_T(512) } else { MEDT_BND_T(1024) }
+#undef MEDT_BND_T
+#undef MEDT_BND
+    return launch_status("bn_dgrad1x1_small");
+}
+
 
 }  // namespace medt

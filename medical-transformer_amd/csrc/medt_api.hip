@@ -15,6 +15,19 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+bool abl_skip(const char* family) {
+    static const char* env = getenv("MEDT_SKIP");
+    if (!env || !*env) return false;
+    const size_t n = strlen(family);
+    for (const char* p = env; *p;) {
+        const char* e = strchr(p, ',');
+        const size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == n && strncmp(p, family, n) == 0) return true;
+        p += len + (e ? 1 : 0);
+    }
+    return false;
+}
+
 int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -505,6 +518,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     if (!ws || !c.ok()) { set_error("conv workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     const float* grad_out;              // gradient wrt the convolution output
+    bool dx_done = false;               // the BatchNorm-backward kernel also produced dx
     if (d->has_bn) {
         BnStats st(const_cast<float*>(stats), d->bn_groups * d->Cout);
         float* gb = (d->has_res && dres) ? dres : cw.gbuf;        // d(res) == the ReLU-masked incoming gradient
@@ -514,7 +528,12 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         if (small || (aligned && bn_chan_threads(*d, g.HoWo))) {
             // one wave (small blocks) or one workgroup per (group, channel): mask, sums, coefficients and dz in one
             // kernel; the finalisation only produces the parameter gradients (one partial slot per group)
-            if (small)
+            if (small && dx && aligned && bn_dgrad1x1_small_ok(*d)) {
+                // ... and the 1x1 backward-data behind it in the same launch (conv_small.hip, round 4)
+                rc = bn_dgrad1x1_small(*d, dy, y, z, st, bn->weight, w, dx_add, (d->has_res && dres) ? dres : nullptr,
+                                       cw.dz, cw.partials, dx, s);
+                dx_done = true;
+            } else if (small)
                 rc = bn_act_bwd_small(*d, dy, y, z, st, bn->weight, (d->has_res && dres) ? dres : nullptr, cw.dz,
                                       cw.partials, g.HoWo, s);
             else
@@ -542,7 +561,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     } else {
         grad_out = dy;
     }
-    if (dx && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s,
+    if (dx && !dx_done && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s,
                                     dx_add))) return rc;
     Queue* q = queue_for(s);          // parameter gradients: recorded for the grouped flush when a queue is bound
     if (d->has_bias) {

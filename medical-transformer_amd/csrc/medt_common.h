@@ -18,6 +18,9 @@ namespace medt {
 // ---- host side ------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int  launch_status(const char* what);          // hipGetLastError -> MEDT_ELAUNCH
+// TIMING EXPERIMENTS ONLY (scripts/r4_skip.sh): MEDT_SKIP=fam1,fam2 makes the host wrappers of those kernel families return
+// without launching, so the step time that disappears is the family's share of the critical path.  Results are garbage.
+bool abl_skip(const char* family);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int    cdiv(int a, int b) { return (a + b - 1) / b; }

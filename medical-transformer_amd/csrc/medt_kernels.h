@@ -154,6 +154,10 @@ int fast4_max_subtiles(int axis);
 bool conv_small_ok(const medt_conv_desc& d);
 int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,
                    float* z, float* y, float* partials, hipStream_t s);
+bool bn_dgrad1x1_small_ok(const medt_conv_desc& d);    // BatchNorm backward + the 1x1 backward-data behind it, one launch
+int bn_dgrad1x1_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
+                      const float* gamma, const float* w, const float* dx_add, float* g, float* dz, float* partials,
+                      float* dx, hipStream_t s);
 int bn_act_bwd_small(const medt_conv_desc& d, const float* dy, const float* y, const float* z, BnStats st,
                      const float* weight, float* g, float* dz, float* partials, int HoWo, hipStream_t s);
 // axial_small.hip: a whole position-free layer per (BN group, head) workgroup

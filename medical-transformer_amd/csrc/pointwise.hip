@@ -220,7 +220,14 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
     }
 }
 
+int conv1x1_bwd_data_impl(const float* dy, const float* raw, const float* coef, const float* w, float* dx, int N, int Cin,
+                          int Cout, int HW, int groups, hipStream_t s);
 int conv1x1_bwd_data(const float* dy, const float* raw, const float* coef, const float* w, float* dx, int N, int Cin,
+                     int Cout, int HW, int groups, hipStream_t s) {
+    if (abl_skip(groups > 1 ? "qkv_dgrad_l" : "qkv_dgrad_g")) return MEDT_OK;
+    return conv1x1_bwd_data_impl(dy, raw, coef, w, dx, N, Cin, Cout, HW, groups, s);
+}
+int conv1x1_bwd_data_impl(const float* dy, const float* raw, const float* coef, const float* w, float* dx, int N, int Cin,
                      int Cout, int HW, int groups, hipStream_t s) {
     const int npg = N / groups;
     const unsigned gx = (unsigned)(((long)N * HW + MEDT_THREADS - 1) / MEDT_THREADS);

@@ -27,6 +27,7 @@ class StepQueue:
         self._handles = {}             # stream -> queue handle (one shared handle under key None when not SPLIT)
         self._keep = {}                # handle -> tensors the recorded jobs point into
         self._bound = set()
+        self.issued = 0                # jobs handed to grouped launches so far (tests: the forward flushes per branch)
 
     def __del__(self):
         try:
@@ -60,6 +61,7 @@ class StepQueue:
         """Issue everything recorded so far on the current stream (all recording streams must have been joined into it)."""
         cur = torch.cuda.current_stream().cuda_stream
         for h in self._handles.values():
+            self.issued += int(L.lib().medt_queue_pending(h))
             L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
             self._keep[h].clear()
 
@@ -70,6 +72,7 @@ class StepQueue:
         cur = torch.cuda.current_stream().cuda_stream
         h = self._handles.get(cur)
         if h is not None:
+            self.issued += int(L.lib().medt_queue_pending(h))
             L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
             self._keep[h].clear()
 

@@ -17,6 +17,7 @@ import torch
 
 from ._lib import MedtError
 from . import ops
+from . import defer as DEFER
 
 import os
 
@@ -24,6 +25,7 @@ PATCH = 32          # hard-coded in the reference (:664)
 GRID = 4
 TWO_STREAMS = os.environ.get("MEDT_TWO_STREAMS", "1") != "0"
 SINKS = os.environ.get("MEDT_GRAD_SINKS", "1") != "0"       # gradient fan-in in dgrad epilogues (ops.GradSink)
+EARLY_FIN = os.environ.get("MEDT_EARLY_FIN", "1") != "0"    # forward bookkeeping flushed per branch, off the loss trunk
 _side = {}
 
 
@@ -116,6 +118,10 @@ def medt_forward(net, x):
     x2 = _layer(net.layer2, x1)
     y = ops.up2x_relu_add(ops.conv_block(x2, net.decoder4), x1, ops.sink_of(x1) if SINKS else None)
     y = ops.up2x_relu_add(ops.conv_block(y, net.decoder5), None)
+    if side is not None and EARLY_FIN:
+        # the global branch's forward ends here, ~100 us before the local one's: its recorded bookkeeping (running
+        # statistics) is issued now, while this stream would wait for the other, instead of after the loss
+        DEFER.flush_current_stream()
     # local branch: all 16 patches at once, patch-major on the batch dim, one BatchNorm group per patch.  In eval mode
     # the grouping does not change the result (running statistics); it is kept so the small per-group slices still
     # take the fused small-layer kernels (2 launches per layer instead of 6)
@@ -124,7 +130,17 @@ def medt_forward(net, x):
         with torch.cuda.stream(side):
             xp = ops.patch_gather(xin, PATCH, GRID)
             yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
-        main.wait_stream(side)
+            if EARLY_FIN:
+                # the local branch's recorded bookkeeping (saved statistics of the fused small layers, running statistics)
+                # is issued on ITS stream behind an event the merge waits for: it runs under the merge / decoderf / loss
+                # kernels of the main stream and still precedes the local backward, which is ordered on this stream
+                joined = torch.cuda.Event()
+                joined.record(side)
+                DEFER.flush_current_stream()
+        if EARLY_FIN:
+            main.wait_event(joined)
+        else:
+            main.wait_stream(side)
         yp.record_stream(main)
     else:
         xp = ops.patch_gather(xin, PATCH, GRID)

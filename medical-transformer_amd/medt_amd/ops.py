@@ -327,10 +327,13 @@ class CrossEntropyFn(torch.autograd.Function):
         ctx.ignore_index = ignore_index
         loss = out[0]
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)          # no zero-fill launch for the gradient of the non-differentiable output
         return loss, out
 
     @staticmethod
     def backward(ctx, dloss, _dout):
+        if dloss is None:
+            return None, None, None
         lib = L.lib()
         logits, target, out = ctx.saved_tensors
         N, K = logits.shape[0], logits.shape[1]

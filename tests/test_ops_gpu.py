@@ -59,6 +59,15 @@ CONV_CASES = [
     (8, 128, 3, 1, 1, False, True, False, True, 4, 64, 1),      # conv2 at BASELINE size (dgrad wave-split at 16384 positions)
     (64, 32, 3, 1, 1, True, False, False, False, 4, 32, 1),     # decoder4: bias, no BatchNorm
     (72, 24, 3, 2, 1, False, True, True, True, 6, 18, 3),       # ragged: stride 2, 81-position maps, grouped statistics
+    # MedT's local branch at BASELINE size (16 patch groups x 4 images): the BatchNorm backward + 1x1 dgrad of these blocks is
+    # ONE launch (bn_dgrad1x1_small_kernel: 256 / 512 threads, 1 / 2 / 4 input channels per thread)
+    (128, 64, 1, 1, 0, False, True, False, True, 64, 4, 16),    # layer3_p.1-3 conv_down (T=256, 16 values per thread)
+    (64, 128, 1, 1, 0, False, True, True, True, 64, 4, 16),     # layer3_p.1-3 conv_up + identity
+    (64, 32, 1, 1, 0, False, True, False, True, 64, 8, 16),     # layer2_p.1 conv_down (one thread group over the positions)
+    (32, 64, 1, 1, 0, False, True, True, True, 64, 8, 16),      # layer2_p.1 conv_up (T=512)
+    (64, 64, 1, 1, 0, False, True, False, True, 64, 8, 16),     # layer3_p.0 conv_down (T=512, 4 channels per thread)
+    (128, 256, 1, 1, 0, False, True, True, True, 64, 2, 16),    # layer4_p.0 conv_up on 2x2 maps (one thread per channel)
+    (128, 128, 1, 1, 0, False, True, False, True, 64, 4, 16),   # layer4_p.0 conv_down
 ]
 
 
