@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 6
+#define MEDT_ABI_VERSION 7
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -164,6 +164,47 @@ int medt_axial_core_fwd(const medt_axial_desc*, const medt_axial_params*, const 
  * bn_output / bn_similarity backward coefficients these passes read in the workspace).  Same kernels as the layer call. */
 int medt_axial_core_bwd(const medt_axial_desc*, const medt_axial_params*, const medt_axial_saved*, const float* dy,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * A whole AxialBlock_wopos forward as ONE launch (lib/models/axialnet.py:368-391):
+ *   y = relu( bn2(conv_up( relu(width_block(hight_block( relu(bn1(conv_down(x))) ))) )) + x )
+ * for the deep blocks of the LoGo local branch (:661-700), whose BatchNorm group (4 images on 4x4 maps) fits one
+ * workgroup: stride 1, no downsample, in_planes == out_planes == C, attention width `width`.  The saved tensors are
+ * exactly those medt_conv_block_fwd / medt_axial_layer_fwd would have produced for the four stages, so the backward runs
+ * through medt_conv_block_bwd / medt_axial_layer_bwd unchanged.  medt_wopos_block_workspace_bytes() returns 0 for shapes
+ * the fused kernel is not built for (the caller then uses the per-stage entry points).
+ * ------------------------------------------------------------------------- */
+typedef struct medt_block_desc {
+    int32_t N, C, width, H, W;   /* x, y: (N,C,H,W); the attention layers work on (N,width,H,W)      */
+    int32_t G;                   /* heads                                                            */
+    int32_t training, bn_groups; /* as in medt_axial_desc                                            */
+    float   eps, momentum;
+} medt_block_desc;
+
+typedef struct medt_block_params {
+    const float*      w_down;    /* conv_down.weight (width, C)                                 :355 */
+    medt_bn_ptrs      bn1;       /* BatchNorm2d(width)                                          :356 */
+    medt_axial_params height;    /* hight_block: w_qkv + the three BatchNorms (relative / f_* NULL)  */
+    medt_axial_params width;     /* width_block                                                      */
+    const float*      w_up;      /* conv_up.weight (C, width)                                   :359 */
+    medt_bn_ptrs      bn2;       /* BatchNorm2d(C)                                              :360 */
+} medt_block_params;
+
+typedef struct medt_block_saved {
+    float* z1;                   /* (N,width,H,W) conv_down output before bn1                        */
+    float* y1;                   /* (N,width,H,W) relu(bn1(z1)) = input of the height layer          */
+    float* stats1;               /* medt_conv_stats_floats() of the conv_down block                  */
+    medt_axial_saved height;     /* as medt_axial_layer_fwd fills it for the height layer            */
+    float* y_h;                  /* (N,width,H,W) height layer output = input of the width layer     */
+    medt_axial_saved width;
+    float* y_w;                  /* (N,width,H,W) relu(width layer output) = input of conv_up        */
+    float* z2;                   /* (N,C,H,W) conv_up output before bn2                              */
+    float* stats2;               /* medt_conv_stats_floats() of the conv_up block                    */
+} medt_block_saved;
+
+size_t medt_wopos_block_workspace_bytes(const medt_block_desc*);      /* 0: not a shape of the fused kernel */
+int medt_wopos_block_fwd(const medt_block_desc*, const medt_block_params*, const float* x, float* y,
+                         const medt_block_saved*, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Convolution block:  y = act( BN( conv2d(x, w) + bias ) + res )

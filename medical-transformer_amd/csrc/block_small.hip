@@ -1,0 +1,383 @@
+// block_small.hip -- a whole AxialBlock_wopos forward (lib/models/axialnet.py:368-391) in ONE workgroup per BatchNorm group.
+//
+// The deep layers of MedT's local branch (layer3_p.1-3: 4x4 maps, 4 images per patch group = 64 positions) ran four
+// dependent launches per block -- conv_down + bn1 + ReLU, the height and the width attention layer, conv_up + bn2 +
+// identity + ReLU -- of 11-13 us each for ~4 MFLOP: chains of ~12 barrier-separated phases at one wave per SIMD
+// (the MEDT_SKIP experiment puts these launches at 1:1 on the step's critical path).
+// Every BatchNorm of the block is per channel and per patch group, so ONE workgroup can own a whole group:
+//   * 1024 threads = 16 waves; a wave = the 64 positions of the group (lane = position) x a slice of the output channels;
+//   * the 1x1 convolutions read the activation tile from LDS (one conflict-free ds_read_b32 per input channel) and their
+//     weights through the scalar unit (wave-uniform rows: s_load_dwordx8/16 feeding v_fmac_f32 v, s, v -- no LDS staging,
+//     no broadcast ds_read_b128 per four FMAs);
+//   * every BatchNorm statistic is a wave reduction of values that are still in registers (no LDS pass, no barrier), its
+//     double-precision finalisation runs on the lanes in parallel (lane k finalises channel k of the wave's slice);
+//   * the attention layers: two waves per head (each half of the value channels), logits and softmax from LDS.
+// The tile never leaves LDS between the four stages; what the backward needs (z1, y1, qkv_raw / stacked / lse / y of both
+// attention layers, z2) is written to global memory on the way -- the saved tensors and statistics partials are exactly
+// those of the layer-by-layer path, so the four backward entry points do not care which forward ran.
+#include "medt_common.h"
+#include "defer.h"
+
+namespace medt {
+
+// -DMEDT_STAMPS (scripts/phase_stamps.py): lane 0 of wave 0 of workgroup 0 records the 100 MHz wall clock at the phase boundaries
+#ifdef MEDT_STAMPS
+__device__ unsigned long long g_blk_stamps[32];
+#define BLK_STAMP(i)                                                                     \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_blk_stamps[i] = wall_clock64();       \
+    } while (0)
+#else
+#define BLK_STAMP(i) do { } while (0)
+#endif
+
+struct BlkBnP { const float *weight, *bias, *rmean, *rvar; };
+struct BlkArgs {
+    float *z1, *y1, *qkv_h, *stk_h, *lse_h, *y_h, *qkv_w, *stk_w, *lse_w, *y_w, *z2, *y;
+    BlkBnP bn[8];                    // bn1 | bn_qkv, bn_similarity, bn_output of the height layer | the same of the width layer | bn2
+    double* part[8];                 // [groups][CH][2] sum / sum of squares (training)
+    int training;
+    float eps;
+};
+
+// Sum over the 64 lanes, the same bits in every lane: a butterfly of DPP moves inside the 16-lane rows (quad_perm, half-row and
+// row mirrors: VALU, ~1 instruction per step) and the gfx950 lane swaps across rows -- not __shfl_xor, which goes through the
+// LDS crossbar (ds_bpermute_b32): this kernel does ~80 wave reductions per wave, 16 waves at once.
+template <int CTRL>
+__device__ __forceinline__ float blk_dpp(float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float blk_wave_sum(float v) {
+    v += blk_dpp<0xB1>(v);             // quad_perm [1,0,3,2]
+    v += blk_dpp<0x4E>(v);             // quad_perm [2,3,0,1]
+    v += blk_dpp<0x141>(v);            // row_half_mirror: the other quad of the half row
+    v += blk_dpp<0x140>(v);            // row_mirror: the other half of the row
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(h[0]) + __uint_as_float(h[1]);
+}
+__device__ __forceinline__ float blk_lane(float v, int k) {     // the value of lane k (compile-time k), wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+
+// scale / shift of one BatchNorm channel from its centred sums (s = sum x, m2 = sum (x - s/n)^2, both float32: the values
+// were in registers for a second pass about the mean, so the variance is m2 / n without cancellation and needs no
+// double-precision division / square root -- ~100 f64 instructions per call that every one of the 16 waves would execute
+// for 4-8 useful lanes); running statistics in eval mode.  The (sum, sum of squares) pair the recorded finalisation
+// (saved statistics, running-stat recurrence: bn_finalize, pointwise.hip) reads is written in double, exactly as the
+// per-stage kernels do (centered_to_raw).
+__device__ __forceinline__ void blk_scale_shift(float s, float m2, float n, const float* prm, float eps, int training,
+                                                float& scale, float& shift) {
+    const float g = prm[0], b = prm[1];
+    float mean, rstd;
+    if (training) {
+        mean = s / n;
+        rstd = 1.f / sqrtf(m2 / n + eps);
+    } else {
+        mean = prm[2];
+        rstd = 1.f / sqrtf(prm[3] + eps);
+    }
+    scale = g * rstd;
+    shift = fmaf(-mean, scale, b);
+}
+
+// BatchNorm of K channels whose 64 values (the group's positions) sit one per lane: v[k] = channel ch0 + k.
+// prm: the BatchNorm's parameter table in LDS ([CH][4]: weight, bias, running mean, running variance).
+template <int K>
+__device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, double* part, int ch0, int training, float eps,
+                                        float (&sc)[K], float (&sh)[K]) {
+    const int lane = threadIdx.x & 63;
+    float my_s = 0.f, my_m2 = 0.f;
+    if (training) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float s = blk_wave_sum(v[k]);
+            const float d = v[k] - s * (1.f / 64.f);      // second pass about the mean (centered_to_raw, medt_common.h)
+            const float m2 = blk_wave_sum(d * d);
+            if (lane == k) { my_s = s; my_m2 = m2; }
+        }
+    }
+    float scale, shift;
+    blk_scale_shift(my_s, my_m2, 64.f, prm + (ch0 + min(lane, K - 1)) * 4, eps, training, scale, shift);
+    if (training && lane < K) {
+        double s, ss;
+        centered_to_raw(my_s, my_m2, my_s * (1.f / 64.f), 64.0, s, ss);
+        part[(size_t)(ch0 + lane) * 2] = s;
+        part[(size_t)(ch0 + lane) * 2 + 1] = ss;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        sc[k] = blk_lane(scale, k);
+        sh[k] = blk_lane(shift, k);
+    }
+}
+
+// out[k] = sum_c w[(row0 + k) * CIN + c] * T[c * 64 + lane]: K output channels of a 1x1 convolution over the LDS tile T;
+// the weight rows are wave-uniform (scalar loads)
+template <int K, int CIN>
+__device__ __forceinline__ void wave_conv1x1(const float* __restrict__ w, int row0, const float* T, float (&acc)[K]) {
+    const int lane = threadIdx.x & 63;
+    const float* wr = w + (size_t)row0 * CIN;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < CIN; ++c) {
+        const float t = T[c * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(wr[k * CIN + c], t, acc[k]);
+    }
+}
+
+// One AxialAttention_wopos layer on the tile A (CW x 64) -> A (in place), through Q (2CW x 64).  AXIS 0: along H, 1: along W.
+template <int CW, int GP, int AXIS, bool RELU>
+__device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, float* A, float* Q, const float* prm_q,
+                                               const float* prm_s, const float* prm_o, double* part_q, double* part_s,
+                                               double* part_o, float* qkv_raw, float* stacked, float* lse, float* y, int n0,
+                                               int training, float eps, int wv, int stamp0) {
+    constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 4, HW = 16, CB = 2 * CW / 16, HV = GP / 2;
+    static_assert(CB * 2 == NCH, "two waves per head");
+    const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
+    // 1. qkv_transform rows wv*CB .. +CB, bn_qkv                                             (axialnet.py:228)
+    {
+        float acc[CB], sc[CB], sh[CB];
+        wave_conv1x1<CB, CW>(w_qkv, wv * CB, A, acc);
+#pragma unroll
+        for (int k = 0; k < CB; ++k) qkv_raw[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = acc[k];
+        wave_bn<CB>(acc, prm_q, part_q, wv * CB, training, eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < CB; ++k) Q[(wv * CB + k) * 64 + lane] = fmaf(acc[k], sc[k], sh[k]);
+    }
+    MEDT_LDS_BARRIER();                                   // q | k | v of every head in LDS; A is free
+    BLK_STAMP(stamp0);                                 // projection + bn_qkv
+    // 2. logits of this lane's row, bn_similarity, softmax, P.V for half of the head's value channels   (:232-241)
+    const int g = wv >> 1, hf = wv & 1;
+    const float* Qh = Q + g * NCH * 64;
+    const int i = AXIS == 1 ? (p & 3) : (p >> 2), sj = AXIS == 1 ? 1 : 4, base = lane - i * sj;
+    float qv[HQ], z[L];
+#pragma unroll
+    for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 64 + lane];
+    float v0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        float qk = 0.f;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qk = fmaf(qv[c], Qh[(HQ + c) * 64 + base + j * sj], qk);
+        z[j] = qk;
+        v0 += qk;
+    }
+    float a_qk;
+    {
+        // bn_similarity: the head's 64 x L logits, sum and centred sum of squares (the logits are still in registers)
+        float s1 = 0.f, m2 = 0.f;
+        if (training) {
+            s1 = blk_wave_sum(v0);
+            const float mz = s1 * (1.f / (64.f * L));
+            float v1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < L; ++j) v1 = fmaf(z[j] - mz, z[j] - mz, v1);
+            m2 = blk_wave_sum(v1);
+        }
+        float scale, shift;
+        blk_scale_shift(s1, m2, 64.f * L, prm_s + g * 4, eps, training, scale, shift);
+        if (training && hf == 0 && lane == 0) {
+            double sd, ssd;
+            centered_to_raw(s1, m2, s1 * (1.f / (64.f * L)), 64.0 * L, sd, ssd);
+            part_s[(size_t)g * 2] = sd;
+            part_s[(size_t)g * 2 + 1] = ssd;
+        }
+        a_qk = scale * MEDT_LOG2E;                      // the shift is constant along a softmax row
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < L; ++j) { z[j] *= a_qk; m = fmaxf(m, z[j]); }
+    float l = 0.f, acc[HV];
+#pragma unroll
+    for (int c = 0; c < HV; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const float pj = __builtin_amdgcn_exp2f(z[j] - m);
+        l += pj;
+#pragma unroll
+        for (int c = 0; c < HV; ++c) acc[c] = fmaf(pj, Qh[(GP + hf * HV + c) * 64 + base + j * sj], acc[c]);
+    }
+    BLK_STAMP(stamp0 + 1);                             // logits, bn_similarity, softmax, P.V
+    const float inv = 1.f / l;
+    float o[HV], sc[HV], sh[HV];
+#pragma unroll
+    for (int c = 0; c < HV; ++c) {
+        o[c] = acc[c] * inv;
+        stacked[((size_t)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = o[c];
+    }
+    if (hf == 0) lse[((size_t)(n0 + ni) * G + g) * HW + p] = m + __log2f(l);
+    // 3. bn_output (+ the block's ReLU behind the width layer)                                 (:242, :381-383)
+    wave_bn<HV>(o, prm_o, part_o, g * GP + hf * HV, training, eps, sc, sh);
+#pragma unroll
+    for (int c = 0; c < HV; ++c) {
+        float v = fmaf(o[c], sc[c], sh[c]);
+        if (RELU) v = fmaxf(v, 0.f);
+        A[(g * GP + hf * HV + c) * 64 + lane] = v;
+        y[((size_t)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = v;
+    }
+    MEDT_LDS_BARRIER();                                   // the layer's output tile in A; Q is free
+    BLK_STAMP(stamp0 + 2);                             // bn_output + tile
+}
+
+template <int CI, int CW, int GP>
+__global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
+                                                               const float* __restrict__ w_qh, const float* __restrict__ w_qw,
+                                                               const float* __restrict__ w_up, BlkArgs a) {
+    constexpr int HW = 16, G = CW / GP, CA = CW / 16, CF = CI / 16;
+    constexpr int CHS[8] = {CW, 2 * CW, G, CW, 2 * CW, G, CW, CI};
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                    // [CI][64]   block input (the identity of the last stage)
+    float* A = X + CI * 64;                             // [CW][64]   the running activation tile
+    float* Q = A + CW * 64;                             // [2CW][64]  normalised q | k | v of the current attention layer
+    float* prm = Q + 2 * CW * 64;                       // BatchNorm parameters of the eight BatchNorms, [CH][4] each
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, n0 = grp * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ni = lane >> 4, p = lane & 15;
+    BLK_STAMP(0);
+    int poff[8];
+    {
+        int o = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { poff[b] = o; o += CHS[b] * 4; }
+    }
+    // ---- everything global the block needs before its first result, in one batch: the input tile and the BatchNorm parameters
+    {
+        constexpr int NX4 = CI * 64 / 4 / 1024;          // float4 per thread
+        float4 xv[NX4];
+#pragma unroll
+        for (int k = 0; k < NX4; ++k) {
+            const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4);
+            xv[k] = *reinterpret_cast<const float4*>(x + ((size_t)(n0 + img) * CI) * HW + (size_t)rem * 4);
+        }
+        float pv[4] = {0.f, 0.f, 0.f, 1.f};
+        int pdst = -1;
+        {
+            int o = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (tid >= o && tid < o + CHS[b]) {
+                    const int ch = tid - o;
+                    pv[0] = a.bn[b].weight[ch];
+                    pv[1] = a.bn[b].bias[ch];
+                    if (!a.training) { pv[2] = a.bn[b].rmean[ch]; pv[3] = a.bn[b].rvar[ch]; }
+                    pdst = poff[b] + ch * 4;
+                }
+                o += CHS[b];
+            }
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < NX4; ++k) {
+            const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4), c = rem >> 2, p4 = rem & 3;
+            *reinterpret_cast<float4*>(X + c * 64 + img * 16 + p4 * 4) = xv[k];
+        }
+        if (pdst >= 0) {
+            prm[pdst] = pv[0]; prm[pdst + 1] = pv[1]; prm[pdst + 2] = pv[2]; prm[pdst + 3] = pv[3];
+        }
+    }
+    MEDT_LDS_BARRIER();
+    BLK_STAMP(1);                                       // input tile + BatchNorm parameters in LDS
+    // ---- conv_down + bn1 + ReLU                                                              (axialnet.py:373-375)
+    {
+        float acc[CA], sc[CA], sh[CA];
+        wave_conv1x1<CA, CI>(w_down, wv * CA, X, acc);
+#pragma unroll
+        for (int k = 0; k < CA; ++k) a.z1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
+        wave_bn<CA>(acc, prm + poff[0], a.part[0] ? a.part[0] + (size_t)grp * CW * 2 : nullptr, wv * CA, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < CA; ++k) {
+            const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]), 0.f);
+            A[(wv * CA + k) * 64 + lane] = v;
+            a.y1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = v;
+        }
+    }
+    MEDT_LDS_BARRIER();
+    BLK_STAMP(2);                                       // conv_down + bn1 + ReLU
+    // ---- height layer, width layer (+ ReLU)                                                   (:377-379)
+    wave_attention<CW, GP, 0, false>(w_qh, A, Q, prm + poff[1], prm + poff[2], prm + poff[3],
+                                     a.part[1] + (size_t)grp * 2 * CW * 2, a.part[2] + (size_t)grp * G * 2,
+                                     a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h, a.y_h, n0, a.training, a.eps, wv, 3);
+    wave_attention<CW, GP, 1, true>(w_qw, A, Q, prm + poff[4], prm + poff[5], prm + poff[6],
+                                    a.part[4] + (size_t)grp * 2 * CW * 2, a.part[5] + (size_t)grp * G * 2,
+                                    a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w, a.y_w, n0, a.training, a.eps, wv, 6);
+    // ---- conv_up + bn2 + identity + ReLU                                                       (:381-389)
+    {
+        float acc[CF], sc[CF], sh[CF];
+        wave_conv1x1<CF, CW>(w_up, wv * CF, A, acc);
+#pragma unroll
+        for (int k = 0; k < CF; ++k) a.z2[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = acc[k];
+        wave_bn<CF>(acc, prm + poff[7], a.part[7] + (size_t)grp * CI * 2, wv * CF, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < CF; ++k) {
+            const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]) + X[(wv * CF + k) * 64 + lane], 0.f);
+            a.y[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = v;
+        }
+    }
+    BLK_STAMP(9);                                       // conv_up + bn2 + identity + ReLU
+}
+
+static bool block_fused_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MEDT_BLOCK_FUSED");
+        const char* d = getenv("MEDT_DISABLE_SMALL");
+        return !(e && e[0] == '0') && !(d && d[0] == '1');
+    }();
+    return on;
+}
+
+// Shapes the fused kernel is built for: 4-image BatchNorm groups on 4x4 maps (64 positions = one wave), 8 heads,
+// (C, width) = (128, 64) -- layer3_p.1-3 of MedT at 128 px, BASELINE.json's batch size.
+bool wopos_block_ok(const medt_block_desc& d) {
+    if (!block_fused_enabled()) return false;
+    if (d.N <= 0 || d.bn_groups <= 0 || d.N != 4 * d.bn_groups || d.H != 4 || d.W != 4 || d.G != 8) return false;
+    return d.C == 128 && d.width == 64;
+}
+
+size_t wopos_block_part_doubles(const medt_block_desc& d) {
+    return (size_t)d.bn_groups * 2 * (d.width + 2 * (2 * d.width + d.G + d.width) + d.C);
+}
+
+int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const float* x, float* y,
+                    const medt_block_saved& sv, double* parts, hipStream_t s) {
+    if (abl_skip("block_fwd")) return MEDT_OK;
+    BlkArgs a;
+    a.z1 = sv.z1; a.y1 = sv.y1;
+    a.qkv_h = (float*)sv.height.qkv_raw; a.stk_h = (float*)sv.height.stacked; a.lse_h = sv.height.lse; a.y_h = sv.y_h;
+    a.qkv_w = (float*)sv.width.qkv_raw; a.stk_w = (float*)sv.width.stacked; a.lse_w = sv.width.lse; a.y_w = sv.y_w;
+    a.z2 = sv.z2; a.y = y;
+    const medt_bn_ptrs* bns[8] = {&p.bn1, &p.height.bn_qkv, &p.height.bn_similarity, &p.height.bn_output,
+                                  &p.width.bn_qkv, &p.width.bn_similarity, &p.width.bn_output, &p.bn2};
+    const int chs[8] = {d.width, 2 * d.width, d.G, d.width, 2 * d.width, d.G, d.width, d.C};
+    size_t off = 0;
+    for (int b = 0; b < 8; ++b) {
+        a.bn[b] = BlkBnP{bns[b]->weight, bns[b]->bias, bns[b]->running_mean, bns[b]->running_var};
+        a.part[b] = parts + off;
+        off += (size_t)d.bn_groups * chs[b] * 2;
+    }
+    a.training = d.training ? 1 : 0;
+    a.eps = d.eps;
+    size_t nprm = 0;
+    for (int b = 0; b < 8; ++b) nprm += (size_t)chs[b] * 4;
+    const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {                    // more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU)
+        (void)hipFuncSetAttribute((const void*)wopos_block_fwd_kernel<128, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wopos_block_fwd_kernel<128, 64, 8>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.w_down,
+                       p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+    return launch_status("wopos_block_fwd");
+}
+
+}  // namespace medt
+
+#ifdef MEDT_STAMPS
+extern "C" int medt_debug_block_stamps(unsigned long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(medt::g_blk_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

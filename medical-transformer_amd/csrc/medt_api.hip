@@ -574,6 +574,57 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
                              d->pad, 1, s, q);
 }
 
+size_t medt_wopos_block_workspace_bytes(const medt_block_desc* d) {
+    if (!d || !wopos_block_ok(*d)) return 0;
+    return align_up(wopos_block_part_doubles(*d) * sizeof(double), 256) + 256;
+}
+
+int medt_wopos_block_fwd(const medt_block_desc* d, const medt_block_params* p, const float* x, float* y,
+                         const medt_block_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    if (!d || !p || !x || !y || !sv) { set_error("block fwd: null argument"); return MEDT_EINVAL; }
+    if (!wopos_block_ok(*d)) { set_error("block fwd: shape not supported by the fused kernel"); return MEDT_EUNSUPPORTED; }
+    if (!p->w_down || !p->w_up || !p->height.w_qkv || !p->width.w_qkv || !sv->z1 || !sv->y1 || !sv->stats1 || !sv->y_h ||
+        !sv->y_w || !sv->z2 || !sv->stats2 || !sv->height.qkv_raw || !sv->height.stacked || !sv->height.lse ||
+        !sv->height.stats || !sv->width.qkv_raw || !sv->width.stacked || !sv->width.lse || !sv->width.stats) {
+        set_error("block fwd: null pointer"); return MEDT_EINVAL;
+    }
+    const medt_bn_ptrs* bns[8] = {&p->bn1, &p->height.bn_qkv, &p->height.bn_similarity, &p->height.bn_output,
+                                  &p->width.bn_qkv, &p->width.bn_similarity, &p->width.bn_output, &p->bn2};
+    for (int b = 0; b < 8; ++b) {
+        if (!bns[b]->weight || !bns[b]->bias) { set_error("block fwd: null BatchNorm parameter"); return MEDT_EINVAL; }
+        if (!d->training && (!bns[b]->running_mean || !bns[b]->running_var)) {
+            set_error("block fwd: eval mode needs running statistics"); return MEDT_EINVAL;
+        }
+    }
+    Carver c(ws, ws_bytes);
+    double* parts = c.take<double>(wopos_block_part_doubles(*d));
+    if (!ws || !c.ok()) { set_error("block workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = wopos_block_fwd(*d, *p, x, y, *sv, parts, s);
+    if (rc) return rc;
+    // saved statistics + ordered running-stat updates of the eight BatchNorms: recorded for the grouped flush when a queue
+    // is bound (nothing in the forward chain reads them), else issued now
+    const int tr = d->training ? 1 : 0, gs = d->bn_groups, W = d->width, G = d->G;
+    const double rows = (double)(d->N / gs) * d->H * d->W, sims = rows * d->H;       // H == W: sequence length either axis
+    AxialGeom gh;
+    {
+        medt_axial_desc ad{d->N, W, d->H, d->W, G, 0, 0, 1, d->training, gs, d->eps, d->momentum, 0, 0, 0};
+        if ((rc = axial_geom(ad, &gh))) return rc;
+    }
+    LayerStats sh(sv->height.stats, gh), sw(sv->width.stats, gh);
+    const int chs[8] = {W, 2 * W, G, W, 2 * W, G, W, d->C};
+    const double cnt[8] = {rows, rows, sims, rows, rows, sims, rows, rows};
+    BnStats outs[8] = {BnStats(sv->stats1, gs * W), sh.qkv, sh.sim, sh.out, sw.qkv, sw.sim, sw.out, BnStats(sv->stats2, gs * d->C)};
+    const float* pp = reinterpret_cast<const float*>(parts);
+    Queue* q = queue_for(s);
+    for (int b = 0; b < 8; ++b) {
+        if (q) q->fin.push_back(FinJob{make_fin(pp, 1, chs[b], cnt[b], *bns[b], outs[b]), gs, tr, d->momentum, d->eps});
+        else if ((rc = bn_finalize(pp, 1, gs, chs[b], cnt[b], *bns[b], d->momentum, d->eps, tr, outs[b], s))) return rc;
+        pp += (size_t)gs * chs[b] * 2 * 2;           // doubles
+    }
+    return MEDT_OK;
+}
+
 int medt_gate_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* xn, float* h,
                       float* o, float* gates, int N, int C, int H, int W, int axis, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !xn || !h || !o || !gates || N < 1 || C < 1 || C > 4096 || H < 1 || W < 1) {

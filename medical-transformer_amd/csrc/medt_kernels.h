@@ -150,6 +150,12 @@ int axial_attn_fwd_fast_bf16(const AxialGeom& g, const float* qkv_raw, BnStats q
 int fast3_max_subtiles(int gp, int L, int axis);
 int fast4_subtile_sequences(int L);
 int fast4_max_subtiles(int axis);
+// block_small.hip: a whole AxialBlock_wopos forward in one workgroup per BatchNorm group
+bool wopos_block_ok(const medt_block_desc& d);
+size_t wopos_block_part_doubles(const medt_block_desc& d);
+int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const float* x, float* y,
+                    const medt_block_saved& sv, double* parts, hipStream_t s);
+
 // conv_small.hip: 1x1 conv + BatchNorm blocks whose BN group fits one workgroup
 bool conv_small_ok(const medt_conv_desc& d);
 int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,

@@ -83,7 +83,7 @@ class _AxialAttentionBase(nn.Module):
     def forward(self, x):
         return self.run(x, self.bn_groups, False)
 
-    def run(self, x, bn_groups=1, out_relu=False):
+    def run(self, x, bn_groups=1, out_relu=False, pre=None):
         L = x.shape[3] if self.width else x.shape[2]
         if self._has_pos and L != self.kernel_size:
             # same failure class as the reference's einsum shape error (e.g. `logo` at 256)
@@ -92,7 +92,7 @@ class _AxialAttentionBase(nn.Module):
         return medt_amd.axial_attention(
             x, self.qkv_transform.weight, self.bn_qkv, self.bn_similarity, self.bn_output,
             self.relative if self._has_pos else None, gates, self.groups, self.width, self.stride,
-            self.training, bn_groups, out_relu, self._gate_mode)
+            self.training, bn_groups, out_relu, self._gate_mode, pre)
 
 
 class AxialAttention(_AxialAttentionBase):

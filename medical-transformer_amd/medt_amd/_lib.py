@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: provides the HIP runtime the lib
 from .build import LIB_PATH
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MedtError(RuntimeError):
@@ -56,6 +56,23 @@ class AxialGrads(C.Structure):
                 ("bn_out_bias", C.c_void_p), ("relative", C.c_void_p), ("gates", C.c_void_p)]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("width", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("G", C.c_int32), ("training", C.c_int32), ("bn_groups", C.c_int32), ("eps", C.c_float),
+                ("momentum", C.c_float)]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [("w_down", C.c_void_p), ("bn1", BnPtrs), ("height", AxialParams), ("width", AxialParams),
+                ("w_up", C.c_void_p), ("bn2", BnPtrs)]
+
+
+class BlockSaved(C.Structure):
+    _fields_ = [("z1", C.c_void_p), ("y1", C.c_void_p), ("stats1", C.c_void_p), ("height", AxialSaved),
+                ("y_h", C.c_void_p), ("width", AxialSaved), ("y_w", C.c_void_p), ("z2", C.c_void_p),
+                ("stats2", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "medt_abi_version": (C.c_int, []),
@@ -79,6 +96,9 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_axial_core_bwd": (C.c_int, [C.POINTER(AxialDesc), C.POINTER(AxialParams), C.POINTER(AxialSaved), C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_wopos_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
+    "medt_wopos_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams), C.c_void_p, C.c_void_p,
+                                       C.POINTER(BlockSaved), C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_conv_stats_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "medt_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "medt_conv_block_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BnPtrs),

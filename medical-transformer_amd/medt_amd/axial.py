@@ -36,7 +36,7 @@ def set_activation_dtype(dtype) -> None:
 class AxialConfig:
     """Static geometry + BatchNorm buffers of one attention layer."""
     __slots__ = ("groups", "axis", "has_pos", "stride", "bn_groups", "eps", "momentum",
-                 "bn_qkv", "bn_similarity", "bn_output", "out_relu", "gate_mode", "act_dtype")
+                 "bn_qkv", "bn_similarity", "bn_output", "out_relu", "gate_mode", "act_dtype", "pre")
 
     def __init__(self, groups, axis, has_pos, stride, bn_qkv, bn_similarity, bn_output, bn_groups=1,
                  eps=1e-5, momentum=0.1, out_relu=False, gate_mode=0):
@@ -46,6 +46,7 @@ class AxialConfig:
         self.act_dtype = 1 if (ACT_BF16 and has_pos) else 0
         self.bn_groups, self.eps, self.momentum, self.out_relu = bn_groups, eps, momentum, out_relu
         self.bn_qkv, self.bn_similarity, self.bn_output = bn_qkv, bn_similarity, bn_output
+        self.pre = None       # (qkv_raw, stacked, lse, stats, y) already computed by the one-launch block forward (block.py)
 
 
 def _require_device(x: torch.Tensor):
@@ -98,23 +99,27 @@ class AxialAttentionFn(torch.autograd.Function):
         OC = 2 * Cc if cfg.has_pos else Cc
         dev = x.device
         sdt = torch.bfloat16 if cfg.act_dtype == 1 else torch.float32
-        qkv_raw = torch.empty((N, 2 * Cc, H, W), device=dev, dtype=sdt)
-        stacked = torch.empty((N, OC, H, W), device=dev, dtype=sdt)
-        lse = torch.empty((N, cfg.groups, H, W), device=dev, dtype=torch.float32)
-        nstats = lib.medt_axial_stats_floats(C.byref(desc))
-        if nstats == 0:
-            raise L.MedtError("axial attention: " + lib.medt_last_error().decode())
-        stats = torch.empty((nstats,), device=dev, dtype=torch.float32)
-        ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
-        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
-        y = torch.empty((N, Cc, H // cfg.stride, W // cfg.stride), device=dev, dtype=torch.float32)
-        saved = L.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
-        stream = torch.cuda.current_stream().cuda_stream
-        q = DEFER.recording()
-        L.check(lib.medt_axial_layer_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
-                                         ws.data_ptr(), ws_bytes, stream), "medt_axial_layer_fwd")
-        if q is not None:
-            q.hold(ws, stats)
+        if cfg.pre is not None:                    # adopt mode: the one-launch block forward already produced these
+            qkv_raw, stacked, lse, stats, y = cfg.pre
+            cfg.pre = None
+        else:
+            qkv_raw = torch.empty((N, 2 * Cc, H, W), device=dev, dtype=sdt)
+            stacked = torch.empty((N, OC, H, W), device=dev, dtype=sdt)
+            lse = torch.empty((N, cfg.groups, H, W), device=dev, dtype=torch.float32)
+            nstats = lib.medt_axial_stats_floats(C.byref(desc))
+            if nstats == 0:
+                raise L.MedtError("axial attention: " + lib.medt_last_error().decode())
+            stats = torch.empty((nstats,), device=dev, dtype=torch.float32)
+            ws_bytes = lib.medt_axial_workspace_bytes(C.byref(desc))
+            ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+            y = torch.empty((N, Cc, H // cfg.stride, W // cfg.stride), device=dev, dtype=torch.float32)
+            saved = L.AxialSaved(qkv_raw.data_ptr(), stacked.data_ptr(), lse.data_ptr(), stats.data_ptr())
+            stream = torch.cuda.current_stream().cuda_stream
+            q = DEFER.recording()
+            L.check(lib.medt_axial_layer_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
+                                             ws.data_ptr(), ws_bytes, stream), "medt_axial_layer_fwd")
+            if q is not None:
+                q.hold(ws, stats)
         ctx.cfg, ctx.training, ctx.has_gates = cfg, training, gates is not None
         # gradient slots of the parameters (views into FlatAdam's flat bucket): backward writes them directly
         ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None
@@ -204,7 +209,7 @@ class AxialAttentionFn(torch.autograd.Function):
 
 def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: Optional[torch.Tensor],
                     gates, groups: int, width: bool, stride: int, training: bool, bn_groups: int = 1,
-                    out_relu: bool = False, gate_mode: int = 0):
+                    out_relu: bool = False, gate_mode: int = 0, pre=None):
     """Functional entry: modules from lib.models.axialnet pass their own parameters/buffers.
 
     gates = (f_qr, f_kr, f_sve, f_sv) 0-d tensors or None (ungated: all ones).
@@ -214,6 +219,7 @@ def axial_attention(x, qkv_weight, bn_qkv, bn_similarity, bn_output, relative: O
     """
     cfg = AxialConfig(groups, 1 if width else 0, relative is not None, stride, bn_qkv, bn_similarity, bn_output,
                       bn_groups, bn_qkv.eps, _momentum(bn_qkv), out_relu, gate_mode)
+    cfg.pre = pre
     g = gates if gates is not None else (None, None, None, None)
     return AxialAttentionFn.apply(x, qkv_weight, bn_qkv.weight, bn_qkv.bias, bn_similarity.weight,
                                   bn_similarity.bias, bn_output.weight, bn_output.bias, relative,

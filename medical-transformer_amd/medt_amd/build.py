@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # me
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmedt_hip.so")
-SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip", "conv.hip", "elementwise.hip", "axial_fast.hip", "conv_mfma.hip", "axial_small.hip", "conv_small.hip", "axial_stats.hip", "defer.hip", "axial_bwd.hip"]
+SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip", "conv.hip", "elementwise.hip", "axial_fast.hip", "conv_mfma.hip", "axial_small.hip", "conv_small.hip", "axial_stats.hip", "defer.hip", "axial_bwd.hip", "block_small.hip"]
 HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", "sim_tables.h", "defer.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
 
 
@@ -40,7 +40,10 @@ def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str =
     os.makedirs(os.path.join(CSRC, obj_dir), exist_ok=True)
     # axial_bwd.hip: the SLP vectorizer pairs the sweep's FMAs into v_pk_fma_f32, which runs at the scalar rate on gfx950
     # and costs a third of the loop in v_mov register shuffles to line the operand pairs up
-    units = [(s, s.replace(".hip", ".o"), ["-fno-slp-vectorize"] if s == "axial_bwd.hip" else []) for s in SOURCES]
+    # block_small.hip: packing pairs of output channels into v_pk_fma_f32 costs s_mov pairs for the scalar weight operands
+    # (measured: 2.2007 vs 2.2096 ms/step)
+    units = [(s, s.replace(".hip", ".o"), ["-fno-slp-vectorize"] if s in ("axial_bwd.hip", "block_small.hip") else [])
+             for s in SOURCES]
     # the bandwidth-tuned attention kernels once more with bfloat16 storage as a compile-time constant
     units.append(("axial_fast.hip", "axial_fast_bf16.o", ["-DMEDT_FAST_BF16=1"]))
     for s, oname, extra in units:          # one hipcc per translation unit, in parallel

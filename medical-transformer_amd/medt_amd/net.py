@@ -18,6 +18,7 @@ import torch
 from ._lib import MedtError
 from . import ops
 from . import defer as DEFER
+from . import block as BLOCK
 
 import os
 
@@ -48,17 +49,22 @@ def axial_block_forward(blk, x, bn_groups: int = 1):
     # x fans out to conv_down and to the residual / downsample path (and, for layer outputs, to a decoder skip): their
     # gradients meet in conv_down's dgrad epilogue instead of autograd add kernels (ops.GradSink)
     sink = ops.sink_of(x) if (SINKS and x.requires_grad) else None
+    # the deep position-free blocks of the local branch: the whole block forward is ONE launch (block.py); the four stages
+    # below then adopt its outputs (`pre`) instead of launching -- same autograd graph, same backward
+    pre = BLOCK.fused_forward(blk, x, bn_groups) if bn_groups > 1 else None
+    if pre is None:
+        pre = {"down": None, "h": None, "w": None, "up": None}
     out = ops.conv_block(x, blk.conv_down, blk.bn1, relu=True, training=blk.bn1.training, bn_groups=bn_groups,
-                         x_sink=sink, x_role="final")
-    out = blk.hight_block.run(out, bn_groups, False)
-    out = blk.width_block.run(out, bn_groups, True)             # + the block's ReLU (:333)
+                         x_sink=sink, x_role="final", pre=pre["down"])
+    out = blk.hight_block.run(out, bn_groups, False, pre["h"])
+    out = blk.width_block.run(out, bn_groups, True, pre["w"])    # + the block's ReLU (:333)
     if blk.downsample is not None:
         identity = ops.conv_block(x, blk.downsample[0], blk.downsample[1], relu=False,
                                   training=blk.downsample[1].training, bn_groups=bn_groups, x_sink=sink, x_role="deposit")
         return ops.conv_block(out, blk.conv_up, blk.bn2, res=identity, relu=True, training=blk.bn2.training,
                               bn_groups=bn_groups)
     return ops.conv_block(out, blk.conv_up, blk.bn2, res=x, relu=True, training=blk.bn2.training,
-                          bn_groups=bn_groups, res_sink=sink)
+                          bn_groups=bn_groups, res_sink=sink, pre=pre["up"])
 
 
 def _layer(seq, x, bn_groups=1):

@@ -59,12 +59,14 @@ def sink_of(x):
 
 
 class ConvBlockCfg:
-    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink", "last_of_branch")
+    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink", "last_of_branch", "pre")
 
-    def __init__(self, stride, pad, bn, relu, bn_groups=1, x_sink=None, x_role=None, res_sink=None, last_of_branch=False):
+    def __init__(self, stride, pad, bn, relu, bn_groups=1, x_sink=None, x_role=None, res_sink=None, last_of_branch=False,
+                 pre=None):
         self.stride, self.pad, self.bn, self.relu, self.bn_groups = stride, pad, bn, relu, bn_groups
         self.x_sink, self.x_role, self.res_sink = x_sink, x_role, res_sink
         self.last_of_branch = last_of_branch       # this block's backward is the last work of its stream's backward pass
+        self.pre = pre                             # (z, y, stats) already computed by the one-launch block forward (block.py)
 
 
 def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDesc:
@@ -88,21 +90,25 @@ class ConvBlockFn(torch.autograd.Function):
         K, s, p = w.shape[2], cfg.stride, cfg.pad
         N, _, H, W = x.shape
         Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
-        y = torch.empty((N, w.shape[0], Ho, Wo), device=x.device, dtype=torch.float32)
         has_bn = cfg.bn is not None
-        z = torch.empty_like(y) if has_bn else y
-        stats = torch.empty((max(lib.medt_conv_stats_floats(C.byref(desc)), 1),), device=x.device, dtype=torch.float32)
-        ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
-        if ws_bytes == 0:
-            raise L.MedtError("conv block: " + lib.medt_last_error().decode())
-        ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
-        bnp = _bn_ptrs(cfg.bn, training) if has_bn else None
-        q = DEFER.recording() if has_bn else None
-        L.check(lib.medt_conv_block_fwd(C.byref(desc), x.data_ptr(), w.data_ptr(), L.ptr(bias),
-                                        C.byref(bnp) if has_bn else None, L.ptr(res), z.data_ptr(), y.data_ptr(),
-                                        stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "medt_conv_block_fwd")
-        if q is not None:
-            q.hold(ws, stats)
+        if cfg.pre is not None:                    # adopt mode: the one-launch block forward already produced these
+            z, y, stats = cfg.pre
+            cfg.pre = None
+        else:
+            y = torch.empty((N, w.shape[0], Ho, Wo), device=x.device, dtype=torch.float32)
+            z = torch.empty_like(y) if has_bn else y
+            stats = torch.empty((max(lib.medt_conv_stats_floats(C.byref(desc)), 1),), device=x.device, dtype=torch.float32)
+            ws_bytes = lib.medt_conv_workspace_bytes(C.byref(desc))
+            if ws_bytes == 0:
+                raise L.MedtError("conv block: " + lib.medt_last_error().decode())
+            ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+            bnp = _bn_ptrs(cfg.bn, training) if has_bn else None
+            q = DEFER.recording() if has_bn else None
+            L.check(lib.medt_conv_block_fwd(C.byref(desc), x.data_ptr(), w.data_ptr(), L.ptr(bias),
+                                            C.byref(bnp) if has_bn else None, L.ptr(res), z.data_ptr(), y.data_ptr(),
+                                            stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "medt_conv_block_fwd")
+            if q is not None:
+                q.hold(ws, stats)
         ctx.cfg, ctx.training, ctx.has_bias, ctx.has_res = cfg, training, bias is not None, res is not None
         # gradient slots of (w, bias, bn.weight, bn.bias) in FlatAdam's flat bucket: backward writes them directly
         ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None for t in (w, bias, bn_w, bn_b))
@@ -170,10 +176,11 @@ class ConvBlockFn(torch.autograd.Function):
 
 
 def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups=1, x_sink=None, x_role=None,
-               res_sink=None, last_of_branch=False):
-    """conv: nn.Conv2d holder, bn: nn.BatchNorm2d holder or None.  x_sink / x_role / res_sink: see GradSink."""
+               res_sink=None, last_of_branch=False, pre=None):
+    """conv: nn.Conv2d holder, bn: nn.BatchNorm2d holder or None.  x_sink / x_role / res_sink: see GradSink.
+    pre: (z, y, stats) computed by the one-launch block forward (medt_amd.block) -- nothing is launched then."""
     cfg = ConvBlockCfg(conv.stride[0], conv.padding[0], bn, relu, bn_groups if bn is not None else 1, x_sink, x_role,
-                       res_sink, last_of_branch)
+                       res_sink, last_of_branch, pre)
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                              bn.bias if bn is not None else None, res, cfg, training)
 

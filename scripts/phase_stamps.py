@@ -47,3 +47,26 @@ for (C, S, width) in [(64, 8, False), (32, 16, False), (32, 16, True), (128, 4, 
     print(f"C={C} map {S}x{S} axis={'w' if width else 'h'}: total {sum(best) / 1000:.2f} us (thread 0 of workgroup 0; kernel launch to first stamp not included)")
     for n, v in zip(NAMES, best):
         print(f"    {v / 1000:6.2f} us  {n}")
+
+# ---- the one-launch AxialBlock_wopos forward (csrc/block_small.hip), same mechanism ----
+from medt_amd import net  # noqa: E402
+BNAMES = ["input tile + BatchNorm parameters -> LDS", "conv_down + bn1 + ReLU", "height: projection + bn_qkv", "height: logits, bn_similarity, softmax, P.V",
+          "height: bn_output + tile", "width: projection + bn_qkv", "width: logits, bn_similarity, softmax, P.V", "width: bn_output + ReLU + tile",
+          "conv_up + bn2 + identity + ReLU"]
+h.medt_debug_block_stamps.restype = ctypes.c_int
+h.medt_debug_block_stamps.argtypes = [ctypes.c_void_p]
+blk = droplib.models.axialnet.AxialBlock_wopos(128, 64, groups=8, base_width=64, kernel_size=4).to(dev).train()
+x = torch.randn(64, 128, 4, 4, device=dev).relu_()
+best = None
+for rep in range(5):
+    with torch.no_grad():
+        net.axial_block_forward(blk, x, 16)
+    torch.cuda.synchronize()
+    st = (ctypes.c_ulonglong * 32)()
+    assert h.medt_debug_block_stamps(st) == 0
+    d = [(st[i + 1] - st[i]) * 10 for i in range(9)]
+    if best is None or sum(d) < sum(best):
+        best = d
+print(f"AxialBlock_wopos C=128 width=64 4x4 maps, one launch: total {sum(best) / 1000:.2f} us (lane 0 of workgroup 0)")
+for n, v in zip(BNAMES, best):
+    print(f"    {v / 1000:6.2f} us  {n}")

@@ -45,6 +45,9 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.AxialParams) == 8 + 3 * 40 + 5 * 8
     assert ctypes.sizeof(_lib.AxialSaved) == 4 * 8
     assert ctypes.sizeof(_lib.AxialGrads) == 9 * 8
+    assert ctypes.sizeof(_lib.BlockDesc) == 10 * 4
+    assert ctypes.sizeof(_lib.BlockParams) == 8 + 40 + 2 * (8 + 3 * 40 + 5 * 8) + 8 + 40
+    assert ctypes.sizeof(_lib.BlockSaved) == 3 * 8 + 32 + 8 + 32 + 3 * 8
 
 
 def test_descriptor_validation_no_gpu_needed(lib):
@@ -64,6 +67,19 @@ def test_conv_descriptor_validation(lib):
     assert lib.medt_conv_stats_floats(ctypes.byref(d)) == 4 * 128
     bad = _lib.ConvDesc(2, 8, 16, 16, 128, 5, 1, 2, 0, 1, 0, 1, 1, 1, 1e-5, 0.1)
     assert lib.medt_conv_workspace_bytes(ctypes.byref(bad)) == 0
+
+
+def test_block_descriptor_validation(lib):
+    """medt_wopos_block_workspace_bytes: > 0 exactly for the shapes the fused block kernel is built for."""
+    from medt_amd import _lib
+    ok = _lib.BlockDesc(64, 128, 64, 4, 4, 8, 1, 16, 1e-5, 0.1)           # layer3_p.1-3 at BASELINE's batch size
+    if os.environ.get("MEDT_BLOCK_FUSED", "1") != "0" and os.environ.get("MEDT_DISABLE_SMALL", "0") != "1":
+        assert lib.medt_wopos_block_workspace_bytes(ctypes.byref(ok)) > 0
+    for bad in (_lib.BlockDesc(32, 128, 64, 4, 4, 8, 1, 16, 1e-5, 0.1),   # 2 images per group
+                _lib.BlockDesc(64, 128, 64, 8, 8, 8, 1, 16, 1e-5, 0.1),   # 8x8 maps
+                _lib.BlockDesc(64, 64, 32, 4, 4, 8, 1, 16, 1e-5, 0.1)):   # other widths
+        assert lib.medt_wopos_block_workspace_bytes(ctypes.byref(bad)) == 0
+    assert lib.medt_wopos_block_fwd(ctypes.byref(ok), None, None, None, None, None, 0, None) < 0      # null arguments: refused
 
 
 def test_single_hip_runtime(lib):

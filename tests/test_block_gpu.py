@@ -1,0 +1,89 @@
+"""The one-launch AxialBlock_wopos forward (medt_wopos_block_fwd, csrc/block_small.hip) against the per-stage path
+(medt_conv_block_fwd -> medt_axial_layer_fwd x 2 -> medt_conv_block_fwd) and against a float64 torch restatement of
+reference lib/models/axialnet.py:368-391 on the shape it is built for (layer3_p.1-3 of MedT at 128 px, 4 images per group)."""
+import copy
+
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_block(device, seed=5):
+    import lib as droplib
+    torch.manual_seed(seed)
+    blk = droplib.models.axialnet.AxialBlock_wopos(128, 64, groups=8, base_width=64, kernel_size=4)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    return blk.to(device)
+
+
+def run(blk, x, dout, fused, training):
+    from medt_amd import block, net
+    blk = copy.deepcopy(blk)
+    blk.train(training)
+    old = block.ENABLED
+    block.ENABLED = fused
+    try:
+        xd = x.clone().requires_grad_(True)
+        y = net.axial_block_forward(blk, xd, 16)
+        (y * dout).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        block.ENABLED = old
+    grads = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
+    bufs = {k: v.clone() for k, v in blk.state_dict().items() if "running" in k or "num_batches" in k}
+    return y.detach(), xd.grad.clone(), grads, bufs
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_fused_block_equals_stagewise(training, device):
+    from medt_amd import _lib, block
+    import ctypes
+    d = _lib.BlockDesc(64, 128, 64, 4, 4, 8, int(training), 16, 1e-5, 0.1)
+    if not block.ENABLED or _lib.lib().medt_wopos_block_workspace_bytes(ctypes.byref(d)) == 0:
+        pytest.skip("fused block forward disabled (MEDT_BLOCK_FUSED=0 / MEDT_DISABLE_SMALL=1)")
+    blk = make_block(device)
+    torch.manual_seed(11)
+    x = torch.randn(64, 128, 4, 4, device=device).relu_()          # a block input is a ReLU output
+    dout = torch.randn(64, 128, 4, 4, device=device)
+    y0, dx0, g0, b0 = run(blk, x, dout, False, training)
+    y1, dx1, g1, b1 = run(blk, x, dout, True, training)
+    # same arithmetic up to summation order (statistics: wave reductions instead of LDS passes; convolutions: one
+    # ascending channel loop instead of four slices)
+    assert H.rel_err(y1, y0) < 2e-5, H.rel_err(y1, y0)
+    assert H.rel_err(dx1, dx0) < 2e-4, H.rel_err(dx1, dx0)
+    assert g0.keys() == g1.keys() and len(g0) >= 18
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:            # (bn_similarity.bias has gradient zero analytically -- the softmax ignores a shift: absolute floor)
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err < 5e-4 * max(g0[k].abs().max().item(), 1e-3 * gmax), (k, err, g0[k].abs().max().item())
+    for k in b0:
+        if "num_batches" in k:
+            assert int(b0[k]) == int(b1[k]) == (16 if training else 0), k
+        else:
+            assert H.rel_err(b1[k], b0[k]) < 1e-5, (k, H.rel_err(b1[k], b0[k]))
+
+
+def test_fused_block_is_taken_and_counts_one_launch(device):
+    """The block really runs as one forward launch: eight BatchNorm bookkeeping jobs are recorded by a single call, and the
+    adopt-mode stages launch nothing (their workspaces are never requested)."""
+    from medt_amd import block, net
+    from medt_amd.defer import StepQueue
+    if not block.ENABLED:
+        pytest.skip("fused block forward disabled")
+    blk = make_block(device).train()
+    x = torch.randn(64, 128, 4, 4, device=device).relu_()
+    q = StepQueue()
+    with q.active():
+        with torch.no_grad():
+            net.axial_block_forward(blk, x, 16)
+        assert q.pending() == 8
+    torch.cuda.synchronize()

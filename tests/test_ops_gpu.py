@@ -68,6 +68,12 @@ CONV_CASES = [
     (64, 64, 1, 1, 0, False, True, False, True, 64, 8, 16),     # layer3_p.0 conv_down (T=512, 4 channels per thread)
     (128, 256, 1, 1, 0, False, True, True, True, 64, 2, 16),    # layer4_p.0 conv_up on 2x2 maps (one thread per channel)
     (128, 128, 1, 1, 0, False, True, False, True, 64, 4, 16),   # layer4_p.0 conv_down
+    # more local-branch shapes: 1024-position groups, 8 input channels, stride-2 downsample
+    (8, 16, 1, 1, 0, False, True, False, True, 64, 16, 16),     # layer1_p.0 conv_down (1024 positions, one channel per wave)
+    (16, 32, 1, 1, 0, False, True, True, True, 64, 16, 16),     # layer1_p.0 conv_up + downsampled identity
+    (32, 32, 1, 1, 0, False, True, False, True, 64, 16, 16),    # layer2_p.0 conv_down
+    (32, 64, 1, 2, 0, False, True, False, False, 64, 16, 16),   # layer2_p.0 downsample (stride 2, 256 output positions)
+    (64, 128, 1, 2, 0, False, True, False, False, 64, 8, 16),   # layer3_p.0 downsample (stride 2, 64 output positions)
 ]
 
 
