@@ -163,7 +163,7 @@ __device__ __forceinline__ void wg_sum(float (&v)[K], float* red, float* out, in
 }
 
 template <int GP, int L, int LS, bool GATES>
-__global__ __launch_bounds__(MEDT_THREADS, L > 64 ? 1 : 2) void attn_bwd_sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void attn_bwd_sweep_kernel(SweepArgs a) {
     using C = Sw<GP, L, LS>;
     constexpr int HQ = C::HQ, NCH = C::NCH, D = C::D, SPW = C::SPW, TL = C::TL, NT = C::NT, TREC = C::TREC,
                   RREC = C::RREC, CREC = C::CREC, NP = C::NP, NPG = C::NPG, RS = C::RS;
@@ -837,7 +837,8 @@ __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_grouped_kernel
     const int j = find_job(b, blockIdx.x);
     const RelfixJob& a = b.job[j];
     if (a.hq == 1) relfix_body<1>(a, blockIdx.x - b.start[j], pgs, gred);
-    else relfix_body<2>(a, blockIdx.x - b.start[j], pgs, gred);
+    else if (a.hq == 2) relfix_body<2>(a, blockIdx.x - b.start[j], pgs, gred);
+    else relfix_body<4>(a, blockIdx.x - b.start[j], pgs, gred);
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void bwd_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
@@ -862,12 +863,13 @@ static bool sweep_enabled() {
 }  // namespace
 
 // Plan: lanes per sequence, waves per workgroup, tiles, persistent workgroups.  Returns false when the generic two-pass
-// kernels of axial_core.hip have to run (gp > 4, other lengths, per-sequence gates, MEDT_BWD_SWEEP=0).
+// kernels of axial_core.hip have to run (gp = 16, other lengths, per-sequence gates, MEDT_BWD_SWEEP=0).
 bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     if (!g.pos || gate_stride != 0 || !sweep_enabled() || !fast_path_enabled()) return false;
     int ls = 0;
     if (g.gp == 2 && (g.L == 32 || g.L == 64 || g.L == 128)) ls = g.L == 32 ? 8 : 16;
     else if (g.gp == 4 && (g.L == 32 || g.L == 64)) ls = g.L == 32 ? 8 : 16;
+    else if (g.gp == 8 && (g.L == 32 || g.L == 16)) ls = 16;       // round 4: the deep layers of axialunet / gatedaxialunet
     if (!ls) return false;
     // the sweep / fix kernels address qkv_raw, stacked and dqkv with 32-bit byte offsets (saddr + voffset): tensors of 4 GiB
     // and more take the generic kernels (size_t arithmetic)
@@ -890,7 +892,8 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     const int hq = g.hq, np = hq * (hq + 1) / 2;
     p->npg_floats = 2 * (np + hq);
     if (g.gp == 2) p->lds = g.L == 32 ? sweep_lds_bytes<2, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<2, 64, 16>(nw) : sweep_lds_bytes<2, 128, 16>(nw));
-    else p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : sweep_lds_bytes<4, 64, 16>(nw);
+    else if (g.gp == 4) p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : sweep_lds_bytes<4, 64, 16>(nw);
+    else p->lds = g.L == 32 ? sweep_lds_bytes<8, 32, 16>(nw) : sweep_lds_bytes<8, 16, 16>(nw);
     return p->lds <= 160 * 1024;
 }
 
@@ -924,6 +927,8 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
     else if (g.gp == 2 && g.L == 128) MEDT_SWEEP(2, 128, 16);
     else if (g.gp == 4 && g.L == 32) MEDT_SWEEP(4, 32, 8);
     else if (g.gp == 4 && g.L == 64) MEDT_SWEEP(4, 64, 16);
+    else if (g.gp == 8 && g.L == 32) MEDT_SWEEP(8, 32, 16);
+    else if (g.gp == 8 && g.L == 16) MEDT_SWEEP(8, 16, 16);
     else { set_error("attn_bwd_sweep: no instantiation for gp=%d L=%d", g.gp, g.L); return MEDT_EUNSUPPORTED; }
 #undef MEDT_SWEEP
     return launch_status("attn_bwd_sweep_kernel");
@@ -937,7 +942,8 @@ int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_
     a.dqkv = dqkv; a.part_qb = part_qb; a.fparts = p.fparts; a.qb_rpg = qb_rpg; a.qb_row0 = p.nparts; a.apply = apply;
     const dim3 grid(g.groups * p.fparts, g.G), block(MEDT_THREADS);
     if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_fix_kernel<1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_fix_kernel<2>), grid, block, 0, s, a);
+    else if (g.hq == 2) hipLaunchKernelGGL((attn_bwd_fix_kernel<2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fix_kernel<4>), grid, block, 0, s, a);
     return launch_status("attn_bwd_fix_kernel");
 }
 
@@ -957,7 +963,8 @@ int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* r
     if (q && defer_on) { q->relfix.push_back(a); return MEDT_OK; }
     const dim3 grid(a.blocks), block(RELFIX_THREADS);
     if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, a.lds, s, a);
-    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, a.lds, s, a);
+    else if (g.hq == 2) hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, a.lds, s, a);
+    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<4>), grid, block, a.lds, s, a);
     return launch_status("attn_bwd_relfix_kernel");
 }
 

@@ -722,6 +722,12 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
     if (splits == 1) scratch = dw;                         // a single slab is the result: no reduction pass
     if (mfma) {
+        static const bool defer_m = [] { const char* e = getenv("MEDT_DEFER_MFMA_WGRAD"); return !(e && e[0] == '0'); }();
+        if (q && defer_m) {       // recorded like the grouped jobs: nothing on the layer chain reads a weight gradient
+            q->mwgrad.push_back(MJob{dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits, N / groups});
+            if (splits > 1) q->reduce.push_back(RJob{scratch, dw, splits, Cout * Ktot});
+            return MEDT_OK;
+        }
         int rc = conv_wgrad_mfma(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits,
                                  N / groups, s);
         if (rc) return rc;

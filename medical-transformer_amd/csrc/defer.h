@@ -50,6 +50,12 @@ struct WJob {                        // conv_wgrad_body<K, 64, 64> over a (gx, g
     int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K;
 };
 
+struct MJob {                        // conv_wgrad_mfma: the dedicated MFMA weight-gradient kernels (LDS-patch kernel of the 16-wide
+    const float *dy, *raw, *coef, *x;    // maps, few-tile split-K kernels), one launch per job at the flush
+    float* scratch;
+    int N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits, npg;
+};
+
 struct RelfixJob {                   // attn_bwd_relfix (axial_bwd.hip): u / w terms of one layer's relative-table and gate gradients
     const float *relative, *sim_coef, *pg_part, *gate_raw;
     BnStats ss;
@@ -68,8 +74,11 @@ struct Queue {
     std::vector<SmallFinArgs> sfin;
     std::vector<CJob> csum;
     std::vector<WJob> wgrad;
+    std::vector<MJob> mwgrad;
     std::vector<RJob> reduce;
-    size_t pending() const { return relfix.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + reduce.size(); }
+    size_t pending() const {
+        return relfix.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + mwgrad.size() + reduce.size();
+    }
 };
 
 Queue* queue_for(hipStream_t s);     // the queue bound to this stream, or nullptr (immediate launches)

@@ -60,15 +60,20 @@ int medt_queue_flush(void* qv, void* stream) {
     if (!rc && !q.sfin.empty()) rc = wopos_small_bwd_finalize_grouped(q.sfin.data(), (int)q.sfin.size(), s);
     if (!rc && !q.csum.empty()) rc = channel_sum_grouped(q.csum.data(), (int)q.csum.size(), s);
     if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
+    for (size_t i = 0; !rc && i < q.mwgrad.size(); ++i) {
+        const MJob& m = q.mwgrad[i];
+        rc = conv_wgrad_mfma(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.K, m.stride, m.pad,
+                             m.QS, m.splits, m.npg, s);
+    }
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
-    q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
+    q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
     return rc == -1000 ? MEDT_OK : rc;
 }
 
 int medt_queue_discard(void* qv) {
     if (!qv) { set_error("queue discard: null queue"); return MEDT_EINVAL; }
     Queue& q = *(Queue*)qv;
-    q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.reduce.clear();
+    q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
     return MEDT_OK;
 }
 

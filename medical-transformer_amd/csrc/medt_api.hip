@@ -84,7 +84,9 @@ struct BwdWs {
         const size_t rel_rows = sweep ? sweep_blocks + (size_t)g.groups * g.G : nblocks;
         part_ob = c.take<float>((size_t)g.groups * ppg * g.OC * 2);
         coef_out = c.take<float>((size_t)g.groups * g.OC * 3);
-        part_sb = c.take<float>((size_t)g.groups * g.tpg * g.G * 4);
+        // (rows per group: the generic pass writes one per forward tile, the sweep one per persistent workgroup -- with 16 lanes
+        //  per sequence on short sequences, gp = 8, a group has more sweep workgroups than forward tiles)
+        part_sb = c.take<float>((size_t)g.groups * (sweep && plan.nparts > g.tpg ? plan.nparts : g.tpg) * g.G * 4);
         coef_sim = c.take<float>((size_t)g.groups * g.SC * 3);
         dqkv = c.take<float>((size_t)g.N * 2 * g.C * g.HW);
         part_qb = c.take<float>((size_t)g.groups * (qb_rpg > g.tpg ? qb_rpg : g.tpg) * 2 * g.C * 2);
