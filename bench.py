@@ -31,6 +31,7 @@ def log(msg):
 
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+VALU_PEAK_TFLOPS = 157.3        # fp32 vector peak: 256 CUs x 128 lanes x 2 flop x 2.4 GHz (same guide)
 PER_GPU_BATCH = 4               # BASELINE.json configs[2]/[3]: MedT imgsize=128 bs=4 per GPU
 IMG = 128
 
@@ -130,12 +131,16 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     # the launch = memset of the repair flag + the bound-referenced four-rows-per-lane kernel + the exact kernel's
     # early exit; MEDT_ROWS4=0 / MEDT_BOUND_PATH=0 select the other variants
     kname = ("attn_fwd4r_kernel<AXIS=%d,L=%d,EXACT=false>" if C // 8 == 2 else "attn_fwd3_kernel<GP=%d,AXIS=%%d,L=%%d,EXACT=false>" % (C // 8))
-    roof = {"bound": "hbm", "kernel": kname % (1 if width else 0, L),
+    # bound: the main pass is limited by VALU issue, not by HBM (7 L C flop per position against 4 C e bytes = 28 flop/B at
+    # L = 64: 224 TFLOP/s at 8 TB/s, above the 157 TFLOP/s fp32 vector peak; PMC: VALU busy 70 %, HBM traffic = the algorithmic
+    # bytes) -- `frac` stays the HBM fraction SURVEY.md 8(d) defines, `valu_frac` is the fraction of the roof that binds
+    roof = {"bound": "valu", "kernel": kname % (1 if width else 0, L),
             "shape": {"C": C, "G": 8, "L": L, "sequences": N * H, "bytes_per_launch": bytes_main,
                       "storage": "bf16" if e == 2 else "f32"},
             "achieved": bytes_main / t_main / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-            "launch_ms": t_main * 1e3, "valu_tflops": flops_main / t_main / 1e12,
+            "launch_ms": t_main * 1e3, "valu_tflops": flops_main / t_main / 1e12, "valu_peak_tflops": VALU_PEAK_TFLOPS,
+            "valu_frac": flops_main / t_main / 1e12 / VALU_PEAK_TFLOPS, "hbm_frac": bytes_main / t_main / 1e9 / HBM_PEAK_GBPS,
             "stats_kernel": {"kernel": "sim_stats_rows_kernel" if width else "sim_stats_kernel",
                              "achieved": bytes_stats / t_stats / 1e9, "launch_ms": t_stats * 1e3,
                              "bytes_per_launch": bytes_stats, "frac": bytes_stats / t_stats / 1e9 / HBM_PEAK_GBPS},
@@ -219,20 +224,32 @@ def cpu_baseline_leg(steps=8):
 
 
 def box_probe():
-    """Latency of a dependent global load on this box (scripts/ubench/load_latency.hip; built by __graft_entry__.build()).
-    The step is a chain of ~330 small kernels whose workgroups each wait on a few dependent memory round trips, so its
-    time follows this number: boxes of the same SKU and clocks were seen at 2.34 and 3.63 ms/step."""
+    """Two probes of the GPU box beside the step time (scripts/ubench/*.hip; built by __graft_entry__.build()): boxes of the
+    same SKU and reported clocks were seen at 2.2-2.3 and 3.6 ms/step.
+    dependent_load_ns: latency of a dependent global load (L2 / Infinity Cache / HBM footprints).  Round 4: a 3.60 ms box read
+    87 / 222 / 374 ns, the same as the 2.3 ms boxes -- this probe does NOT separate them.
+    clock: the effective shader clock under light load (dependent v_fma / ds_read chains at 1 wave, 128 and 2048 workgroups):
+    the kernels that are 2-5x slower on the slow boxes are the LDS / VALU chains on small grids; fast boxes read 2.61-2.65 ns
+    per dependent FMA at every grid size."""
     import subprocess
-    exe = os.path.join(ROOT, "scripts", "ubench", "load_latency.bin")
-    src = os.path.join(ROOT, "scripts", "ubench", "load_latency.hip")
-    try:
-        if not os.path.exists(exe):
-            subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", src, "-o", exe],
-                           check=True, capture_output=True, timeout=120)
-        out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[-1]
-        return json.loads(out)
-    except Exception as e:                                   # a probe, not the product: never fails the bench
-        return {"error": repr(e)[:200]}
+    out = {}
+    for key, name in (("dependent_load_ns", "load_latency"), ("clock", "clock_probe")):
+        exe = os.path.join(ROOT, "scripts", "ubench", name + ".bin")
+        src = os.path.join(ROOT, "scripts", "ubench", name + ".hip")
+        try:
+            if not os.path.exists(exe):
+                subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", src, "-o", exe],
+                               check=True, capture_output=True, timeout=120)
+            line = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[-1]
+            j = json.loads(line)
+            if key == "clock":                               # medians only: {grid: [ns per dependent FMA, ns per dependent LDS read]}
+                j = {g: [v["ns_per_dependent_fma"]["median"], v["ns_per_dependent_lds_read"]["median"]] for g, v in j.items()}
+                out[key] = j
+            else:
+                out.update(j)
+        except Exception as e:                               # a probe, not the product: never fails the bench
+            out[key + "_error"] = repr(e)[:200]
+    return out
 
 
 def baseline_config(args):

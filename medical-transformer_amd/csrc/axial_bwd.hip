@@ -838,7 +838,8 @@ __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_grouped_kernel
     const RelfixJob& a = b.job[j];
     if (a.hq == 1) relfix_body<1>(a, blockIdx.x - b.start[j], pgs, gred);
     else if (a.hq == 2) relfix_body<2>(a, blockIdx.x - b.start[j], pgs, gred);
-    else relfix_body<4>(a, blockIdx.x - b.start[j], pgs, gred);
+    else if (a.hq == 4) relfix_body<4>(a, blockIdx.x - b.start[j], pgs, gred);
+    else relfix_body<8>(a, blockIdx.x - b.start[j], pgs, gred);
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void bwd_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
@@ -863,13 +864,14 @@ static bool sweep_enabled() {
 }  // namespace
 
 // Plan: lanes per sequence, waves per workgroup, tiles, persistent workgroups.  Returns false when the generic two-pass
-// kernels of axial_core.hip have to run (gp = 16, other lengths, per-sequence gates, MEDT_BWD_SWEEP=0).
+// kernels of axial_core.hip have to run (other lengths, per-sequence gates, MEDT_BWD_SWEEP=0).
 bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     if (!g.pos || gate_stride != 0 || !sweep_enabled() || !fast_path_enabled()) return false;
     int ls = 0;
     if (g.gp == 2 && (g.L == 32 || g.L == 64 || g.L == 128)) ls = g.L == 32 ? 8 : 16;
     else if (g.gp == 4 && (g.L == 32 || g.L == 64)) ls = g.L == 32 ? 8 : 16;
     else if (g.gp == 8 && (g.L == 32 || g.L == 16)) ls = 16;       // round 4: the deep layers of axialunet / gatedaxialunet
+    else if (g.gp == 16 && g.L == 16) ls = 16;                     // (layer4 at 128 px: 256 VGPRs + 70 AGPRs, no scratch)
     if (!ls) return false;
     // the sweep / fix kernels address qkv_raw, stacked and dqkv with 32-bit byte offsets (saddr + voffset): tensors of 4 GiB
     // and more take the generic kernels (size_t arithmetic)
@@ -893,7 +895,8 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     p->npg_floats = 2 * (np + hq);
     if (g.gp == 2) p->lds = g.L == 32 ? sweep_lds_bytes<2, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<2, 64, 16>(nw) : sweep_lds_bytes<2, 128, 16>(nw));
     else if (g.gp == 4) p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : sweep_lds_bytes<4, 64, 16>(nw);
-    else p->lds = g.L == 32 ? sweep_lds_bytes<8, 32, 16>(nw) : sweep_lds_bytes<8, 16, 16>(nw);
+    else if (g.gp == 8) p->lds = g.L == 32 ? sweep_lds_bytes<8, 32, 16>(nw) : sweep_lds_bytes<8, 16, 16>(nw);
+    else p->lds = sweep_lds_bytes<16, 16, 16>(nw);
     return p->lds <= 160 * 1024;
 }
 
@@ -929,6 +932,7 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
     else if (g.gp == 4 && g.L == 64) MEDT_SWEEP(4, 64, 16);
     else if (g.gp == 8 && g.L == 32) MEDT_SWEEP(8, 32, 16);
     else if (g.gp == 8 && g.L == 16) MEDT_SWEEP(8, 16, 16);
+    else if (g.gp == 16 && g.L == 16) MEDT_SWEEP(16, 16, 16);
     else { set_error("attn_bwd_sweep: no instantiation for gp=%d L=%d", g.gp, g.L); return MEDT_EUNSUPPORTED; }
 #undef MEDT_SWEEP
     return launch_status("attn_bwd_sweep_kernel");
@@ -943,7 +947,8 @@ int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_
     const dim3 grid(g.groups * p.fparts, g.G), block(MEDT_THREADS);
     if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_fix_kernel<1>), grid, block, 0, s, a);
     else if (g.hq == 2) hipLaunchKernelGGL((attn_bwd_fix_kernel<2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_fix_kernel<4>), grid, block, 0, s, a);
+    else if (g.hq == 4) hipLaunchKernelGGL((attn_bwd_fix_kernel<4>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fix_kernel<8>), grid, block, 0, s, a);
     return launch_status("attn_bwd_fix_kernel");
 }
 
@@ -964,7 +969,8 @@ int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* r
     const dim3 grid(a.blocks), block(RELFIX_THREADS);
     if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, a.lds, s, a);
     else if (g.hq == 2) hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, a.lds, s, a);
-    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<4>), grid, block, a.lds, s, a);
+    else if (g.hq == 4) hipLaunchKernelGGL((attn_bwd_relfix_kernel<4>), grid, block, a.lds, s, a);
+    else hipLaunchKernelGGL((attn_bwd_relfix_kernel<8>), grid, block, a.lds, s, a);
     return launch_status("attn_bwd_relfix_kernel");
 }
 

@@ -286,16 +286,23 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
 // round trip.  Both operands have the channel on the fragment's row index and the position on k:
 //   dY  Ds[o][68]:  bank = 4 (l&15) + (l>>4) + const;   patch Ps[c][132]: bank = 4 (l&15) + (l>>4) + const.
 // grid (Cout/64, Cin/16, splits); slab bz of `scratch` receives the partial sum over its position tiles.
-__global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(
-    const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
-    const float* __restrict__ x, float* __restrict__ scratch, int Cin, int H, int Cout, int tiles_per_split, int ptiles,
-    int npg) {
-    __shared__ float Ds[64 * R16_DST];
-    __shared__ float Ps[16 * R16_WCST];
+struct R16WJob {                         // one weight-gradient problem of the kernel below (kernel arguments / job table)
+    const float *dy, *raw, *coef, *x;
+    float* scratch;
+    int Cin, H, Cout, tiles_per_split, ptiles, npg, gx, gy, gz;
+};
+
+__device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int bx, int by, int bz, float* Ds, float* Ps) {
+    const float* __restrict__ dy = jb.dy;
+    const float* __restrict__ raw = jb.raw;
+    const float* __restrict__ coef = jb.coef;
+    const float* __restrict__ x = jb.x;
+    float* __restrict__ scratch = jb.scratch;
+    const int Cin = jb.Cin, H = jb.H, Cout = jb.Cout, tiles_per_split = jb.tiles_per_split, ptiles = jb.ptiles, npg = jb.npg;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int o0 = blockIdx.x * 64, c0 = blockIdx.y * 16;
+    const int o0 = bx * 64, c0 = by * 16;
     const int Ktot = Cin * 9, HW = H * 16, tpi = H >> 2;
-    const int pt_begin = blockIdx.z * tiles_per_split;
+    const int pt_begin = bz * tiles_per_split;
     const int pt_end = min(ptiles, pt_begin + tiles_per_split);
     if (tid < 192) {
         const int c = tid / 12, rem = tid - c * 12;
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(
         }
         __syncthreads();
     }
-    float* out = scratch + (size_t)blockIdx.z * Cout * Ktot;
+    float* out = scratch + (size_t)bz * Cout * Ktot;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
@@ -367,6 +374,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(
             for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
         }
     }
+}
+
+// Several of these problems in ONE launch (the recorded weight gradients of conv2_p and conv3_p at the end of the local
+// branch's backward): each alone puts one workgroup of one wave per SIMD on every CU and spends two thirds of its time
+// waiting for the next tile; side by side they fill each other's gaps (46 + 46 us back to back before).
+using R16WBatch = JobBatch<R16WJob, 4>;
+__global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(R16WBatch b) {
+    __shared__ float Ds[64 * R16_DST];
+    __shared__ float Ps[16 * R16_WCST];
+    const int j = find_job(b, blockIdx.x);
+    const R16WJob& jb = b.job[j];
+    const int r = blockIdx.x - b.start[j], bx = r % jb.gx, by = (r / jb.gx) % jb.gy, bz = r / (jb.gx * jb.gy);
+    conv3x3_rows16_wgrad_body(jb, bx, by, bz, Ds, Ps);
 }
 
 // y[n,o,p] = bias[o] + sum over K slices; optional ReLU and BatchNorm partials ([group][256-position part][Cout][2]).
@@ -760,15 +780,43 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     return MEDT_OK;
 }
 
+bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stride, int pad, int QS) {
+    return QS % 64 == 0 && Ho == H && Wo == W && conv_rows16_ok(Cin, H, W, K, stride, pad);
+}
+
+// the LDS-patch weight-gradient kernel for up to four recorded problems at once
+int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s) {
+    if (abl_skip(jobs[0]->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        R16WBatch b;
+        b.n = n - i0 < 4 ? n - i0 : 4;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const MJob& m = *jobs[i0 + i];
+            R16WJob& j = b.job[i];
+            j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
+            j.Cin = m.Cin; j.H = m.H; j.Cout = m.Cout; j.tiles_per_split = m.QS / 64; j.ptiles = m.N * m.H / 4; j.npg = m.npg;
+            j.gx = cdiv(m.Cout, 64); j.gy = m.Cin / 16; j.gz = m.splits;
+            b.start[i] = blocks;
+            blocks += j.gx * j.gy * j.gz;
+        }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        int rc = launch_status("conv3x3_rows16_wgrad");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
+}
+
 int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const float* x, float* scratch, int N, int Cin,
                     int H, int W, int Cout, int Ho, int Wo, int K, int stride, int pad, int QS, int splits, int npg,
                     hipStream_t s) {
     const dim3 grid(cdiv(Cout, 64), cdiv(Cin * K * K, 64), splits), block(MEDT_THREADS);
     if (abl_skip(N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
-    if (QS % 64 == 0 && Ho == H && Wo == W && conv_rows16_ok(Cin, H, W, K, stride, pad)) {
-        hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel, dim3(cdiv(Cout, 64), Cin / 16, splits), block, 0, s, dy, raw, coef,
-                           x, scratch, Cin, H, Cout, QS / 64, N * H / 4, npg);
-        return launch_status("conv3x3_rows16_wgrad");
+    if (conv_wgrad_rows16_ok(Cin, H, W, Ho, Wo, K, stride, pad, QS)) {
+        const MJob m{dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits, npg};
+        const MJob* one = &m;
+        return conv_wgrad_rows16_grouped(&one, 1, s);
     }
     if (K == 1)
         hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, block, 0, s, dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho,
