@@ -221,6 +221,11 @@ typedef struct medt_conv_desc {
     int32_t relu;                 /* ReLU last                                                   */
     int32_t training, bn_groups;  /* as in medt_axial_desc                                       */
     float   eps, momentum;
+    int32_t lean;                 /* scheduling hint, no effect on results.  1: the caller runs CU-filling kernels on ANOTHER
+                                     stream at the same time (MedT's global branch at 256 px: persistent attention kernels that
+                                     hold ~all of a CU's LDS): keep to the per-stage kernels, whose workgroups co-reside with
+                                     anything, instead of the fused BatchNorm-backward + dgrad kernel (tens of KB of LDS per
+                                     workgroup -- measured: +0.5 ms on the 5.7 ms MedT-256 step, -0.02 ms on the MedT-128 step) */
 } medt_conv_desc;
 
 size_t medt_conv_stats_floats(const medt_conv_desc*);      /* 4*bn_groups*Cout if has_bn else 0 */

@@ -641,7 +641,8 @@ static bool bn_dgrad1x1_plan(const medt_conv_desc& d, BnDgradPlan* pl) {
     if (CPT != 1 && CPT != 2 && CPT != 4) return false;
     pl->T = T; pl->E = (int)E; pl->CT = CT; pl->CPT = CPT;
     pl->lds = ((size_t)tile + (size_t)d.Cout * CT) * sizeof(float);
-    return pl->lds <= 150 * 1024;
+    static const size_t lds_cap = [] { const char* e = getenv("MEDT_BN_DGRAD_LDS_KB"); return (size_t)(e ? atoi(e) : 150) * 1024; }();
+    return pl->lds <= lds_cap;
 }
 
 bool bn_dgrad1x1_small_ok(const medt_conv_desc& d) {
@@ -664,7 +665,7 @@ int bn_dgrad1x1_small(const medt_conv_desc& d, const float* dy, const float* y, 
 #define MEDT_BND(TT, CP)                                                                                              \
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
-        if (!attr) {          /* more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU) */            \
+        if (!attr && pl.lds > 64 * 1024) {   /* more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU) */ \
             (void)hipFuncSetAttribute((const void*)bn_dgrad1x1_small_kernel<TT, CP>,                                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
             attr = true;                                                                                              \

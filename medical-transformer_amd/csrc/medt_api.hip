@@ -530,7 +530,7 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
         if (small || (aligned && bn_chan_threads(*d, g.HoWo))) {
             // one wave (small blocks) or one workgroup per (group, channel): mask, sums, coefficients and dz in one
             // kernel; the finalisation only produces the parameter gradients (one partial slot per group)
-            if (small && dx && aligned && bn_dgrad1x1_small_ok(*d)) {
+            if (small && dx && aligned && !d->lean && bn_dgrad1x1_small_ok(*d)) {
                 // ... and the 1x1 backward-data behind it in the same launch (conv_small.hip, round 4)
                 rc = bn_dgrad1x1_small(*d, dy, y, z, st, bn->weight, w, dx_add, (d->has_res && dres) ? dres : nullptr,
                                        cw.dz, cw.partials, dx, s);

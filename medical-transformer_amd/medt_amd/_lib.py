@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32),
                 ("K", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("has_bias", C.c_int32),
                 ("has_bn", C.c_int32), ("has_res", C.c_int32), ("relu", C.c_int32), ("training", C.c_int32),
-                ("bn_groups", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float)]
+                ("bn_groups", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float), ("lean", C.c_int32)]
 
 
 class BnPtrs(C.Structure):

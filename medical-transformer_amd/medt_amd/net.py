@@ -132,6 +132,9 @@ def medt_forward(net, x):
     # the grouping does not change the result (running statistics); it is kept so the small per-group slices still
     # take the fused small-layer kernels (2 launches per layer instead of 6)
     groups = GRID * GRID
+    # beyond 128 px the global branch dominates the step and runs CU-filling persistent attention kernels (L = 128): the
+    # local branch then keeps to kernels whose workgroups co-reside with them (ops.LEAN -> medt_conv_desc.lean)
+    ops.LEAN = side is not None and xin.shape[2] * xin.shape[3] > 128 * 128
     if side is not None:
         with torch.cuda.stream(side):
             xp = ops.patch_gather(xin, PATCH, GRID)
@@ -151,6 +154,7 @@ def medt_forward(net, x):
     else:
         xp = ops.patch_gather(xin, PATCH, GRID)
         yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
+    ops.LEAN = False
     y = ops.logo_merge(y, yp, PATCH, GRID)
     y = ops.conv_block(y, net.decoderf, relu=True)
     return ops.conv_block(y, net.adjust)

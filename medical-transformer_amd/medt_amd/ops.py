@@ -58,8 +58,13 @@ def sink_of(x):
     return s
 
 
+# Scheduling hint (net.medt_forward sets it per call): True when the OTHER branch's stream runs CU-filling persistent kernels
+# (MedT's global branch beyond 128 px): the local branch then keeps to kernels with small LDS footprints (medt_conv_desc.lean)
+LEAN = False
+
+
 class ConvBlockCfg:
-    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink", "last_of_branch", "pre")
+    __slots__ = ("stride", "pad", "bn", "relu", "bn_groups", "x_sink", "x_role", "res_sink", "last_of_branch", "pre", "lean")
 
     def __init__(self, stride, pad, bn, relu, bn_groups=1, x_sink=None, x_role=None, res_sink=None, last_of_branch=False,
                  pre=None):
@@ -67,6 +72,7 @@ class ConvBlockCfg:
         self.x_sink, self.x_role, self.res_sink = x_sink, x_role, res_sink
         self.last_of_branch = last_of_branch       # this block's backward is the last work of its stream's backward pass
         self.pre = pre                             # (z, y, stats) already computed by the one-launch block forward (block.py)
+        self.lean = LEAN
 
 
 def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDesc:
@@ -75,7 +81,7 @@ def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDe
     return L.ConvDesc(N, Cin, H, W, w.shape[0], w.shape[2], cfg.stride, cfg.pad, int(has_bias), int(bn is not None),
                       int(has_res), int(cfg.relu), int(training), cfg.bn_groups,
                       bn.eps if bn is not None else 1e-5,
-                      _momentum(bn) if bn is not None else 0.1)
+                      _momentum(bn) if bn is not None else 0.1, int(cfg.lean))
 
 
 class ConvBlockFn(torch.autograd.Function):

@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     """sizeof of the ctypes mirrors == what the C compiler lays out (checked via the documented field lists)."""
     from medt_amd import _lib
     assert ctypes.sizeof(_lib.AxialDesc) == 15 * 4
-    assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 17 * 4
     assert ctypes.sizeof(_lib.BnPtrs) == 5 * 8
     assert ctypes.sizeof(_lib.AxialParams) == 8 + 3 * 40 + 5 * 8
     assert ctypes.sizeof(_lib.AxialSaved) == 4 * 8
