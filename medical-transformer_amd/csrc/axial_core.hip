@@ -39,6 +39,12 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
         set_error("axial: bad bn_groups=%d / stride=%d / axis=%d", d.bn_groups, d.stride, d.axis);
         return MEDT_EINVAL;
     }
+    // every tensor of the layer below 2^31 elements: the kernels index with 32-bit element counts in places, and the size
+    // arithmetic of the workspace must not wrap (found by tests/test_abi_fuzz.py: H = 2^30 used to be "accepted")
+    if ((double)d.N * 2.0 * d.C * d.H * d.W >= 2147483648.0) {
+        set_error("axial: N*2C*H*W = %.3g elements: tensors of 2^31 elements and more are unsupported", (double)d.N * 2.0 * d.C * d.H * d.W);
+        return MEDT_EUNSUPPORTED;
+    }
     const int gp = d.C / d.G;
     if (gp != 2 && gp != 4 && gp != 8 && gp != 16) {
         set_error("axial: group_planes=%d not in {2,4,8,16}", gp);

@@ -410,6 +410,11 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     g->Ho = (d->H + 2 * d->pad - d->K) / d->stride + 1;
     g->Wo = (d->W + 2 * d->pad - d->K) / d->stride + 1;
     if (g->Ho <= 0 || g->Wo <= 0) { set_error("conv: empty output"); return MEDT_EINVAL; }
+    // (tests/test_abi_fuzz.py: H = 2^30 used to pass and wrap the workspace size)
+    if ((double)d->N * d->Cin * d->H * d->W >= 2147483648.0 || (double)d->N * d->Cout * g->Ho * g->Wo >= 2147483648.0 ||
+        (double)d->Cout * d->Cin * d->K * d->K >= 2147483648.0) {
+        set_error("conv: tensors of 2^31 elements and more are unsupported"); return MEDT_EUNSUPPORTED;
+    }
     g->HoWo = g->Ho * g->Wo;
     g->ppg = conv_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo, d->Cin, d->Cout, d->K, d->stride);
     g->ppg_bwd = conv2d_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo);       // bn_act_bwd_stats: 256 positions / part

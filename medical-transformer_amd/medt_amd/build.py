@@ -27,7 +27,35 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str = None, obj_dir: str = "build") -> str:
+ASAN_LIB_PATH = os.path.join(PKG_DIR, "libmedt_asan.so")
+
+
+def build_asan(verbose: bool = False) -> str:
+    """libmedt_asan.so: the same sources with the HOST side under AddressSanitizer (-fsanitize=address -fno-gpu-sanitize: the
+    descriptor validation, workspace carving, job recording and launch wrappers; device code is not instrumented).
+    tests/test_abi_fuzz.py drives it with fuzzed descriptors in a subprocess that preloads the ASAN runtime."""
+    if os.path.exists(ASAN_LIB_PATH):
+        t = os.path.getmtime(ASAN_LIB_PATH)
+        deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return ASAN_LIB_PATH
+    return build(force=True, verbose=verbose, defines=("-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g"),
+                 lib_path=ASAN_LIB_PATH, obj_dir="build_asan", link_flags=("-fsanitize=address", "-shared-libsan"))
+
+
+def asan_runtime() -> str:
+    """Path of the AddressSanitizer runtime a non-instrumented python has to LD_PRELOAD before loading libmedt_asan.so."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = subprocess.run([hipcc, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if out and os.path.isabs(out) and os.path.exists(out):
+        return out
+    import glob
+    cands = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return cands[0] if cands else ""
+
+
+def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str = None, obj_dir: str = "build",
+          link_flags=()) -> str:
     """defines / lib_path / obj_dir: an instrumented second library next to the product one (scripts/phase_stamps.py
     builds libmedt_stamps.so with -DMEDT_STAMPS and loads it through MEDT_LIB_OVERRIDE)."""
     if lib_path is None:
@@ -57,7 +85,7 @@ def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str =
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *link_flags, *objs, "-o", lib_path]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
