@@ -121,6 +121,7 @@ __device__ __forceinline__ void wave_conv1x1(const float* __restrict__ w, int ro
     const float* wr = w + (size_t)row0 * CIN;
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    // (8 input channels per batch of scalar loads; 16 for the four-row phases measured slower: 2.188 vs 2.171 ms/step)
 #pragma unroll 8
     for (int c = 0; c < CIN; ++c) {
         const float t = T[c * 64 + lane];
