@@ -704,6 +704,52 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
                             blockIdx.y, blockIdx.z, A, B);
 }
 
+// Up to four of these problems in one launch (the recorded weight gradients of the local decoders' deep 3x3 layers: three
+// launches of 144-288 workgroups back to back at the end of the backward pass before)
+struct MWJob {
+    const float *dy, *raw, *coef, *x;
+    float* scratch;
+    int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K;
+};
+using MWBatch = JobBatch<MWJob, 4>;
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_batch_kernel(MWBatch b) {
+    __shared__ float A[64][65];
+    __shared__ float B[64][65];
+    const int j = find_job(b, blockIdx.x);
+    const MWJob& m = b.job[j];
+    const int r = blockIdx.x - b.start[j], bx = r % m.gx, by = (r / m.gx) % m.gy, bz = r / (m.gx * m.gy);
+    if (m.K == 1)
+        conv_wgrad_mfma_body<1>(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.stride, m.pad,
+                                m.QS, m.npg, bx, by, bz, A, B);
+    else
+        conv_wgrad_mfma_body<3>(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.stride, m.pad,
+                                m.QS, m.npg, bx, by, bz, A, B);
+}
+
+int conv_wgrad_mfma_batch(const MJob* const* jobs, int n, hipStream_t s) {
+    if (abl_skip(jobs[0]->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        MWBatch b;
+        b.n = n - i0 < 4 ? n - i0 : 4;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const MJob& m = *jobs[i0 + i];
+            MWJob& j = b.job[i];
+            j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
+            j.N = m.N; j.Cin = m.Cin; j.H = m.H; j.W = m.W; j.Cout = m.Cout; j.Ho = m.Ho; j.Wo = m.Wo; j.stride = m.stride;
+            j.pad = m.pad; j.QS = m.QS; j.npg = m.npg; j.K = m.K;
+            j.gx = cdiv(m.Cout, 64); j.gy = cdiv(m.Cin * m.K * m.K, 64); j.gz = m.splits;
+            b.start[i] = blocks;
+            blocks += j.gx * j.gy * j.gz;
+        }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(conv_wgrad_mfma_batch_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        int rc = launch_status("conv_wgrad_mfma_batch");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
+}
+
 // The recorded weight gradients of many layers -- all kernel sizes -- in ONE launch (defer.h): 64 x 64 tiles on the
 // matrix cores for every layer.  Per FMA the MFMA tile reads 16x fewer LDS bytes than the 4x4 register tile
 // (profiles/r02_wgrad_ab.json).  A flush holds 20-40 layers and 1-3 thousand workgroups; issued per kernel size the

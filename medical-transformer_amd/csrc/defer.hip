@@ -61,17 +61,15 @@ int medt_queue_flush(void* qv, void* stream) {
     if (!rc && !q.csum.empty()) rc = channel_sum_grouped(q.csum.data(), (int)q.csum.size(), s);
     if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
     {
-        // the LDS-patch problems of the 16-wide maps side by side in one launch (they fill each other's load gaps), the rest one by one
+        // the LDS-patch problems of the 16-wide maps side by side in one launch (they fill each other's load gaps); so the others
         std::vector<const MJob*> r16;
         for (const MJob& m : q.mwgrad)
             if (conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS)) r16.push_back(&m);
         if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), s);
-        for (size_t i = 0; !rc && i < q.mwgrad.size(); ++i) {
-            const MJob& m = q.mwgrad[i];
-            if (conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS)) continue;
-            rc = conv_wgrad_mfma(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.K, m.stride,
-                                 m.pad, m.QS, m.splits, m.npg, s);
-        }
+        std::vector<const MJob*> rest;
+        for (const MJob& m : q.mwgrad)
+            if (!conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS) && (m.K == 1 || m.K == 3)) rest.push_back(&m);
+        if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
     }
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
     q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();

@@ -135,26 +135,29 @@ def medt_forward(net, x):
     # beyond 128 px the global branch dominates the step and runs CU-filling persistent attention kernels (L = 128): the
     # local branch then keeps to kernels whose workgroups co-reside with them (ops.LEAN -> medt_conv_desc.lean)
     ops.LEAN = side is not None and xin.shape[2] * xin.shape[3] > 128 * 128
-    if side is not None:
-        with torch.cuda.stream(side):
+    try:
+        if side is not None:
+            with torch.cuda.stream(side):
+                xp = ops.patch_gather(xin, PATCH, GRID)
+                yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
+                if EARLY_FIN:
+                    # the local branch's recorded bookkeeping (saved statistics of the fused small layers, running
+                    # statistics) is issued on ITS stream behind an event the merge waits for: it runs under the merge /
+                    # decoderf / loss kernels of the main stream and still precedes the local backward, which is ordered
+                    # on this stream
+                    joined = torch.cuda.Event()
+                    joined.record(side)
+                    DEFER.flush_current_stream()
+            if EARLY_FIN:
+                main.wait_event(joined)
+            else:
+                main.wait_stream(side)
+            yp.record_stream(main)
+        else:
             xp = ops.patch_gather(xin, PATCH, GRID)
             yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
-            if EARLY_FIN:
-                # the local branch's recorded bookkeeping (saved statistics of the fused small layers, running statistics)
-                # is issued on ITS stream behind an event the merge waits for: it runs under the merge / decoderf / loss
-                # kernels of the main stream and still precedes the local backward, which is ordered on this stream
-                joined = torch.cuda.Event()
-                joined.record(side)
-                DEFER.flush_current_stream()
-        if EARLY_FIN:
-            main.wait_event(joined)
-        else:
-            main.wait_stream(side)
-        yp.record_stream(main)
-    else:
-        xp = ops.patch_gather(xin, PATCH, GRID)
-        yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
-    ops.LEAN = False
+    finally:
+        ops.LEAN = False               # (the hint is read when a block's configuration is built: forward time)
     y = ops.logo_merge(y, yp, PATCH, GRID)
     y = ops.conv_block(y, net.decoderf, relu=True)
     return ops.conv_block(y, net.adjust)
