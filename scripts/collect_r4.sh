@@ -29,8 +29,5 @@ timeout 100 python scripts/phase_stamps.py 2>&1 | grep -v "^/opt" > $O/phase_sta
 scripts/ubench/group_barrier.bin > $O/group_barrier.json 2>&1
 find $O -name "*kernel_trace.csv" -size +20M -delete
 cut -c1-150 $O/ab.txt; head -40 $O/step_chains.txt
-# SQ counters of the round's new kernels inside the timed step (two counter groups, --pmc with --kernel-trace only)
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_step1 -- python bench.py --no-cpu-baseline --no-roofline > $O/pmc_step1.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_step2 -- python bench.py --no-cpu-baseline --no-roofline > $O/pmc_step2.log 2>&1
-find $O -name "*kernel_trace.csv" -path "*pmc*" -delete
-ls $O/pmc_step1/*/ $O/pmc_step2/*/ | head
+# (the bench line, the step's kernel statistics and its SQ counters: scripts/r4_final.sh -- the raw counter tables exceed gpurun's
+#  64 MiB merge limit and are reduced to per-kernel averages on the box there)
