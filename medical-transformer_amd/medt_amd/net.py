@@ -51,7 +51,7 @@ def axial_block_forward(blk, x, bn_groups: int = 1):
     sink = ops.sink_of(x) if (SINKS and x.requires_grad) else None
     # the deep position-free blocks of the local branch: the whole block forward is ONE launch (block.py); the four stages
     # below then adopt its outputs (`pre`) instead of launching -- same autograd graph, same backward
-    pre = BLOCK.fused_forward(blk, x, bn_groups) if bn_groups > 1 else None
+    pre = BLOCK.fused_forward(blk, x, bn_groups)
     if pre is None:
         pre = {"down": None, "h": None, "w": None, "up": None}
     out = ops.conv_block(x, blk.conv_down, blk.bn1, relu=True, training=blk.bn1.training, bn_groups=bn_groups,

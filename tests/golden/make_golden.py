@@ -236,6 +236,43 @@ def layer_fixture(kind, C, L, width, stride, N, seed):
     return fx
 
 
+def block_fixture(inplanes, planes, S, groups_n, npg, seed):
+    """One AxialBlock_wopos of the reference (lib/models/axialnet.py:346-391) applied to `groups_n` patch groups of `npg`
+    images ONE AFTER THE OTHER -- what medt_net's patch loop (:661-700) does with every block of the local branch: each
+    group is normalised with its own batch statistics, the running statistics receive the groups' updates in order, the
+    parameter gradients are the sums over the groups.  Everything stored in full (float64)."""
+    ax = ref_loader.load()
+    torch.manual_seed(seed)
+    blk = ax.AxialBlock_wopos(inplanes, planes, groups=8, base_width=64, kernel_size=S)
+    sd = O.randomize_state(blk.state_dict(), seed)
+    blk.load_state_dict(sd)
+    blk = blk.double()
+    for p in blk.parameters():
+        p.requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 1)
+    N = groups_n * npg
+    x = torch.randn((N, inplanes, S, S), generator=g, dtype=torch.float64).relu_().requires_grad_(True)
+    w = torch.randn((N, inplanes, S, S), generator=g, dtype=torch.float64)
+    import json
+    fx = {"meta": np.array([inplanes, planes, S, groups_n, npg, seed]), "x": x.detach().numpy(), "dout": w.numpy(),
+          "state_layout": np.array(json.dumps([[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]))}
+    blk.eval()
+    fx["out_eval"] = torch.cat([blk(x[i * npg:(i + 1) * npg]) for i in range(groups_n)]).detach().numpy()
+    blk.train()
+    outs = [blk(x[i * npg:(i + 1) * npg]) for i in range(groups_n)]          # in patch order
+    out = torch.cat(outs)
+    (out * w).sum().backward()
+    fx["out_train"] = out.detach().numpy()
+    fx["dx"] = x.grad.numpy()
+    for k, p in blk.named_parameters():
+        if p.grad is not None:                      # (conv1 of AxialBlock_wopos is registered and never used, SURVEY.md Q5)
+            fx["grad/" + k] = p.grad.numpy()
+    for k, b in blk.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            fx["buf/" + k] = b.numpy()
+    return fx
+
+
 def manifest():
     """state_dict key / shape / dtype manifest of every factory (the drop-in contract)."""
     import json
@@ -280,6 +317,12 @@ def main():
             continue
         fx = layer_fixture(*case)
         np.savez_compressed(os.path.join(HERE, fn), **fx)
+        print("wrote", fn)
+    # layer3_p.1-3 of MedT at BASELINE's batch size (128 -> 64 -> 128 channels on 4x4 maps, 4 images per patch group): the shape
+    # the one-launch block forward (csrc/block_small.hip) is built for, here as two patch groups
+    fn = "block_wopos_C128_P64_S4_G2.npz"
+    if fn.startswith(only):
+        np.savez_compressed(os.path.join(HERE, fn), **block_fixture(128, 64, 4, 2, 4, 21))
         print("wrote", fn)
     model_cases = [
         ("gatedaxialunet", 128, 2, 101, "train"),

@@ -72,6 +72,53 @@ def test_fused_block_equals_stagewise(training, device):
             assert H.rel_err(b1[k], b0[k]) < 1e-5, (k, H.rel_err(b1[k], b0[k]))
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "per-stage"])
+def test_block_vs_reference_fixture(fused, device):
+    """Against the reference itself (tests/golden/block_wopos_*.npz: lib/models/axialnet.py's AxialBlock_wopos applied to two
+    patch groups one after the other, float64): outputs in eval and train mode, dx, every parameter gradient, the running
+    statistics after the two ordered updates.  1e-3 relative (north_star); observed ~1e-5."""
+    import json
+    import numpy as np
+    import lib as droplib
+    from medt_amd import block, net
+    from oracle import medt_oracle as O                 # randomize_state only: the fixture's weights are re-derived from the seed
+    fx = H.load_golden("block_wopos_C128_P64_S4_G2.npz")
+    inplanes, planes, S, groups_n, npg, seed = [int(v) for v in fx["meta"]]
+    blk = droplib.models.axialnet.AxialBlock_wopos(inplanes, planes, groups=8, base_width=64, kernel_size=S)
+    layout = json.loads(str(fx["state_layout"]))
+    assert [k for k, _, _ in layout] == list(blk.state_dict().keys())
+    blk.load_state_dict(O.randomize_state({k: v.clone() for k, v in blk.state_dict().items()}, seed))
+    blk = blk.to(device)
+    x = torch.from_numpy(fx["x"]).float().to(device)
+    old = block.ENABLED
+    block.ENABLED = fused and old
+    if fused and not old:
+        pytest.skip("fused block forward disabled")
+    try:
+        blk.eval()
+        with torch.no_grad():
+            assert H.rel_err(net.axial_block_forward(blk, x, groups_n), fx["out_eval"]) < 1e-3
+        blk.train()
+        xg = x.clone().requires_grad_(True)
+        y = net.axial_block_forward(blk, xg, groups_n)
+        assert H.rel_err(y, fx["out_train"]) < 1e-3
+        (y * torch.from_numpy(fx["dout"]).float().to(device)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        block.ENABLED = old
+    assert H.rel_err(xg.grad, fx["dx"]) < 1e-3
+    gscale = max(np.abs(fx[k]).max() for k in fx if k.startswith("grad/"))
+    params = dict(blk.named_parameters())
+    for k in fx:
+        if k.startswith("grad/"):
+            want = torch.from_numpy(fx[k])
+            scale = max(want.abs().max().item(), 1e-3 * gscale)
+            err = (params[k[5:]].grad.double().cpu() - want).abs().max().item() / scale
+            assert err < 1e-3, (k, err)
+        if k.startswith("buf/"):
+            assert H.rel_err(blk.state_dict()[k[4:]].double(), fx[k]) < 1e-3, k
+
+
 def test_fused_block_is_taken_and_counts_one_launch(device):
     """The block really runs as one forward launch: eight BatchNorm bookkeeping jobs are recorded by a single call, and the
     adopt-mode stages launch nothing (their workspaces are never requested)."""

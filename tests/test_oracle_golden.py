@@ -61,6 +61,40 @@ def test_layer_oracle_matches_reference_fixture(fn):
             assert H.rel_err(st_t["m." + k[4:]].double(), fx[k]) < 1e-10, k
 
 
+BLOCK_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(H.GOLDEN, "block_*.npz")))
+
+
+@pytest.mark.parametrize("fn", BLOCK_FILES)
+def test_block_oracle_matches_reference_fixture(fn):
+    """O.axial_block with grouped BatchNorm statistics == the reference's AxialBlock_wopos applied to the patch groups one after
+    the other (medt_net's patch loop, axialnet.py:661-700): outputs, every gradient, the running statistics in patch order."""
+    fx = H.load_golden(fn)
+    inplanes, planes, S, groups_n, npg, seed = [int(v) for v in fx["meta"]]
+    layout = json.loads(str(fx["state_layout"]))
+    blank = {k: torch.zeros(shape, dtype=getattr(torch, dt)) for k, shape, dt in layout}
+    st = {("m." + k): v for k, v in O.randomize_state(blank, seed).items()}
+    x = torch.from_numpy(fx["x"]).double()
+    out = O.axial_block(x, O.clone_state(st, torch.float64), "m", 1, False, groups_n)
+    assert H.rel_err(out, fx["out_eval"]) < 1e-10
+    st_t = O.clone_state(st, torch.float64, requires_grad=True)
+    xg = x.clone().requires_grad_(True)
+    out = O.axial_block(xg, st_t, "m", 1, True, groups_n)
+    assert H.rel_err(out, fx["out_train"]) < 1e-10
+    (out * torch.from_numpy(fx["dout"])).sum().backward()
+    assert H.rel_err(xg.grad, fx["dx"]) < 1e-9
+    gscale = max(np.abs(fx[k]).max() for k in fx if k.startswith("grad/"))
+    ngrads = 0
+    for k in fx:
+        if k.startswith("grad/"):
+            g = st_t["m." + k[5:]].grad
+            g = torch.zeros_like(st_t["m." + k[5:]]) if g is None else g
+            assert (g - torch.from_numpy(fx[k])).abs().max().item() < 1e-9 * max(gscale, 1.0), k
+            ngrads += 1
+        if k.startswith("buf/"):
+            assert H.rel_err(st_t["m." + k[4:]].double(), fx[k]) < 1e-10, k
+    assert ngrads >= 18
+
+
 @pytest.mark.parametrize("fn", MODEL_FILES)
 def test_model_oracle_matches_reference_fixture(fn):
     fx = H.load_golden(fn)
