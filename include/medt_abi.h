@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 7
+#define MEDT_ABI_VERSION 8
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -205,6 +205,25 @@ typedef struct medt_block_saved {
 size_t medt_wopos_block_workspace_bytes(const medt_block_desc*);      /* 0: not a shape of the fused kernel */
 int medt_wopos_block_fwd(const medt_block_desc*, const medt_block_params*, const float* x, float* y,
                          const medt_block_saved*, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same block's BACKWARD as one launch: dy -> dx through bn2, conv_up, the two attention layers, bn1 and conv_down,
+ * the identity's gradient and `dx_add` (the other consumers' contribution to d(x), may be NULL) summed in the last phase;
+ * every parameter gradient in `grads` is written (not accumulated) -- when a queue is bound to the stream the weight
+ * gradients and the BatchNorm parameter reductions are recorded for the grouped flush exactly like the per-stage entry
+ * points record theirs.  `saved` is what medt_wopos_block_fwd (or the four per-stage forwards) filled, `y` the block output.
+ * medt_wopos_block_bwd_workspace_bytes() returns 0 when this path is not available for the shape or not enabled
+ * (MEDT_BLOCK_BWD=1; the caller then runs medt_conv_block_bwd / medt_axial_layer_bwd for the four stages).
+ * State: verified against the reference fixture on the CPU lane emulator (tests/test_lane_emu.py); off by default until
+ * it has been run and timed on the GPU. */
+typedef struct medt_block_grads {
+    float *w_down, *bn1_weight, *bn1_bias;
+    medt_axial_grads height, width;          /* relative / gates: NULL (position-free layers)                 */
+    float *w_up, *bn2_weight, *bn2_bias;
+} medt_block_grads;
+size_t medt_wopos_block_bwd_workspace_bytes(const medt_block_desc*);
+int medt_wopos_block_bwd(const medt_block_desc*, const medt_block_params*, const float* x, const float* y, const float* dy,
+                         const medt_block_saved*, float* dx, const float* dx_add, const medt_block_grads*,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Convolution block:  y = act( BN( conv2d(x, w) + bias ) + res )

@@ -375,6 +375,411 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
     return launch_status("wopos_block_fwd");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------ //
+// The block's BACKWARD in one workgroup per BatchNorm group (same shapes, same workgroup: lane = position, 16 waves).
+// The per-stage path runs six dependent launches per block (BatchNorm backward + 1x1 dgrad of conv_up, two per attention
+// layer, BatchNorm backward + dgrad of conv_down); here the gradient tile stays in registers / LDS from dy to dx:
+//   bn2 backward (ReLU mask by y, two wave sums per channel)            -> dz2  (global: weight-gradient job; LDS: dgrad)
+//   conv_up dgrad (w_up columns through the scalar unit)                -> d(y_w), four channels per wave in registers
+//   width layer, height layer: [ReLU mask,] bn_output backward, softmax / bn_similarity backward of the head (two waves per
+//     head: one produces dq | dk, the other dv; P and dS change hands through a wave-private LDS strip), bn_qkv backward
+//     -> dqkv + its coefficients (global: weight-gradient job) and the normalised gradient tile (LDS), projection dgrad
+//   bn1 backward (ReLU mask by y1) -> dz1, conv_down dgrad + identity gradient + the fan-in deposit -> dx
+// What leaves the kernel for the recorded jobs is exactly what the six launches left: dz2, dqkv_w / coef_qkv_w, dqkv_h /
+// coef_qkv_h, dz1 for the four weight gradients, the eight per-group partial rows for the BatchNorm parameter gradients.
+// Verified on the CPU lane emulator against the reference's own fixture (tests/test_lane_emu.py); NOT yet run on the GPU.
+// ------------------------------------------------------------------------------------------------------------------------ //
+struct BlkBnB { const float *mean, *rstd, *scale, *shift, *weight; };   // saved statistics [groups][CH] + BatchNorm weight [CH]
+struct BlkBwdArgs {
+    const float *y, *dy, *dx_add, *z1, *y1, *z2;
+    const float *qkv[2], *stk[2], *lse[2], *yl[2];       // [0] height layer, [1] width layer; yl: the layer's output (ReLU mask)
+    BlkBnB bn[8];                                        // bn1 | bn_qkv, bn_similarity, bn_output (height) | the same (width) | bn2
+    float *dz2, *dz1, *dx;
+    float *dqkv[2], *coef_q[2];                          // gradient at the bn_qkv output + bn_qkv's backward as c0 d + c1 x + c2
+    float* part[8];                                      // per group: [CH][2] = sum g, sum g * xhat; bn_similarity: [G][4]
+    int training;
+};
+
+// Backward of a BatchNorm whose K channels' 64 values sit one per lane: g = gradient at its output, xr = its input.
+//   dz = A (g - m1 - xhat m2) (training) | A g (eval),  A = weight * rstd, m1 = mean g, m2 = mean g * xhat
+// The two sums go out as this group's partial row (what bn_bwd_finalize / wopos_small_bwd_finalize reduce over the groups into
+// the parameter gradients); coef (optional): the same backward as dz = c0 g + c1 x + c2 for the recorded weight-gradient job.
+template <int K>
+__device__ __forceinline__ void wave_bn_bwd(const float (&g)[K], const float (&xr)[K], const BlkBnB& bn, int grp, int CH, int ch0,
+                                            float* part, float* coef, int training, float (&dz)[K]) {
+    const int lane = threadIdx.x & 63;
+    float my1 = 0.f, my2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float mean = bn.mean[grp * CH + ch0 + k], rstd = bn.rstd[grp * CH + ch0 + k], A = bn.weight[ch0 + k] * rstd;
+        const float xh = (xr[k] - mean) * rstd;
+        const float s1 = blk_wave_sum(g[k]), s2 = blk_wave_sum(g[k] * xh);
+        const float m1 = training ? s1 * (1.f / 64.f) : 0.f, m2 = training ? s2 * (1.f / 64.f) : 0.f;
+        dz[k] = A * (g[k] - m1 - xh * m2);
+        if (lane == k) {
+            my1 = s1; my2 = s2;
+            c0 = A; c1 = -A * rstd * m2; c2 = A * (rstd * mean * m2 - m1);
+        }
+    }
+    if (lane < K) {
+        part[(size_t)(grp * CH + ch0 + lane) * 2] = my1;
+        part[(size_t)(grp * CH + ch0 + lane) * 2 + 1] = my2;
+        if (coef) {
+            float* cf = coef + (size_t)(grp * CH + ch0 + lane) * 3;
+            cf[0] = c0; cf[1] = c1; cf[2] = c2;
+        }
+    }
+}
+
+// out[k] = sum_o w[o * CIN + col0 + k] * T[o * 64 + lane]: K input channels of a 1x1 backward-data over the LDS tile T of the
+// COUT output-channel gradients; the K weights of a row are adjacent (one scalar load of K dwords per o)
+template <int K, int COUT, int CIN>
+__device__ __forceinline__ void wave_dgrad1x1(const float* __restrict__ w, int col0, const float* T, float (&acc)[K]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < COUT; ++o) {
+        const float t = T[o * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(w[(size_t)o * CIN + col0 + k], t, acc[k]);
+    }
+}
+
+// Backward of one AxialAttention_wopos layer: gio = gradient at the layer's output (channels wv * CW/16 ..) on entry, at its
+// input on return.  Q | D | S: tiles of the normalised q|k|v, of d(sv) and of sv; DZ: the gradient tile behind bn_qkv's backward;
+// E: this wave's private 4 x 64 strip.
+template <int CW, int GP, int AXIS, bool RELU>
+__device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_qkv, float (&gio)[CW / 16], float* Q, float* D,
+                                                   float* S, float* DZ, float* E, const BlkBnB& bq, const BlkBnB& bs,
+                                                   const BlkBnB& bo, const float* __restrict__ qkv_raw,
+                                                   const float* __restrict__ stacked, const float* __restrict__ lse,
+                                                   const float* __restrict__ yl, float* dqkv, float* coef_q, float* part_q,
+                                                   float* part_s, float* part_o, int grp, int n0, int training, int wv) {
+    constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 4, HW = 16, CB = 2 * CW / 16, HV = CW / 16;
+    static_assert(CB == NCH / 2 && HV * 2 == GP && 2 * HQ == CB, "two waves per head: q | k and v");
+    const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
+    const int g = wv >> 1, hf = wv & 1;
+    // everything global this layer needs, in one batch
+    float raw[CB], sv[HV], yv[HV];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) raw[k] = qkv_raw[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p];
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        sv[k] = stacked[((size_t)(n0 + ni) * CW + wv * HV + k) * HW + p];
+        yv[k] = RELU ? yl[((size_t)(n0 + ni) * CW + wv * HV + k) * HW + p] : 1.f;
+    }
+    const float ls = lse[((size_t)(n0 + ni) * G + g) * HW + p];
+    MEDT_SCHED_FENCE();
+    // 1. [ReLU mask,] bn_output backward; tiles                                               (axialnet.py:242, :381-383)
+    {
+        float gm[HV], d_o[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) gm[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : gio[k];
+        wave_bn_bwd<HV>(gm, sv, bo, grp, CW, wv * HV, part_o, nullptr, training, d_o);
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            D[(wv * HV + k) * 64 + lane] = d_o[k];
+            S[(wv * HV + k) * 64 + lane] = sv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < CB; ++k)
+            Q[(wv * CB + k) * 64 + lane] = fmaf(raw[k], bq.scale[grp * 2 * CW + wv * CB + k], bq.shift[grp * 2 * CW + wv * CB + k]);
+    }
+    MEDT_LDS_BARRIER();                                   // d(sv), sv and q | k | v of every head in LDS
+    // 2. softmax and bn_similarity backward of this lane's row (both waves of the head)            (:232-241)
+    const float* Qh = Q + g * NCH * 64;
+    const float* Dh = D + g * GP * 64;
+    const float* Sh = S + g * GP * 64;
+    const int i = AXIS == 1 ? (p & 3) : (p >> 2), sj = AXIS == 1 ? 1 : 4, base = lane - i * sj;
+    float dl[GP], dlt = 0.f;
+#pragma unroll
+    for (int c = 0; c < GP; ++c) {
+        dl[c] = Dh[c * 64 + lane];
+        dlt = fmaf(dl[c], Sh[c * 64 + lane], dlt);        // Delta_i = sum_c d(sv)[c,i] sv[c,i]
+    }
+    float qv[HQ];
+#pragma unroll
+    for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 64 + lane];
+    const float a_qk = bs.scale[grp * G + g] * MEDT_LOG2E;
+    float Sx[L], Px[L], dZ[L], v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int kj = base + j * sj;
+        float qk = 0.f, dP = 0.f;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qk = fmaf(qv[c], Qh[(HQ + c) * 64 + kj], qk);
+#pragma unroll
+        for (int c = 0; c < GP; ++c) dP = fmaf(dl[c], Qh[(GP + c) * 64 + kj], dP);
+        Sx[j] = qk;
+        Px[j] = __builtin_amdgcn_exp2f(fmaf(qk, a_qk, -ls));
+        dZ[j] = Px[j] * (dP - dlt);
+        v0 += dZ[j];
+        v1 = fmaf(dZ[j], qk, v1);
+    }
+    float ce, cu, cw;
+    {
+        const float a0 = blk_wave_sum(v0), ax = blk_wave_sum(v1);
+        if (hf == 0 && lane == 0) {
+            float* ps = part_s + (size_t)(grp * G + g) * 4;
+            ps[0] = a0; ps[1] = ax; ps[2] = 0.f; ps[3] = 0.f;
+        }
+        // same formulas as sim_bwd_finalize_kernel (axial_core.hip): dS = e dZ + u S + w
+        const float mean = bs.mean[grp * G + g], rstd = bs.rstd[grp * G + g];
+        ce = bs.weight[g] * rstd;
+        cu = 0.f; cw = 0.f;
+        if (training) {
+            const float icnt = 1.f / (64.f * L), m1 = a0 * icnt, m2 = rstd * (ax - mean * a0) * icnt;
+            cu = -ce * rstd * m2;
+            cw = -ce * m1 - cu * mean;
+        }
+    }
+    // 3. the head's 16 gradient rows: wave hf = 0 produces dq | dk, wave hf = 1 dv; what a lane needs of its row mates
+    //    (dS or P of the pairs in which it is the KEY) changes hands through the wave's LDS strip
+#pragma unroll
+    for (int j = 0; j < L; ++j) E[j * 64 + lane] = hf == 0 ? fmaf(ce, dZ[j], fmaf(cu, Sx[j], cw)) : Px[j];
+    __builtin_amdgcn_wave_barrier();
+    float gq[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) gq[k] = 0.f;
+    if (hf == 0) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int o = base + j * sj;
+            const float dS = fmaf(ce, dZ[j], fmaf(cu, Sx[j], cw));      // lane as query, o as key
+            const float dT = E[i * 64 + o];                              // o as query, lane as key
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                gq[c] = fmaf(dS, Qh[(HQ + c) * 64 + o], gq[c]);
+                gq[HQ + c] = fmaf(dT, Qh[c * 64 + o], gq[HQ + c]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int o = base + j * sj;
+            const float pT = E[i * 64 + o];
+#pragma unroll
+            for (int c = 0; c < GP; ++c) gq[c] = fmaf(pT, Dh[c * 64 + o], gq[c]);
+        }
+    }
+    // 4. bn_qkv backward                                                                       (:228)
+    {
+        float dzq[CB];
+        wave_bn_bwd<CB>(gq, raw, bq, grp, 2 * CW, wv * CB, part_q, coef_q, training, dzq);
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            dqkv[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = gq[k];
+            DZ[(wv * CB + k) * 64 + lane] = dzq[k];
+        }
+    }
+    MEDT_LDS_BARRIER();                                   // the gradient at the qkv_transform output in LDS
+    // 5. qkv_transform dgrad
+    wave_dgrad1x1<HV, 2 * CW, CW>(w_qkv, wv * HV, DZ, gio);
+}
+
+template <int CI, int CW, int GP>
+__global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __restrict__ w_down, const float* __restrict__ w_qh,
+                                                               const float* __restrict__ w_qw, const float* __restrict__ w_up,
+                                                               BlkBwdArgs a) {
+    constexpr int HW = 16, G = CW / GP, CA = CW / 16, CF = CI / 16;
+    static_assert(CI == 2 * CW, "tile sizes below");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS: every tile is written by all waves before one barrier and read by all waves behind it; a region is reused only by a
+    // phase that lies behind the barrier after its last readers' phase (see the phase list above)
+    float* BA = smem;                                   // [CI][64]  dz2, then the layers' gradient tiles behind bn_qkv
+    float* Q = BA + CI * 64;                            // [2CW][64] normalised q | k | v; at the end dz1
+    float* D = Q + 2 * CW * 64;                         // [CW][64]  d(sv)
+    float* S = D + CW * 64;                             // [CW][64]  sv
+    float* E = S + CW * 64;                             // [16][4][64] the waves' private strips
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, n0 = grp * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ni = lane >> 4, p = lane & 15;
+    // ---- bn2 backward behind the ReLU mask                                                       (axialnet.py:385-389)
+    {
+        float gy[CF], zz[CF], dz[CF];
+#pragma unroll
+        for (int k = 0; k < CF; ++k) {
+            const size_t e = ((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p;
+            const float yv = a.y[e];
+            gy[k] = a.dy[e];
+            zz[k] = a.z2[e];
+            if (!(yv > 0.f)) gy[k] = 0.f;
+        }
+        wave_bn_bwd<CF>(gy, zz, a.bn[7], grp, CI, wv * CF, a.part[7], nullptr, a.training, dz);
+#pragma unroll
+        for (int k = 0; k < CF; ++k) {
+            a.dz2[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = dz[k];
+            BA[(wv * CF + k) * 64 + lane] = dz[k];
+        }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_up dgrad                                                                            (:385)
+    float gio[CA];
+    wave_dgrad1x1<CA, CI, CW>(w_up, wv * CA, BA, gio);
+    // ---- width layer (behind the block's ReLU), height layer                                      (:377-383)
+    wave_attention_bwd<CW, GP, 1, true>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, a.bn[4], a.bn[5], a.bn[6], a.qkv[1], a.stk[1],
+                                        a.lse[1], a.yl[1], a.dqkv[1], a.coef_q[1], a.part[4], a.part[5], a.part[6], grp, n0,
+                                        a.training, wv);
+    wave_attention_bwd<CW, GP, 0, false>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, a.bn[1], a.bn[2], a.bn[3], a.qkv[0], a.stk[0],
+                                         a.lse[0], nullptr, a.dqkv[0], a.coef_q[0], a.part[1], a.part[2], a.part[3], grp, n0,
+                                         a.training, wv);
+    // ---- bn1 backward behind the ReLU mask                                                        (:373-375)
+    {
+        float gm[CA], zz[CA], dz[CA];
+#pragma unroll
+        for (int k = 0; k < CA; ++k) {
+            const size_t e = ((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p;
+            zz[k] = a.z1[e];
+            gm[k] = a.y1[e] > 0.f ? gio[k] : 0.f;
+        }
+        wave_bn_bwd<CA>(gm, zz, a.bn[0], grp, CW, wv * CA, a.part[0], nullptr, a.training, dz);
+#pragma unroll
+        for (int k = 0; k < CA; ++k) {
+            a.dz1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = dz[k];
+            Q[(wv * CA + k) * 64 + lane] = dz[k];
+        }
+    }
+    // the identity's gradient (the ReLU-masked dy again) and the other consumers' deposit, requested before the barrier
+    float add[CF];
+#pragma unroll
+    for (int k = 0; k < CF; ++k) {
+        const size_t e = ((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p;
+        const float yv = a.y[e], d = a.dy[e];
+        add[k] = (yv > 0.f ? d : 0.f) + (a.dx_add ? a.dx_add[e] : 0.f);
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_down dgrad + identity + deposit                                                     (:371, :387)
+    {
+        float dxv[CF];
+        wave_dgrad1x1<CF, CW, CI>(w_down, wv * CF, Q, dxv);
+#pragma unroll
+        for (int k = 0; k < CF; ++k) a.dx[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = dxv[k] + add[k];
+    }
+}
+
+#ifndef MEDT_LANE_EMU          // (tests/lane_emu compiles the kernels and the launch function only)
+// Workspace of the backward, in floats: the gradient tensors the recorded weight-gradient jobs read, bn_qkv's coefficients, the
+// partial rows of the eight BatchNorms, the coefficient outputs of bn1 / bn2's finalisation, the weight-gradient scratch slabs.
+struct BlkBwdWs {
+    float *dz2, *dz1, *dqkv[2], *coef_q[2], *part[8], *coef1, *coef2, *dw_scratch[4];
+    BlkBwdWs(Carver& c, const medt_block_desc& d) {
+        const int N = d.N, CI = d.C, CW = d.width, HW = d.H * d.W, gs = d.bn_groups, G = d.G;
+        dz2 = c.take<float>((size_t)N * CI * HW);
+        dz1 = c.take<float>((size_t)N * CW * HW);
+        for (int l = 0; l < 2; ++l) {
+            dqkv[l] = c.take<float>((size_t)N * 2 * CW * HW);
+            coef_q[l] = c.take<float>((size_t)gs * 2 * CW * 3);
+        }
+        const int chs[8] = {CW * 2, 2 * CW * 2, G * 4, CW * 2, 2 * CW * 2, G * 4, CW * 2, CI * 2};
+        for (int b = 0; b < 8; ++b) part[b] = c.take<float>((size_t)gs * chs[b]);
+        coef1 = c.take<float>((size_t)gs * CW * 3);
+        coef2 = c.take<float>((size_t)gs * CI * 3);
+        dw_scratch[0] = c.take<float>((size_t)conv2d_bwd_weight_splits(N, CI, CW, 1, d.H, d.W) * CW * CI);       // conv_down
+        dw_scratch[1] = c.take<float>((size_t)conv2d_bwd_weight_splits(N, CW, 2 * CW, 1, d.H, d.W) * 2 * CW * CW);
+        dw_scratch[2] = c.take<float>((size_t)conv2d_bwd_weight_splits(N, CW, 2 * CW, 1, d.H, d.W) * 2 * CW * CW);
+        dw_scratch[3] = c.take<float>((size_t)conv2d_bwd_weight_splits(N, CW, CI, 1, d.H, d.W) * CI * CW);       // conv_up
+    }
+};
+
+#endif
+
+static bool block_bwd_enabled() {
+    // default OFF until the kernel has been run and timed on the GPU (it is checked on the CPU lane emulator only so far)
+    static const bool on = [] { const char* e = getenv("MEDT_BLOCK_BWD"); return e && e[0] == '1'; }();
+    return on;
+}
+bool wopos_block_bwd_ok(const medt_block_desc& d) { return block_bwd_enabled() && wopos_block_ok(d); }
+
+#ifndef MEDT_LANE_EMU
+size_t wopos_block_bwd_ws_bytes(const medt_block_desc& d) {
+    Carver c(nullptr, 0);
+    BlkBwdWs w(c, d);
+    return align_up(c.off, 256) + 256;
+}
+#endif
+
+static BlkBnB blk_bnb(BnStats st, const float* weight) { return BlkBnB{st.mean, st.rstd, st.scale, st.shift, weight}; }
+
+// the kernel launch alone (device or -- tests/lane_emu -- emulated): statistics blocks and outputs as plain pointers
+int wopos_block_bwd_launch(const medt_block_desc& d, const medt_block_params& p, const float* y, const float* dy,
+                           const float* dx_add, const medt_block_saved& sv, const BnStats (&st)[8], float* dz2, float* dz1,
+                           float* const (&dqkv)[2], float* const (&coef_q)[2], float* const (&part)[8], float* dx, hipStream_t s) {
+    if (abl_skip("block_bwd")) return MEDT_OK;
+    BlkBwdArgs a;
+    a.y = y; a.dy = dy; a.dx_add = dx_add; a.z1 = sv.z1; a.y1 = sv.y1; a.z2 = sv.z2;
+    a.qkv[0] = (const float*)sv.height.qkv_raw; a.stk[0] = (const float*)sv.height.stacked; a.lse[0] = sv.height.lse; a.yl[0] = sv.y_h;
+    a.qkv[1] = (const float*)sv.width.qkv_raw; a.stk[1] = (const float*)sv.width.stacked; a.lse[1] = sv.width.lse; a.yl[1] = sv.y_w;
+    const float* wts[8] = {p.bn1.weight, p.height.bn_qkv.weight, p.height.bn_similarity.weight, p.height.bn_output.weight,
+                           p.width.bn_qkv.weight, p.width.bn_similarity.weight, p.width.bn_output.weight, p.bn2.weight};
+    for (int b = 0; b < 8; ++b) { a.bn[b] = blk_bnb(st[b], wts[b]); a.part[b] = part[b]; }
+    a.dz2 = dz2; a.dz1 = dz1; a.dx = dx;
+    for (int l = 0; l < 2; ++l) { a.dqkv[l] = dqkv[l]; a.coef_q[l] = coef_q[l]; }
+    a.training = d.training ? 1 : 0;
+    const size_t lds = ((size_t)(d.C + 2 * d.width + 2 * d.width) * 64 + 16 * 4 * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wopos_block_bwd_kernel<128, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wopos_block_bwd_kernel<128, 64, 8>), dim3(d.bn_groups), dim3(1024), lds, s, p.w_down, p.height.w_qkv,
+                       p.width.w_qkv, p.w_up, a);
+    return launch_status("wopos_block_bwd");
+}
+
+#ifndef MEDT_LANE_EMU
+// launch + the jobs nothing in the gradient chain waits for (recorded when a queue is bound to the stream, else issued now)
+int wopos_block_bwd(const medt_block_desc& d, const medt_block_params& p, const float* x, const float* y, const float* dy,
+                    const float* dx_add, const medt_block_saved& sv, float* dx, const medt_block_grads& gr, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+    Carver c(ws, ws_bytes);
+    BlkBwdWs w(c, d);
+    if (!ws || !c.ok()) { set_error("block bwd workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    const int gs = d.bn_groups, CW = d.width, CI = d.C, G = d.G, tr = d.training ? 1 : 0;
+    AxialGeom gh;
+    medt_axial_desc ad{d.N, CW, d.H, d.W, G, 0, 0, 1, d.training, gs, d.eps, d.momentum, 0, 0, 0};
+    int rc = axial_geom(ad, &gh);
+    if (rc) return rc;
+    BnStats st[8];
+    st[0] = BnStats(sv.stats1, gs * CW);
+    st[7] = BnStats(sv.stats2, gs * CI);
+    float* lst[2] = {sv.height.stats, sv.width.stats};
+    for (int l = 0; l < 2; ++l) {               // the three statistics blocks of a layer: bn_qkv | bn_similarity | bn_output
+        const int nq = gs * 2 * CW, ns = gs * G;
+        st[1 + 3 * l] = BnStats(lst[l], nq);
+        st[2 + 3 * l] = BnStats(lst[l] + 4 * (size_t)nq, ns);
+        st[3 + 3 * l] = BnStats(lst[l] + 4 * (size_t)(nq + ns), gs * CW);
+    }
+    if ((rc = wopos_block_bwd_launch(d, p, y, dy, dx_add, sv, st, w.dz2, w.dz1, w.dqkv, w.coef_q, w.part, dx, s))) return rc;
+    Queue* q = queue_for(s);
+    const double rows = (double)(d.N / gs) * d.H * d.W;
+    // BatchNorm parameter gradients: sums of the per-group partial rows
+    if (q) {
+        q->bfin.push_back(BfinJob{w.part[7], 1, gs, CI, tr, rows, 1.f, st[7], p.bn2.weight, w.coef2, gr.bn2_weight, gr.bn2_bias});
+        q->bfin.push_back(BfinJob{w.part[0], 1, gs, CW, tr, rows, 1.f, st[0], p.bn1.weight, w.coef1, gr.bn1_weight, gr.bn1_bias});
+    } else {
+        if ((rc = bn_bwd_finalize(w.part[7], 1, gs, CI, rows, 1.f, st[7], p.bn2.weight, tr, w.coef2, gr.bn2_weight, gr.bn2_bias, s)))
+            return rc;
+        if ((rc = bn_bwd_finalize(w.part[0], 1, gs, CW, rows, 1.f, st[0], p.bn1.weight, tr, w.coef1, gr.bn1_weight, gr.bn1_bias, s)))
+            return rc;
+    }
+    if ((rc = wopos_small_bwd_finalize(gh, ad, p.width, w.part[6], w.part[5], w.part[4], st[4], st[5], st[6], gr.width, s, q)))
+        return rc;
+    if ((rc = wopos_small_bwd_finalize(gh, ad, p.height, w.part[3], w.part[2], w.part[1], st[1], st[2], st[3], gr.height, s, q)))
+        return rc;
+    // weight gradients (the qkv_transforms' jobs apply bn_qkv's backward coefficients on load)
+    if ((rc = conv2d_bwd_weight(w.dz2, nullptr, nullptr, sv.y_w, gr.w_up, w.dw_scratch[3], d.N, CW, d.H, d.W, CI, 1, 1, 0, 1, s, q)))
+        return rc;
+    if ((rc = conv2d_bwd_weight(w.dqkv[1], (const float*)sv.width.qkv_raw, w.coef_q[1], sv.y_h, gr.width.w_qkv, w.dw_scratch[2],
+                                d.N, CW, d.H, d.W, 2 * CW, 1, 1, 0, gs, s, q))) return rc;
+    if ((rc = conv2d_bwd_weight(w.dqkv[0], (const float*)sv.height.qkv_raw, w.coef_q[0], sv.y1, gr.height.w_qkv, w.dw_scratch[1],
+                                d.N, CW, d.H, d.W, 2 * CW, 1, 1, 0, gs, s, q))) return rc;
+    return conv2d_bwd_weight(w.dz1, nullptr, nullptr, x, gr.w_down, w.dw_scratch[0], d.N, CI, d.H, d.W, CW, 1, 1, 0, 1, s, q);
+}
+#endif
+
 }  // namespace medt
 
 #ifdef MEDT_STAMPS

@@ -1,0 +1,120 @@
+// lane_emu.cpp -- see lane_emu.h (test infrastructure)
+#include "lane_emu.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <vector>
+
+namespace lane_emu {
+
+Idx3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+namespace {
+constexpr size_t STACK = 256 * 1024;
+struct Lane { ucontext_t ctx; bool done; int xpar; };
+struct Wave { int count, gen, alive; uint64_t slot[2][64]; };
+std::vector<Lane> lanes;
+std::vector<Wave> waves;
+ucontext_t main_ctx;
+int cur = -1, T = 0, alive = 0, bcount = 0, bgen = 0;
+long progress = 0;
+const std::function<void()>* body_fn = nullptr;
+
+void yield() { swapcontext(&lanes[cur].ctx, &main_ctx); }
+
+void release_block_if_complete() {
+    if (bcount > 0 && bcount == alive) { bcount = 0; ++bgen; ++progress; }
+}
+void release_wave_if_complete(Wave& w) {
+    if (w.count > 0 && w.count == w.alive) { w.count = 0; ++w.gen; ++progress; }
+}
+
+void trampoline() {
+    (*body_fn)();
+    Lane& me = lanes[cur];
+    me.done = true;
+    --alive;
+    Wave& w = waves[cur >> 6];
+    --w.alive;
+    ++progress;
+    release_block_if_complete();               // work-items that have exited do not take part in later barriers
+    release_wave_if_complete(w);
+    // returns to main_ctx through uc_link
+}
+}  // namespace
+
+int lane_id() { return cur & 63; }
+
+void block_barrier() {
+    const int gen = bgen;
+    ++bcount;
+    ++progress;
+    release_block_if_complete();
+    while (bgen == gen) yield();
+}
+
+void wave_barrier() {
+    Wave& w = waves[cur >> 6];
+    const int gen = w.gen;
+    ++w.count;
+    ++progress;
+    release_wave_if_complete(w);
+    while (w.gen == gen) yield();
+}
+
+uint64_t exchange(uint64_t v, int src_lane) {
+    Lane& me = lanes[cur];
+    Wave& w = waves[cur >> 6];
+    const int p = me.xpar;
+    me.xpar ^= 1;                               // (two slots: a lane can be at most one operation ahead of its wavefront)
+    w.slot[p][cur & 63] = v;
+    wave_barrier();
+    return w.slot[p][src_lane & 63];
+}
+
+void launch(Idx3 grid, Idx3 block, const std::function<void()>& body) {
+    if (block.y != 1 || block.z != 1) { fprintf(stderr, "lane_emu: 1-D workgroups only\n"); abort(); }
+    T = (int)block.x;
+    g_blockDim = block;
+    g_gridDim = grid;
+    body_fn = &body;
+    char* stacks = (char*)mmap(nullptr, STACK * T, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == MAP_FAILED) { perror("lane_emu: mmap"); abort(); }
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = Idx3{bx, by, bz};
+                lanes.assign(T, Lane());
+                waves.assign((T + 63) / 64, Wave());
+                alive = T; bcount = 0; bgen = 0;
+                for (int t = 0; t < T; ++t) {
+                    Lane& l = lanes[t];
+                    l.done = false; l.xpar = 0;
+                    getcontext(&l.ctx);
+                    l.ctx.uc_stack.ss_sp = stacks + STACK * t;
+                    l.ctx.uc_stack.ss_size = STACK;
+                    l.ctx.uc_link = &main_ctx;
+                    makecontext(&l.ctx, trampoline, 0);
+                    ++waves[t >> 6].alive;
+                }
+                while (alive > 0) {
+                    const long before = progress;
+                    for (int t = 0; t < T; ++t) {
+                        if (lanes[t].done) continue;
+                        cur = t;
+                        g_threadIdx = Idx3{(unsigned)t, 0, 0};
+                        swapcontext(&main_ctx, &lanes[t].ctx);
+                    }
+                    if (progress == before && alive > 0) {
+                        fprintf(stderr, "lane_emu: deadlock in workgroup (%u,%u,%u): %d work-items alive, %d at the barrier\n",
+                                bx, by, bz, alive, bcount);
+                        abort();
+                    }
+                }
+            }
+    munmap(stacks, STACK * T);
+    cur = -1;
+}
+
+}  // namespace lane_emu

@@ -1,0 +1,131 @@
+// hip/hip_runtime.h -- SHIM for tests/lane_emu (test infrastructure): the HIP vocabulary the block kernels use, mapped onto the
+// CPU lane emulator so that the kernels' .hip SOURCE compiles with g++.  Not a HIP implementation: only what
+// medical-transformer_amd/csrc/block_small.hip and the headers it includes touch.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "lane_emu.h"
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__
+
+using std::max;
+using std::min;
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+#define threadIdx lane_emu::g_threadIdx
+#define blockIdx lane_emu::g_blockIdx
+#define blockDim lane_emu::g_blockDim
+#define gridDim lane_emu::g_gridDim
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...)                                                      \
+    do {                                                                                                             \
+        const dim3 g_ = (grid), b_ = (block);                                                                        \
+        (void)(lds); (void)(stream);                                                                                 \
+        lane_emu::launch(lane_emu::Idx3{g_.x, g_.y, g_.z}, lane_emu::Idx3{b_.x, b_.y, b_.z}, [&]() { kern(__VA_ARGS__); }); \
+    } while (0)
+
+// ---- bit casts, transcendental builtins ------------------------------------------------------------------------------------
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline int __double2loint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int)(uint32_t)u; }
+static inline int __double2hiint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int)(uint32_t)(u >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+    const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    double d; memcpy(&d, &u, 8); return d;
+}
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+#define __log2f(x) log2f(x)          // (glibc declares these names itself)
+#define __expf(x) expf(x)
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+
+// ---- synchronisation -------------------------------------------------------------------------------------------------------
+static inline void __syncthreads() { lane_emu::block_barrier(); }
+static inline void __builtin_amdgcn_wave_barrier() { lane_emu::wave_barrier(); }
+static inline void __builtin_amdgcn_s_barrier() { lane_emu::block_barrier(); }
+// (the product's LDS-only barrier is inline gfx950 assembly; medt_common.h only defines it when this is not defined)
+#define MEDT_LDS_BARRIER() lane_emu::block_barrier()
+
+// ---- cross-lane operations (gfx950 semantics) --------------------------------------------------------------------------------
+static inline int lane_emu_dpp_source(int lane, int ctrl, bool* valid) {
+    const int row = lane & ~15, r = lane & 15;
+    *valid = true;
+    if (ctrl >= 0 && ctrl <= 0xFF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);      // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10F) { const int s = r + (ctrl & 15); *valid = s < 16; return row | (s & 15); }   // row_shl
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int s = r - (ctrl & 15); *valid = s >= 0; return row | (s & 15); }   // row_shr
+    if (ctrl >= 0x121 && ctrl <= 0x12F) return row | ((r - (ctrl & 15)) & 15);                                     // row_ror
+    if (ctrl == 0x140) return row | (15 - r);                                                                       // row_mirror
+    if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));                                                       // row_half_mirror
+    abort();
+}
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (row_mask != 0xf || bank_mask != 0xf) abort();
+    bool valid;
+    const int from = lane_emu_dpp_source(lane_emu::lane_id(), ctrl, &valid);
+    const int v = (int)(uint32_t)lane_emu::exchange((uint32_t)src, from);
+    return valid ? v : (bound_ctrl ? 0 : old);
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)lane_emu::exchange((uint32_t)v, lane); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)lane_emu::exchange((uint32_t)v, 0); }
+struct lane_emu_u2 {
+    unsigned v[2];
+    unsigned operator[](int i) const { return v[i]; }
+};
+// v_permlane16_swap: the odd rows of the first operand and the even rows of the second trade places
+static inline lane_emu_u2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    const int lane = lane_emu::lane_id(), row = lane >> 4;
+    // new a: even rows keep a, odd rows receive b of the row below; new b: odd rows keep b, even rows receive a of the row above
+    const uint64_t both = ((uint64_t)a << 32) | b;
+    const uint64_t other = lane_emu::exchange(both, lane ^ 16);
+    lane_emu_u2 r;
+    r.v[0] = (row & 1) ? (unsigned)other : a;
+    r.v[1] = (row & 1) ? b : (unsigned)(other >> 32);
+    return r;
+}
+// v_permlane32_swap: the upper half of the first operand and the lower half of the second trade places
+static inline lane_emu_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const int lane = lane_emu::lane_id();
+    const uint64_t both = ((uint64_t)a << 32) | b;
+    const uint64_t other = lane_emu::exchange(both, lane ^ 32);
+    lane_emu_u2 r;
+    r.v[0] = (lane & 32) ? (unsigned)other : a;
+    r.v[1] = (lane & 32) ? b : (unsigned)(other >> 32);
+    return r;
+}
+static inline float __shfl_xor(float v, int mask, int = 64) {
+    return __uint_as_float((unsigned)lane_emu::exchange(__float_as_uint(v), lane_emu::lane_id() ^ mask));
+}
+static inline double __shfl_xor(double v, int mask, int = 64) {
+    uint64_t u; memcpy(&u, &v, 8);
+    u = lane_emu::exchange(u, lane_emu::lane_id() ^ mask);
+    double d; memcpy(&d, &u, 8); return d;
+}
+static inline float __shfl(float v, int src, int = 64) {
+    return __uint_as_float((unsigned)lane_emu::exchange(__float_as_uint(v), src));
+}
