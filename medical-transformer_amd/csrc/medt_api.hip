@@ -632,6 +632,35 @@ int medt_wopos_block_fwd(const medt_block_desc* d, const medt_block_params* p, c
     return MEDT_OK;
 }
 
+size_t medt_wopos_block_bwd_workspace_bytes(const medt_block_desc* d) {
+    if (!d || !wopos_block_bwd_ok(*d)) return 0;
+    return wopos_block_bwd_ws_bytes(*d);
+}
+
+int medt_wopos_block_bwd(const medt_block_desc* d, const medt_block_params* p, const float* x, const float* y, const float* dy,
+                         const medt_block_saved* sv, float* dx, const float* dx_add, const medt_block_grads* gr, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (!d || !p || !x || !y || !dy || !sv || !dx || !gr) { set_error("block bwd: null argument"); return MEDT_EINVAL; }
+    if (!wopos_block_bwd_ok(*d)) { set_error("block bwd: shape not supported by the fused kernel, or MEDT_BLOCK_BWD != 1"); return MEDT_EUNSUPPORTED; }
+    if (!p->w_down || !p->w_up || !p->height.w_qkv || !p->width.w_qkv || !sv->z1 || !sv->y1 || !sv->stats1 || !sv->y_h ||
+        !sv->y_w || !sv->z2 || !sv->stats2 || !sv->height.qkv_raw || !sv->height.stacked || !sv->height.lse ||
+        !sv->height.stats || !sv->width.qkv_raw || !sv->width.stacked || !sv->width.lse || !sv->width.stats) {
+        set_error("block bwd: null pointer"); return MEDT_EINVAL;
+    }
+    const medt_bn_ptrs* bns[8] = {&p->bn1, &p->height.bn_qkv, &p->height.bn_similarity, &p->height.bn_output,
+                                  &p->width.bn_qkv, &p->width.bn_similarity, &p->width.bn_output, &p->bn2};
+    for (int b = 0; b < 8; ++b)
+        if (!bns[b]->weight) { set_error("block bwd: null BatchNorm weight"); return MEDT_EINVAL; }
+    const medt_axial_grads* ag[2] = {&gr->height, &gr->width};
+    for (int l = 0; l < 2; ++l)
+        if (!ag[l]->w_qkv || !ag[l]->bn_qkv_weight || !ag[l]->bn_qkv_bias || !ag[l]->bn_sim_weight || !ag[l]->bn_sim_bias ||
+            !ag[l]->bn_out_weight || !ag[l]->bn_out_bias) { set_error("block bwd: null gradient pointer"); return MEDT_EINVAL; }
+    if (!gr->w_down || !gr->bn1_weight || !gr->bn1_bias || !gr->w_up || !gr->bn2_weight || !gr->bn2_bias) {
+        set_error("block bwd: null gradient pointer"); return MEDT_EINVAL;
+    }
+    return wopos_block_bwd(*d, *p, x, y, dy, dx_add, *sv, dx, *gr, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int medt_gate_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* xn, float* h,
                       float* o, float* gates, int N, int C, int H, int W, int axis, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !xn || !h || !o || !gates || N < 1 || C < 1 || C > 4096 || H < 1 || W < 1) {

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: provides the HIP runtime the lib
 from .build import LIB_PATH
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MedtError(RuntimeError):
@@ -73,6 +73,11 @@ class BlockSaved(C.Structure):
                 ("stats2", C.c_void_p)]
 
 
+class BlockGrads(C.Structure):
+    _fields_ = [("w_down", C.c_void_p), ("bn1_weight", C.c_void_p), ("bn1_bias", C.c_void_p), ("height", AxialGrads),
+                ("width", AxialGrads), ("w_up", C.c_void_p), ("bn2_weight", C.c_void_p), ("bn2_bias", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "medt_abi_version": (C.c_int, []),
@@ -99,6 +104,10 @@ SIGNATURES = {
     "medt_wopos_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "medt_wopos_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams), C.c_void_p, C.c_void_p,
                                        C.POINTER(BlockSaved), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_wopos_block_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
+    "medt_wopos_block_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(BlockSaved), C.c_void_p, C.c_void_p, C.POINTER(BlockGrads), C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
     "medt_conv_stats_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "medt_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "medt_conv_block_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BnPtrs),

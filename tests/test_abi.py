@@ -48,6 +48,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.BlockDesc) == 10 * 4
     assert ctypes.sizeof(_lib.BlockParams) == 8 + 40 + 2 * (8 + 3 * 40 + 5 * 8) + 8 + 40
     assert ctypes.sizeof(_lib.BlockSaved) == 3 * 8 + 32 + 8 + 32 + 3 * 8
+    assert ctypes.sizeof(_lib.BlockGrads) == 3 * 8 + 2 * 9 * 8 + 3 * 8
 
 
 def test_descriptor_validation_no_gpu_needed(lib):
@@ -80,6 +81,10 @@ def test_block_descriptor_validation(lib):
                 _lib.BlockDesc(64, 64, 32, 4, 4, 8, 1, 16, 1e-5, 0.1)):   # other widths
         assert lib.medt_wopos_block_workspace_bytes(ctypes.byref(bad)) == 0
     assert lib.medt_wopos_block_fwd(ctypes.byref(ok), None, None, None, None, None, 0, None) < 0      # null arguments: refused
+    # the one-launch backward is off until it has been run on the GPU (MEDT_BLOCK_BWD=1): no workspace, the entry refuses
+    if os.environ.get("MEDT_BLOCK_BWD", "0") != "1":
+        assert lib.medt_wopos_block_bwd_workspace_bytes(ctypes.byref(ok)) == 0
+    assert lib.medt_wopos_block_bwd(ctypes.byref(ok), None, None, None, None, None, None, None, None, None, 0, None) < 0
 
 
 def test_single_hip_runtime(lib):
