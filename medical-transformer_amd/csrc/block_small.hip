@@ -390,14 +390,33 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
 // coef_qkv_h, dz1 for the four weight gradients, the eight per-group partial rows for the BatchNorm parameter gradients.
 // Verified on the CPU lane emulator against the reference's own fixture (tests/test_lane_emu.py); NOT yet run on the GPU.
 // ------------------------------------------------------------------------------------------------------------------------ //
-struct BlkBnB { const float *mean, *rstd, *scale, *shift, *weight; };   // saved statistics [groups][CH] + BatchNorm weight [CH]
+// A BatchNorm as the backward reads it: its saved-statistics block (mean | rstd | scale | shift, n = groups * CH floats each,
+// medt_common.h: BnStats) and its weight.  All of it is wave-uniform data written by EARLIER launches: blk_ldu reads it through
+// the constant address space, i.e. the scalar unit (s_load), like the convolution weights.
+struct BlkBnB { const float* st; int n; const float* gamma; };
+#ifdef MEDT_LANE_EMU
+__device__ __forceinline__ float blk_ldu(const float* p) { return *p; }
+#else
+__device__ __forceinline__ float blk_ldu(const float* p) {
+    return *(const float __attribute__((address_space(4)))*)(uintptr_t)p;
+}
+#endif
+// floats before BatchNorm b's partial rows in the kernel's one partial-row buffer: [groups][CH][2] each (bn_similarity: [G][4]),
+// in the order bn1 | bn_qkv, bn_similarity, bn_output (height) | the same (width) | bn2
+__host__ __device__ inline size_t blk_part_off(int b, int gs, int CW, int CI, int G) {
+    const int sz[8] = {CW * 2, 2 * CW * 2, G * 4, CW * 2, 2 * CW * 2, G * 4, CW * 2, CI * 2};
+    size_t o = 0;
+    for (int i = 0; i < b; ++i) o += (size_t)gs * sz[i];
+    return o;
+}
 struct BlkBwdArgs {
     const float *y, *dy, *dx_add, *z1, *y1, *z2;
-    const float *qkv[2], *stk[2], *lse[2], *yl[2];       // [0] height layer, [1] width layer; yl: the layer's output (ReLU mask)
-    BlkBnB bn[8];                                        // bn1 | bn_qkv, bn_similarity, bn_output (height) | the same (width) | bn2
+    const float *qkv[2], *stk[2], *lse[2], *y_w;         // [0] height layer, [1] width layer; y_w: the width layer's output (ReLU mask)
+    const float* stats[4];                               // stats1 | height layer's block | width layer's block | stats2
+    const float* gamma[8];                               // BatchNorm weights: bn1 | qkv, similarity, output (height) | (width) | bn2
     float *dz2, *dz1, *dx;
     float *dqkv[2], *coef_q[2];                          // gradient at the bn_qkv output + bn_qkv's backward as c0 d + c1 x + c2
-    float* part[8];                                      // per group: [CH][2] = sum g, sum g * xhat; bn_similarity: [G][4]
+    float* part;                                         // the eight BatchNorms' partial rows (blk_part_off)
     int training;
 };
 
@@ -412,7 +431,8 @@ __device__ __forceinline__ void wave_bn_bwd(const float (&g)[K], const float (&x
     float my1 = 0.f, my2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float mean = bn.mean[grp * CH + ch0 + k], rstd = bn.rstd[grp * CH + ch0 + k], A = bn.weight[ch0 + k] * rstd;
+        const float mean = blk_ldu(bn.st + grp * CH + ch0 + k), rstd = blk_ldu(bn.st + bn.n + grp * CH + ch0 + k);
+        const float A = blk_ldu(bn.gamma + ch0 + k) * rstd;
         const float xh = (xr[k] - mean) * rstd;
         const float s1 = blk_wave_sum(g[k]), s2 = blk_wave_sum(g[k] * xh);
         const float m1 = training ? s1 * (1.f / 64.f) : 0.f, m2 = training ? s2 * (1.f / 64.f) : 0.f;
@@ -423,10 +443,10 @@ __device__ __forceinline__ void wave_bn_bwd(const float (&g)[K], const float (&x
         }
     }
     if (lane < K) {
-        part[(size_t)(grp * CH + ch0 + lane) * 2] = my1;
-        part[(size_t)(grp * CH + ch0 + lane) * 2 + 1] = my2;
+        part[(unsigned)(grp * CH + ch0 + lane) * 2] = my1;
+        part[(unsigned)(grp * CH + ch0 + lane) * 2 + 1] = my2;
         if (coef) {
-            float* cf = coef + (size_t)(grp * CH + ch0 + lane) * 3;
+            float* cf = coef + (unsigned)(grp * CH + ch0 + lane) * 3;
             cf[0] = c0; cf[1] = c1; cf[2] = c2;
         }
     }
@@ -443,7 +463,7 @@ __device__ __forceinline__ void wave_dgrad1x1(const float* __restrict__ w, int c
     for (int o = 0; o < COUT; ++o) {
         const float t = T[o * 64 + lane];
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = fmaf(w[(size_t)o * CIN + col0 + k], t, acc[k]);
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(w[o * CIN + col0 + k], t, acc[k]);
     }
 }
 
@@ -462,15 +482,17 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
     const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
     const int g = wv >> 1, hf = wv & 1;
     // everything global this layer needs, in one batch
+    // (32-bit element offsets: one address register per tensor shape, the channel steps fold into the instruction offsets)
+    const unsigned eq = ((unsigned)(n0 + ni) * 2 * CW + wv * CB) * HW + p, ev = ((unsigned)(n0 + ni) * CW + wv * HV) * HW + p;
     float raw[CB], sv[HV], yv[HV];
 #pragma unroll
-    for (int k = 0; k < CB; ++k) raw[k] = qkv_raw[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p];
+    for (int k = 0; k < CB; ++k) raw[k] = qkv_raw[eq + k * HW];
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
-        sv[k] = stacked[((size_t)(n0 + ni) * CW + wv * HV + k) * HW + p];
-        yv[k] = RELU ? yl[((size_t)(n0 + ni) * CW + wv * HV + k) * HW + p] : 1.f;
+        sv[k] = stacked[ev + k * HW];
+        yv[k] = RELU ? yl[ev + k * HW] : 1.f;
     }
-    const float ls = lse[((size_t)(n0 + ni) * G + g) * HW + p];
+    const float ls = lse[((unsigned)(n0 + ni) * G + g) * HW + p];
     MEDT_SCHED_FENCE();
     // 1. [ReLU mask,] bn_output backward; tiles                                               (axialnet.py:242, :381-383)
     {
@@ -485,7 +507,8 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
         }
 #pragma unroll
         for (int k = 0; k < CB; ++k)
-            Q[(wv * CB + k) * 64 + lane] = fmaf(raw[k], bq.scale[grp * 2 * CW + wv * CB + k], bq.shift[grp * 2 * CW + wv * CB + k]);
+            Q[(wv * CB + k) * 64 + lane] = fmaf(raw[k], blk_ldu(bq.st + 2 * bq.n + grp * 2 * CW + wv * CB + k),
+                                                blk_ldu(bq.st + 3 * bq.n + grp * 2 * CW + wv * CB + k));
     }
     MEDT_LDS_BARRIER();                                   // d(sv), sv and q | k | v of every head in LDS
     // 2. softmax and bn_similarity backward of this lane's row (both waves of the head)            (:232-241)
@@ -502,7 +525,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
     float qv[HQ];
 #pragma unroll
     for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 64 + lane];
-    const float a_qk = bs.scale[grp * G + g] * MEDT_LOG2E;
+    const float a_qk = blk_ldu(bs.st + 2 * bs.n + grp * G + g) * MEDT_LOG2E;
     float Sx[L], Px[L], dZ[L], v0 = 0.f, v1 = 0.f;
 #pragma unroll
     for (int j = 0; j < L; ++j) {
@@ -522,12 +545,12 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
     {
         const float a0 = blk_wave_sum(v0), ax = blk_wave_sum(v1);
         if (hf == 0 && lane == 0) {
-            float* ps = part_s + (size_t)(grp * G + g) * 4;
+            float* ps = part_s + (unsigned)(grp * G + g) * 4;
             ps[0] = a0; ps[1] = ax; ps[2] = 0.f; ps[3] = 0.f;
         }
         // same formulas as sim_bwd_finalize_kernel (axial_core.hip): dS = e dZ + u S + w
-        const float mean = bs.mean[grp * G + g], rstd = bs.rstd[grp * G + g];
-        ce = bs.weight[g] * rstd;
+        const float mean = blk_ldu(bs.st + grp * G + g), rstd = blk_ldu(bs.st + bs.n + grp * G + g);
+        ce = blk_ldu(bs.gamma + g) * rstd;
         cu = 0.f; cw = 0.f;
         if (training) {
             const float icnt = 1.f / (64.f * L), m1 = a0 * icnt, m2 = rstd * (ax - mean * a0) * icnt;
@@ -570,7 +593,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
         wave_bn_bwd<CB>(gq, raw, bq, grp, 2 * CW, wv * CB, part_q, coef_q, training, dzq);
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
-            dqkv[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = gq[k];
+            dqkv[eq + k * HW] = gq[k];
             DZ[(wv * CB + k) * 64 + lane] = dzq[k];
         }
     }
@@ -596,21 +619,27 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, n0 = grp * 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ni = lane >> 4, p = lane & 15;
+    const int gs = gridDim.x, nq = gs * 2 * CW, ns = gs * G, no = gs * CW;
+    const BlkBnB bn1{a.stats[0], gs * CW, a.gamma[0]}, bn2{a.stats[3], gs * CI, a.gamma[7]};
+    const BlkBnB bqh{a.stats[1], nq, a.gamma[1]}, bsh{a.stats[1] + 4 * nq, ns, a.gamma[2]}, boh{a.stats[1] + 4 * (nq + ns), no, a.gamma[3]};
+    const BlkBnB bqw{a.stats[2], nq, a.gamma[4]}, bsw{a.stats[2] + 4 * nq, ns, a.gamma[5]}, bow{a.stats[2] + 4 * (nq + ns), no, a.gamma[6]};
+    float* const part = a.part;
+    // 32-bit element offsets of this lane's first channel in the (N, CI, 4, 4) and (N, CW, 4, 4) tensors
+    const unsigned ei = ((unsigned)(n0 + ni) * CI + wv * CF) * HW + p, ew = ((unsigned)(n0 + ni) * CW + wv * CA) * HW + p;
     // ---- bn2 backward behind the ReLU mask                                                       (axialnet.py:385-389)
     {
         float gy[CF], zz[CF], dz[CF];
 #pragma unroll
         for (int k = 0; k < CF; ++k) {
-            const size_t e = ((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p;
-            const float yv = a.y[e];
-            gy[k] = a.dy[e];
-            zz[k] = a.z2[e];
+            const float yv = a.y[ei + k * HW];
+            gy[k] = a.dy[ei + k * HW];
+            zz[k] = a.z2[ei + k * HW];
             if (!(yv > 0.f)) gy[k] = 0.f;
         }
-        wave_bn_bwd<CF>(gy, zz, a.bn[7], grp, CI, wv * CF, a.part[7], nullptr, a.training, dz);
+        wave_bn_bwd<CF>(gy, zz, bn2, grp, CI, wv * CF, part + blk_part_off(7, gs, CW, CI, G), nullptr, a.training, dz);
 #pragma unroll
         for (int k = 0; k < CF; ++k) {
-            a.dz2[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = dz[k];
+            a.dz2[ei + k * HW] = dz[k];
             BA[(wv * CF + k) * 64 + lane] = dz[k];
         }
     }
@@ -619,25 +648,26 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     float gio[CA];
     wave_dgrad1x1<CA, CI, CW>(w_up, wv * CA, BA, gio);
     // ---- width layer (behind the block's ReLU), height layer                                      (:377-383)
-    wave_attention_bwd<CW, GP, 1, true>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, a.bn[4], a.bn[5], a.bn[6], a.qkv[1], a.stk[1],
-                                        a.lse[1], a.yl[1], a.dqkv[1], a.coef_q[1], a.part[4], a.part[5], a.part[6], grp, n0,
+    wave_attention_bwd<CW, GP, 1, true>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, bqw, bsw, bow, a.qkv[1], a.stk[1], a.lse[1], a.y_w,
+                                        a.dqkv[1], a.coef_q[1], part + blk_part_off(4, gs, CW, CI, G),
+                                        part + blk_part_off(5, gs, CW, CI, G), part + blk_part_off(6, gs, CW, CI, G), grp, n0,
                                         a.training, wv);
-    wave_attention_bwd<CW, GP, 0, false>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, a.bn[1], a.bn[2], a.bn[3], a.qkv[0], a.stk[0],
-                                         a.lse[0], nullptr, a.dqkv[0], a.coef_q[0], a.part[1], a.part[2], a.part[3], grp, n0,
+    wave_attention_bwd<CW, GP, 0, false>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, bqh, bsh, boh, a.qkv[0], a.stk[0], a.lse[0], nullptr,
+                                         a.dqkv[0], a.coef_q[0], part + blk_part_off(1, gs, CW, CI, G),
+                                         part + blk_part_off(2, gs, CW, CI, G), part + blk_part_off(3, gs, CW, CI, G), grp, n0,
                                          a.training, wv);
     // ---- bn1 backward behind the ReLU mask                                                        (:373-375)
     {
         float gm[CA], zz[CA], dz[CA];
 #pragma unroll
         for (int k = 0; k < CA; ++k) {
-            const size_t e = ((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p;
-            zz[k] = a.z1[e];
-            gm[k] = a.y1[e] > 0.f ? gio[k] : 0.f;
+            zz[k] = a.z1[ew + k * HW];
+            gm[k] = a.y1[ew + k * HW] > 0.f ? gio[k] : 0.f;
         }
-        wave_bn_bwd<CA>(gm, zz, a.bn[0], grp, CW, wv * CA, a.part[0], nullptr, a.training, dz);
+        wave_bn_bwd<CA>(gm, zz, bn1, grp, CW, wv * CA, part, nullptr, a.training, dz);
 #pragma unroll
         for (int k = 0; k < CA; ++k) {
-            a.dz1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = dz[k];
+            a.dz1[ew + k * HW] = dz[k];
             Q[(wv * CA + k) * 64 + lane] = dz[k];
         }
     }
@@ -645,9 +675,8 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     float add[CF];
 #pragma unroll
     for (int k = 0; k < CF; ++k) {
-        const size_t e = ((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p;
-        const float yv = a.y[e], d = a.dy[e];
-        add[k] = (yv > 0.f ? d : 0.f) + (a.dx_add ? a.dx_add[e] : 0.f);
+        const float yv = a.y[ei + k * HW], d = a.dy[ei + k * HW];
+        add[k] = (yv > 0.f ? d : 0.f) + (a.dx_add ? a.dx_add[ei + k * HW] : 0.f);
     }
     MEDT_LDS_BARRIER();
     // ---- conv_down dgrad + identity + deposit                                                     (:371, :387)
@@ -655,7 +684,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
         float dxv[CF];
         wave_dgrad1x1<CF, CW, CI>(w_down, wv * CF, Q, dxv);
 #pragma unroll
-        for (int k = 0; k < CF; ++k) a.dx[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = dxv[k] + add[k];
+        for (int k = 0; k < CF; ++k) a.dx[ei + k * HW] = dxv[k] + add[k];
     }
 }
 
@@ -663,7 +692,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
 // Workspace of the backward, in floats: the gradient tensors the recorded weight-gradient jobs read, bn_qkv's coefficients, the
 // partial rows of the eight BatchNorms, the coefficient outputs of bn1 / bn2's finalisation, the weight-gradient scratch slabs.
 struct BlkBwdWs {
-    float *dz2, *dz1, *dqkv[2], *coef_q[2], *part[8], *coef1, *coef2, *dw_scratch[4];
+    float *dz2, *dz1, *dqkv[2], *coef_q[2], *part, *coef1, *coef2, *dw_scratch[4];
     BlkBwdWs(Carver& c, const medt_block_desc& d) {
         const int N = d.N, CI = d.C, CW = d.width, HW = d.H * d.W, gs = d.bn_groups, G = d.G;
         dz2 = c.take<float>((size_t)N * CI * HW);
@@ -672,8 +701,7 @@ struct BlkBwdWs {
             dqkv[l] = c.take<float>((size_t)N * 2 * CW * HW);
             coef_q[l] = c.take<float>((size_t)gs * 2 * CW * 3);
         }
-        const int chs[8] = {CW * 2, 2 * CW * 2, G * 4, CW * 2, 2 * CW * 2, G * 4, CW * 2, CI * 2};
-        for (int b = 0; b < 8; ++b) part[b] = c.take<float>((size_t)gs * chs[b]);
+        part = c.take<float>(blk_part_off(8, gs, CW, CI, G));
         coef1 = c.take<float>((size_t)gs * CW * 3);
         coef2 = c.take<float>((size_t)gs * CI * 3);
         dw_scratch[0] = c.take<float>((size_t)conv2d_bwd_weight_splits(N, CI, CW, 1, d.H, d.W) * CW * CI);       // conv_down
@@ -700,20 +728,21 @@ size_t wopos_block_bwd_ws_bytes(const medt_block_desc& d) {
 }
 #endif
 
-static BlkBnB blk_bnb(BnStats st, const float* weight) { return BlkBnB{st.mean, st.rstd, st.scale, st.shift, weight}; }
-
-// the kernel launch alone (device or -- tests/lane_emu -- emulated): statistics blocks and outputs as plain pointers
+// the kernel launch alone (device or -- tests/lane_emu -- emulated).  stats: stats1 | the height layer's block | the width
+// layer's block | stats2 (medt_block_saved); part: blk_part_off(8, ...) floats
 int wopos_block_bwd_launch(const medt_block_desc& d, const medt_block_params& p, const float* y, const float* dy,
-                           const float* dx_add, const medt_block_saved& sv, const BnStats (&st)[8], float* dz2, float* dz1,
-                           float* const (&dqkv)[2], float* const (&coef_q)[2], float* const (&part)[8], float* dx, hipStream_t s) {
+                           const float* dx_add, const medt_block_saved& sv, float* dz2, float* dz1, float* const (&dqkv)[2],
+                           float* const (&coef_q)[2], float* part, float* dx, hipStream_t s) {
     if (abl_skip("block_bwd")) return MEDT_OK;
     BlkBwdArgs a;
     a.y = y; a.dy = dy; a.dx_add = dx_add; a.z1 = sv.z1; a.y1 = sv.y1; a.z2 = sv.z2;
-    a.qkv[0] = (const float*)sv.height.qkv_raw; a.stk[0] = (const float*)sv.height.stacked; a.lse[0] = sv.height.lse; a.yl[0] = sv.y_h;
-    a.qkv[1] = (const float*)sv.width.qkv_raw; a.stk[1] = (const float*)sv.width.stacked; a.lse[1] = sv.width.lse; a.yl[1] = sv.y_w;
+    a.qkv[0] = (const float*)sv.height.qkv_raw; a.stk[0] = (const float*)sv.height.stacked; a.lse[0] = sv.height.lse;
+    a.qkv[1] = (const float*)sv.width.qkv_raw; a.stk[1] = (const float*)sv.width.stacked; a.lse[1] = sv.width.lse; a.y_w = sv.y_w;
+    a.stats[0] = sv.stats1; a.stats[1] = sv.height.stats; a.stats[2] = sv.width.stats; a.stats[3] = sv.stats2;
     const float* wts[8] = {p.bn1.weight, p.height.bn_qkv.weight, p.height.bn_similarity.weight, p.height.bn_output.weight,
                            p.width.bn_qkv.weight, p.width.bn_similarity.weight, p.width.bn_output.weight, p.bn2.weight};
-    for (int b = 0; b < 8; ++b) { a.bn[b] = blk_bnb(st[b], wts[b]); a.part[b] = part[b]; }
+    for (int b = 0; b < 8; ++b) a.gamma[b] = wts[b];
+    a.part = part;
     a.dz2 = dz2; a.dz1 = dz1; a.dx = dx;
     for (int l = 0; l < 2; ++l) { a.dqkv[l] = dqkv[l]; a.coef_q[l] = coef_q[l]; }
     a.training = d.training ? 1 : 0;
@@ -752,22 +781,24 @@ int wopos_block_bwd(const medt_block_desc& d, const medt_block_params& p, const 
         st[2 + 3 * l] = BnStats(lst[l] + 4 * (size_t)nq, ns);
         st[3 + 3 * l] = BnStats(lst[l] + 4 * (size_t)(nq + ns), gs * CW);
     }
-    if ((rc = wopos_block_bwd_launch(d, p, y, dy, dx_add, sv, st, w.dz2, w.dz1, w.dqkv, w.coef_q, w.part, dx, s))) return rc;
+    if ((rc = wopos_block_bwd_launch(d, p, y, dy, dx_add, sv, w.dz2, w.dz1, w.dqkv, w.coef_q, w.part, dx, s))) return rc;
+    float* part[8];
+    for (int b = 0; b < 8; ++b) part[b] = w.part + blk_part_off(b, gs, CW, CI, G);
     Queue* q = queue_for(s);
     const double rows = (double)(d.N / gs) * d.H * d.W;
     // BatchNorm parameter gradients: sums of the per-group partial rows
     if (q) {
-        q->bfin.push_back(BfinJob{w.part[7], 1, gs, CI, tr, rows, 1.f, st[7], p.bn2.weight, w.coef2, gr.bn2_weight, gr.bn2_bias});
-        q->bfin.push_back(BfinJob{w.part[0], 1, gs, CW, tr, rows, 1.f, st[0], p.bn1.weight, w.coef1, gr.bn1_weight, gr.bn1_bias});
+        q->bfin.push_back(BfinJob{part[7], 1, gs, CI, tr, rows, 1.f, st[7], p.bn2.weight, w.coef2, gr.bn2_weight, gr.bn2_bias});
+        q->bfin.push_back(BfinJob{part[0], 1, gs, CW, tr, rows, 1.f, st[0], p.bn1.weight, w.coef1, gr.bn1_weight, gr.bn1_bias});
     } else {
-        if ((rc = bn_bwd_finalize(w.part[7], 1, gs, CI, rows, 1.f, st[7], p.bn2.weight, tr, w.coef2, gr.bn2_weight, gr.bn2_bias, s)))
+        if ((rc = bn_bwd_finalize(part[7], 1, gs, CI, rows, 1.f, st[7], p.bn2.weight, tr, w.coef2, gr.bn2_weight, gr.bn2_bias, s)))
             return rc;
-        if ((rc = bn_bwd_finalize(w.part[0], 1, gs, CW, rows, 1.f, st[0], p.bn1.weight, tr, w.coef1, gr.bn1_weight, gr.bn1_bias, s)))
+        if ((rc = bn_bwd_finalize(part[0], 1, gs, CW, rows, 1.f, st[0], p.bn1.weight, tr, w.coef1, gr.bn1_weight, gr.bn1_bias, s)))
             return rc;
     }
-    if ((rc = wopos_small_bwd_finalize(gh, ad, p.width, w.part[6], w.part[5], w.part[4], st[4], st[5], st[6], gr.width, s, q)))
+    if ((rc = wopos_small_bwd_finalize(gh, ad, p.width, part[6], part[5], part[4], st[4], st[5], st[6], gr.width, s, q)))
         return rc;
-    if ((rc = wopos_small_bwd_finalize(gh, ad, p.height, w.part[3], w.part[2], w.part[1], st[1], st[2], st[3], gr.height, s, q)))
+    if ((rc = wopos_small_bwd_finalize(gh, ad, p.height, part[3], part[2], part[1], st[1], st[2], st[3], gr.height, s, q)))
         return rc;
     // weight gradients (the qkv_transforms' jobs apply bn_qkv's backward coefficients on load)
     if ((rc = conv2d_bwd_weight(w.dz2, nullptr, nullptr, sv.y_w, gr.w_up, w.dw_scratch[3], d.N, CW, d.H, d.W, CI, 1, 1, 0, 1, s, q)))

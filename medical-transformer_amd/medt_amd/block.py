@@ -5,6 +5,11 @@ conv_down+bn1+ReLU, two attention layers and conv_up+bn2+identity+ReLU as four d
 the whole block as one launch that writes exactly the tensors the four stages save for their backward; the four
 autograd Functions are then applied in "adopt" mode (`pre=`): they wrap the precomputed outputs, save what they always
 save, and launch nothing -- the autograd graph, and with it the whole backward, is the one of the per-stage path.
+
+`block_forward` (MEDT_BLOCK_BWD=1 only) wraps the same forward launch into ONE autograd Function whose backward is the
+one-launch block backward (medt_wopos_block_bwd): six dependent launches -> one.  That kernel is verified against the
+reference fixture on the CPU lane emulator (tests/test_lane_emu.py) and is OFF by default until it has been run and timed
+on the GPU.
 """
 from __future__ import annotations
 
@@ -18,6 +23,7 @@ from . import defer as DEFER
 from .axial import _bn_ptrs
 
 ENABLED = os.environ.get("MEDT_BLOCK_FUSED", "1") != "0" and os.environ.get("MEDT_DISABLE_SMALL", "0") != "1"
+BWD_ENABLED = ENABLED and os.environ.get("MEDT_BLOCK_BWD", "0") == "1"     # (the library reads the same variable)
 
 
 def _axial_params(att, training) -> L.AxialParams:
@@ -79,3 +85,98 @@ def fused_forward(blk, x, bn_groups: int):
     if q is not None:                      # the recorded statistics jobs read the partial sums and write the stats blocks
         q.hold(ws, stats1, sv[0][3], sv[1][3], stats2)
     return {"down": (z1, y1, stats1), "h": sv[0], "w": sv[1], "up": (z2, y, stats2)}
+
+
+# --------------------------------------------------------------------------- #
+# the whole block as one autograd node: one-launch forward, one-launch backward
+# --------------------------------------------------------------------------- #
+def _block_params(blk):
+    """The 20 trained tensors of an AxialBlock_wopos in gradient order (conv1 is registered and never used)."""
+    h, w = blk.hight_block, blk.width_block
+    out = [blk.conv_down.weight, blk.bn1.weight, blk.bn1.bias]
+    for a in (h, w):
+        out += [a.qkv_transform.weight, a.bn_qkv.weight, a.bn_qkv.bias, a.bn_similarity.weight, a.bn_similarity.bias,
+                a.bn_output.weight, a.bn_output.bias]
+    return out + [blk.conv_up.weight, blk.bn2.weight, blk.bn2.bias]
+
+
+class WoposBlockFn(torch.autograd.Function):
+    """y = AxialBlock_wopos(x) (reference lib/models/axialnet.py:368-391).  Inputs: x, then the 20 tensors of _block_params."""
+
+    @staticmethod
+    def forward(ctx, x, *rest):
+        from . import optim as OPT
+        params, (blk, bn_groups, sink, pre) = rest[:20], rest[20:]
+        ctx.geom = (x.shape[0], x.shape[1], params[0].shape[0], x.shape[2], x.shape[3], blk.hight_block.groups,
+                    int(blk.bn1.training), bn_groups, blk.bn1.eps, float(blk.bn1.momentum))
+        ctx.sink = sink
+        ctx.slots = tuple(OPT.grad_slot(t) for t in params)
+        z1, y1, stats1 = pre["down"]
+        z2, y, stats2 = pre["up"]
+        ctx.save_for_backward(x, y, z1, y1, stats1, *pre["h"], *pre["w"], z2, stats2, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import optim as OPT
+        lib = L.lib()
+        sv = ctx.saved_tensors
+        x, y, z1, y1, stats1 = sv[:5]
+        qh, sh, lh, sth, yh = sv[5:10]
+        qw, sw, lw, stw, yw = sv[10:15]
+        z2, stats2 = sv[15:17]
+        P = sv[17:]
+        dy = dy.contiguous()
+        dev = x.device
+        desc = L.BlockDesc(*ctx.geom)
+        ws_bytes = lib.medt_wopos_block_bwd_workspace_bytes(C.byref(desc))
+        if ws_bytes == 0:
+            raise L.MedtError("block backward: " + (lib.medt_last_error().decode() or "MEDT_BLOCK_BWD changed since the forward"))
+        # gradient destinations: the parameter's slot in FlatAdam's flat bucket, else a temporary handed back to autograd
+        dst, ret, pend = [None] * 20, [None] * 20, []
+        for k in range(20):
+            slot = OPT.live(ctx.slots[k])
+            if slot is not None and ctx.needs_input_grad[k + 1]:
+                dst[k], direct = OPT.claim(slot)
+                if not direct:
+                    pend.append((slot, dst[k]))
+            else:
+                dst[k] = torch.empty(P[k].shape, device=dev, dtype=torch.float32)
+                if ctx.needs_input_grad[k + 1]:
+                    ret[k] = dst[k]
+        g = [L.ptr(t) for t in dst]
+        grads = L.BlockGrads(g[0], g[1], g[2], L.AxialGrads(*g[3:10], None, None), L.AxialGrads(*g[10:17], None, None),
+                             g[17], g[18], g[19])
+        bn = lambda w: L.BnPtrs(L.ptr(w), None, None, None, None)          # the backward reads the BatchNorm weights only
+        ax = lambda o: L.AxialParams(L.ptr(P[o]), bn(P[o + 1]), bn(P[o + 3]), bn(P[o + 5]), None, None, None, None, None)
+        params = L.BlockParams(L.ptr(P[0]), bn(P[1]), ax(3), ax(10), L.ptr(P[17]), bn(P[18]))
+        saved = L.BlockSaved(z1.data_ptr(), y1.data_ptr(), stats1.data_ptr(),
+                             L.AxialSaved(qh.data_ptr(), sh.data_ptr(), lh.data_ptr(), sth.data_ptr()), yh.data_ptr(),
+                             L.AxialSaved(qw.data_ptr(), sw.data_ptr(), lw.data_ptr(), stw.data_ptr()), yw.data_ptr(),
+                             z2.data_ptr(), stats2.data_ptr())
+        dx = torch.empty_like(x)
+        # fan-in of d(x): this node is conv_down AND the identity path; what other consumers deposited is added in the kernel
+        xs = ctx.sink if ctx.needs_input_grad[0] else None
+        dep = xs.take() if xs is not None else None
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+        q = DEFER.recording(allow=not pend and all(r is None for r in ret))
+        L.check(lib.medt_wopos_block_bwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), dy.data_ptr(), C.byref(saved),
+                                         dx.data_ptr(), L.ptr(dep), C.byref(grads), ws.data_ptr(), ws_bytes,
+                                         torch.cuda.current_stream().cuda_stream), "medt_wopos_block_bwd")
+        if q is not None:                      # the recorded weight-gradient / reduction jobs read these at the flush
+            q.hold(ws, x, y1, yh, yw, qh, qw, stats1, sth, stw, stats2, *dst)
+        for slot, tmp in pend:
+            OPT.accumulate(slot, tmp)
+        if xs is not None:
+            xs.closed = True                   # role "final": later depositors return their gradient the ordinary way
+        return (dx if ctx.needs_input_grad[0] else None, *ret, None, None, None, None)
+
+
+def block_forward(blk, x, bn_groups: int, sink):
+    """The block as ONE autograd node (one-launch forward and backward), or None when that path is not taken."""
+    if not BWD_ENABLED or not torch.is_grad_enabled():
+        return None
+    pre = fused_forward(blk, x, bn_groups)
+    if pre is None:
+        return None
+    return WoposBlockFn.apply(x, *_block_params(blk), blk, bn_groups, sink, pre)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# First GPU call for the one-launch block backward (written in round 4 without GPU minutes left; verified on the CPU lane
+# emulator only): parity of the compiled kernel, then the step A/B.  Usage (from the repo root, on the GPU box):
+#   bash scripts/r5_block_bwd.sh            -> gpurun_out/r5_block_bwd.txt
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+out=gpurun_out/r5_block_bwd.txt
+: > $out
+echo "== parity, MEDT_BLOCK_BWD=1" >> $out
+MEDT_BLOCK_BWD=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py tests/test_dist_gpu.py -m gpu -x -q 2>&1 | tail -15 >> $out
+echo "== smoke, MEDT_BLOCK_BWD=1" >> $out
+MEDT_BLOCK_BWD=1 timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -4 >> $out
+for rep in 1 2; do
+  for v in 0 1; do
+    echo "== bench MEDT_BLOCK_BWD=$v (rep $rep)" >> $out
+    MEDT_BLOCK_BWD=$v timeout 600 python bench.py --steps 200 --warmup 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
+  done
+done
+cat $out

@@ -134,3 +134,62 @@ def test_fused_block_is_taken_and_counts_one_launch(device):
             net.axial_block_forward(blk, x, 16)
         assert q.pending() == 8
     torch.cuda.synchronize()
+
+
+# ---- the one-launch BACKWARD (medt_wopos_block_bwd): opt-in (MEDT_BLOCK_BWD=1 for the whole process -- the library reads the
+# variable once) until it has been run and timed on the GPU; verified against the reference fixture on the CPU lane emulator
+# (tests/test_lane_emu.py).  With the variable set, test_block_vs_reference_fixture[one-launch] above also runs through it.
+bwd_opt_in = pytest.mark.skipif(__import__("os").environ.get("MEDT_BLOCK_BWD", "0") != "1",
+                                reason="one-launch block backward is opt-in: MEDT_BLOCK_BWD=1")
+
+
+@bwd_opt_in
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_block_backward_one_launch_equals_stagewise(training, device):
+    from medt_amd import block
+    assert block.BWD_ENABLED
+    blk = make_block(device)
+    torch.manual_seed(11)
+    x = torch.randn(64, 128, 4, 4, device=device).relu_()
+    dout = torch.randn(64, 128, 4, 4, device=device)
+    block.BWD_ENABLED = False
+    try:
+        y0, dx0, g0, b0 = run(blk, x, dout, True, training)          # one-launch forward, per-stage backward
+    finally:
+        block.BWD_ENABLED = True
+    y1, dx1, g1, b1 = run(blk, x, dout, True, training)              # one autograd node, one-launch backward
+    assert torch.equal(y1, y0)                                        # the same forward launch
+    assert H.rel_err(dx1, dx0) < 2e-5, H.rel_err(dx1, dx0)
+    assert g0.keys() == g1.keys() and len(g0) == 20
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err < 5e-5 * max(g0[k].abs().max().item(), 1e-2 * gmax), (k, err, g0[k].abs().max().item())
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+
+
+@bwd_opt_in
+def test_block_backward_is_one_launch_and_takes_the_deposit(device):
+    """One call records the block's 4 + 4 parameter-gradient jobs (2 BatchNorm finalisations, 2 layer finalisations, 4 weight
+    gradients), and what another consumer of x deposited in x's sink comes back inside dx."""
+    from medt_amd import block, net, ops
+    from medt_amd.defer import StepQueue
+    blk = make_block(device).train()
+    torch.manual_seed(3)
+    x = torch.randn(64, 128, 4, 4, device=device).relu_().requires_grad_(True)
+    dout = torch.randn(64, 128, 4, 4, device=device)
+    y = net.axial_block_forward(blk, x, 16)
+    assert type(y.grad_fn).__name__ == "WoposBlockFnBackward"
+    (y * dout).sum().backward()
+    dx_plain = x.grad.clone()
+    x.grad = None
+    for p in blk.parameters():
+        p.grad = None
+    del x._medt_sink                              # (the first backward closed x's sink: role "final")
+    y = net.axial_block_forward(blk, x, 16)
+    extra = torch.randn_like(x)
+    assert ops.sink_of(x).deposit(extra)
+    (y * dout).sum().backward()
+    torch.cuda.synchronize()
+    assert H.rel_err(x.grad, dx_plain + extra) < 1e-6
