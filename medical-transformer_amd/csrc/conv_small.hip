@@ -351,7 +351,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_small_kernel(SmallBnB
 // tensor size) on the layer chain; the parameter gradients are produced off the chain by the recorded finalisation.
 template <int TT>
 __global__ __launch_bounds__(TT) void bn_act_bwd_chan_kernel(SmallBnBwdArgs a) {
-    __shared__ float red[2 * (TT / 64)];
+    MEDT_STATIC_SHARED float red[2 * (TT / 64)];
     const int grp = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     const int HW = a.HW, P = a.npg * HW, gc = grp * a.C + c;
     const float mean = a.st.mean[gc], rstd = a.st.rstd[gc];

@@ -3,12 +3,6 @@
 #define MEDT_LANE_EMU 1
 #include "../../medical-transformer_amd/csrc/block_small.hip"
 
-namespace medt {
-alignas(16) float smem[160 * 1024 / 4];          // the workgroup's LDS (extern __shared__ in the kernels)
-void set_error(const char*, ...) {}
-int launch_status(const char*) { return MEDT_OK; }
-bool abl_skip(const char*) { return false; }
-}  // namespace medt
 
 extern "C" int emu_wopos_block_fwd(const medt_block_desc* d, const medt_block_params* p, const float* x, float* y,
                                    const medt_block_saved* sv, double* parts) {

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <ucontext.h>
+#include <utility>
 #include <vector>
 
 namespace lane_emu {
@@ -22,6 +23,26 @@ long progress = 0;
 const std::function<void()>* body_fn = nullptr;
 
 void yield() { swapcontext(&lanes[cur].ctx, &main_ctx); }
+
+// Which work-item runs u-th in a pass over the workgroup.  Work-items only interact at the synchronisation points they yield at,
+// so a kernel without data races computes the same bits under every order; a missing barrier shows up as a difference between
+// orders (the consumer of a tile runs before / after its producer): tests run every kernel under all three.
+int order_mode = 0;                 // 0: ascending, 1: descending, 2: pseudo-random, reshuffled every pass
+uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+std::vector<int> perm;
+int pick(int u) {
+    if (order_mode == 0) return u;
+    if (order_mode == 1) return T - 1 - u;
+    if (u == 0) {                    // new pass: Fisher-Yates with a xorshift generator
+        perm.resize(T);
+        for (int i = 0; i < T; ++i) perm[i] = i;
+        for (int i = T - 1; i > 0; --i) {
+            rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+            std::swap(perm[i], perm[(int)(rng_state % (uint64_t)(i + 1))]);
+        }
+    }
+    return perm[u];
+}
 
 void release_block_if_complete() {
     if (bcount > 0 && bcount == alive) { bcount = 0; ++bgen; ++progress; }
@@ -45,6 +66,12 @@ void trampoline() {
 }  // namespace
 
 int lane_id() { return cur & 63; }
+
+void set_order(int mode, uint64_t seed) {
+    order_mode = mode;
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    if (!rng_state) rng_state = 1;
+}
 
 void block_barrier() {
     const int gen = bgen;
@@ -100,7 +127,8 @@ void launch(Idx3 grid, Idx3 block, const std::function<void()>& body) {
                 }
                 while (alive > 0) {
                     const long before = progress;
-                    for (int t = 0; t < T; ++t) {
+                    for (int u = 0; u < T; ++u) {
+                        const int t = pick(u);
                         if (lanes[t].done) continue;
                         cur = t;
                         g_threadIdx = Idx3{(unsigned)t, 0, 0};

@@ -6,8 +6,9 @@
 // grid x block cooperative coroutines: a work-item runs until it reaches a barrier or a cross-lane operation, where it
 // yields until the other work-items of its workgroup / wavefront have arrived.  Host pointers play device memory, one
 // global array plays the LDS.  It proves index arithmetic, phase ordering (a missing barrier shows up as a wrong result
-// only when the lanes' interleaving exposes it: lanes run in ascending order between synchronisation points) and the
-// mathematics of a kernel without a GPU; it says nothing about timing, register pressure or the real ISA.
+// only when the interleaving exposes it -- set_order() runs the work-items in ascending, descending or shuffled order between
+// synchronisation points, and a race-free kernel computes the same bits under all of them) and the mathematics of a kernel
+// without a GPU; it says nothing about timing, register pressure or the real ISA.
 // Nothing in the product links or imports this (tests/test_lane_emu.py only).
 #pragma once
 #include <stdint.h>
@@ -23,5 +24,6 @@ void block_barrier();                         // __syncthreads / s_barrier
 void wave_barrier();                          // a point every lane of the wavefront reaches together
 uint64_t exchange(uint64_t v, int src_lane);  // every lane of the wavefront posts v and reads lane src_lane's (0..63)
 int lane_id();
+void set_order(int mode, uint64_t seed);   // order of the work-items between synchronisation points: 0 ascending, 1 descending, 2 random
 
 }  // namespace lane_emu

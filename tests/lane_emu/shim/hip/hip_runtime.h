@@ -15,7 +15,8 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__
+#define __shared__                         // extern __shared__ float smem[] -> one global array (emu_common.cpp)
+#define MEDT_STATIC_SHARED static          // in-kernel static LDS arrays: one instance, shared by all work-items
 
 using std::max;
 using std::min;
