@@ -14,5 +14,7 @@ int launch_status(const char*) { return MEDT_OK; }
 bool abl_skip(const char*) { return false; }
 }  // namespace medt
 
+static const bool lds_registered = (lane_emu::set_lds(medt::smem, sizeof(medt::smem)), true);
+
 extern "C" void emu_set_order(int mode, unsigned long long seed) { lane_emu::set_order(mode, seed); }
 extern "C" const char* emu_last_error() { return medt::g_err; }

@@ -45,8 +45,9 @@ static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int)
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...)                                                      \
     do {                                                                                                             \
         const dim3 g_ = (grid), b_ = (block);                                                                        \
-        (void)(lds); (void)(stream);                                                                                 \
-        lane_emu::launch(lane_emu::Idx3{g_.x, g_.y, g_.z}, lane_emu::Idx3{b_.x, b_.y, b_.z}, [&]() { kern(__VA_ARGS__); }); \
+        (void)(stream);                                                                                              \
+        lane_emu::launch(lane_emu::Idx3{g_.x, g_.y, g_.z}, lane_emu::Idx3{b_.x, b_.y, b_.z}, (size_t)(lds),           \
+                         [&]() { kern(__VA_ARGS__); });                                                              \
     } while (0)
 
 // ---- bit casts, transcendental builtins ------------------------------------------------------------------------------------
