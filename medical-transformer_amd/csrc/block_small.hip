@@ -476,7 +476,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
                                                    const BlkBnB& bo, const float* __restrict__ qkv_raw,
                                                    const float* __restrict__ stacked, const float* __restrict__ lse,
                                                    const float* __restrict__ yl, float* dqkv, float* coef_q, float* part_q,
-                                                   float* part_s, float* part_o, int grp, int n0, int training, int wv) {
+                                                   float* part_s, float* part_o, int grp, int n0, int training, int wv, int stamp0) {
     constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 4, HW = 16, CB = 2 * CW / 16, HV = CW / 16;
     static_assert(CB == NCH / 2 && HV * 2 == GP && 2 * HQ == CB, "two waves per head: q | k and v");
     const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
@@ -511,6 +511,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
                                                 blk_ldu(bq.st + 3 * bq.n + grp * 2 * CW + wv * CB + k));
     }
     MEDT_LDS_BARRIER();                                   // d(sv), sv and q | k | v of every head in LDS
+    BLK_STAMP(stamp0);                                    // loads, [mask,] bn_output backward, tiles
     // 2. softmax and bn_similarity backward of this lane's row (both waves of the head)            (:232-241)
     const float* Qh = Q + g * NCH * 64;
     const float* Dh = D + g * GP * 64;
@@ -558,6 +559,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
             cw = -ce * m1 - cu * mean;
         }
     }
+    BLK_STAMP(stamp0 + 1);                                // softmax + bn_similarity backward
     // 3. the head's 16 gradient rows: wave hf = 0 produces dq | dk, wave hf = 1 dv; what a lane needs of its row mates
     //    (dS or P of the pairs in which it is the KEY) changes hands through the wave's LDS strip
 #pragma unroll
@@ -587,6 +589,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
             for (int c = 0; c < GP; ++c) gq[c] = fmaf(pT, Dh[c * 64 + o], gq[c]);
         }
     }
+    BLK_STAMP(stamp0 + 2);                                // dq | dk | dv
     // 4. bn_qkv backward                                                                       (:228)
     {
         float dzq[CB];
@@ -598,8 +601,10 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
         }
     }
     MEDT_LDS_BARRIER();                                   // the gradient at the qkv_transform output in LDS
+    BLK_STAMP(stamp0 + 3);                                // bn_qkv backward + tile
     // 5. qkv_transform dgrad
     wave_dgrad1x1<HV, 2 * CW, CW>(w_qkv, wv * HV, DZ, gio);
+    BLK_STAMP(stamp0 + 4);                                // projection dgrad
 }
 
 template <int CI, int CW, int GP>
@@ -624,6 +629,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     const BlkBnB bqh{a.stats[1], nq, a.gamma[1]}, bsh{a.stats[1] + 4 * nq, ns, a.gamma[2]}, boh{a.stats[1] + 4 * (nq + ns), no, a.gamma[3]};
     const BlkBnB bqw{a.stats[2], nq, a.gamma[4]}, bsw{a.stats[2] + 4 * nq, ns, a.gamma[5]}, bow{a.stats[2] + 4 * (nq + ns), no, a.gamma[6]};
     float* const part = a.part;
+    BLK_STAMP(10);
     // 32-bit element offsets of this lane's first channel in the (N, CI, 4, 4) and (N, CW, 4, 4) tensors
     const unsigned ei = ((unsigned)(n0 + ni) * CI + wv * CF) * HW + p, ew = ((unsigned)(n0 + ni) * CW + wv * CA) * HW + p;
     // ---- bn2 backward behind the ReLU mask                                                       (axialnet.py:385-389)
@@ -644,18 +650,20 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
         }
     }
     MEDT_LDS_BARRIER();
+    BLK_STAMP(11);                                      // loads, mask, bn2 backward, tile
     // ---- conv_up dgrad                                                                            (:385)
     float gio[CA];
     wave_dgrad1x1<CA, CI, CW>(w_up, wv * CA, BA, gio);
+    BLK_STAMP(12);                                      // conv_up dgrad
     // ---- width layer (behind the block's ReLU), height layer                                      (:377-383)
     wave_attention_bwd<CW, GP, 1, true>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, bqw, bsw, bow, a.qkv[1], a.stk[1], a.lse[1], a.y_w,
                                         a.dqkv[1], a.coef_q[1], part + blk_part_off(4, gs, CW, CI, G),
                                         part + blk_part_off(5, gs, CW, CI, G), part + blk_part_off(6, gs, CW, CI, G), grp, n0,
-                                        a.training, wv);
+                                        a.training, wv, 13);
     wave_attention_bwd<CW, GP, 0, false>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, bqh, bsh, boh, a.qkv[0], a.stk[0], a.lse[0], nullptr,
                                          a.dqkv[0], a.coef_q[0], part + blk_part_off(1, gs, CW, CI, G),
                                          part + blk_part_off(2, gs, CW, CI, G), part + blk_part_off(3, gs, CW, CI, G), grp, n0,
-                                         a.training, wv);
+                                         a.training, wv, 18);
     // ---- bn1 backward behind the ReLU mask                                                        (:373-375)
     {
         float gm[CA], zz[CA], dz[CA];
@@ -679,6 +687,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
         add[k] = (yv > 0.f ? d : 0.f) + (a.dx_add ? a.dx_add[ei + k * HW] : 0.f);
     }
     MEDT_LDS_BARRIER();
+    BLK_STAMP(23);                                      // bn1 backward + tile, identity gradient loaded
     // ---- conv_down dgrad + identity + deposit                                                     (:371, :387)
     {
         float dxv[CF];
@@ -686,6 +695,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < CF; ++k) a.dx[ei + k * HW] = dxv[k] + add[k];
     }
+    BLK_STAMP(24);                                      // conv_down dgrad + identity + deposit
 }
 
 #ifndef MEDT_LANE_EMU          // (tests/lane_emu compiles the kernels and the launch function only)

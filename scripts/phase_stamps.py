@@ -70,3 +70,27 @@ for rep in range(5):
 print(f"AxialBlock_wopos C=128 width=64 4x4 maps, one launch: total {sum(best) / 1000:.2f} us (lane 0 of workgroup 0)")
 for n, v in zip(BNAMES, best):
     print(f"    {v / 1000:6.2f} us  {n}")
+
+# ---- ... and its one-launch backward (MEDT_BLOCK_BWD=1), stamps 10 .. 24 of the same array ----
+from medt_amd import block  # noqa: E402
+if block.BWD_ENABLED:
+    WN = ["loads, [mask,] bn_output backward, tiles", "softmax + bn_similarity backward", "dq | dk | dv", "bn_qkv backward + tile",
+          "projection dgrad"]
+    GNAMES = ["loads, mask, bn2 backward, tile", "conv_up dgrad"] + ["width: " + n for n in WN] + ["height: " + n for n in WN] + \
+             ["bn1 backward + tile, identity gradient loaded", "conv_down dgrad + identity + deposit"]
+    best = None
+    for rep in range(5):
+        xg = x.clone().requires_grad_(True)
+        y = net.axial_block_forward(blk, xg, 16)
+        y.backward(torch.ones_like(y))
+        torch.cuda.synchronize()
+        st = (ctypes.c_ulonglong * 32)()
+        assert h.medt_debug_block_stamps(st) == 0
+        d = [(st[i + 1] - st[i]) * 10 for i in range(10, 24)]
+        if best is None or sum(d) < sum(best):
+            best = d
+    print(f"AxialBlock_wopos backward, one launch: total {sum(best) / 1000:.2f} us (lane 0 of workgroup 0)")
+    for n, v in zip(GNAMES, best):
+        print(f"    {v / 1000:6.2f} us  {n}")
+else:
+    print("(one-launch block backward not enabled: MEDT_BLOCK_BWD=1)")

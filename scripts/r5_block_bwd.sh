@@ -17,4 +17,6 @@ for rep in 1 2; do
     MEDT_BLOCK_BWD=$v timeout 600 python bench.py --steps 200 --warmup 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
   done
 done
+echo "== phase stamps of the block kernels (libmedt_stamps.so must have been built here: python scripts/phase_stamps.py --build)" >> $out
+MEDT_BLOCK_BWD=1 timeout 300 python scripts/phase_stamps.py 2>&1 | tail -28 >> $out
 cat $out
