@@ -113,12 +113,37 @@ __device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, d
     }
 }
 
+// Two FMAs per lane and instruction (v_pk_fma_f32 with the weights as an SGPR pair: the kernels are VALU-issue-bound on the one CU a
+// patch group gets, and two thirds of their instructions are these FMAs).  PK variants: MEDT_BLOCK_PK=1, off until measured.
+#ifdef MEDT_LANE_EMU
+struct blk_v2f { float x, y; };
+__device__ __forceinline__ blk_v2f blk_pk_fma(blk_v2f a, blk_v2f b, blk_v2f c) { return blk_v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float blk_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ blk_v2f blk_pk_fma(blk_v2f a, blk_v2f b, blk_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+
 // out[k] = sum_c w[(row0 + k) * CIN + c] * T[c * 64 + lane]: K output channels of a 1x1 convolution over the LDS tile T;
-// the weight rows are wave-uniform (scalar loads)
-template <int K, int CIN>
+// the weight rows are wave-uniform (scalar loads).  PK: even and odd input channels accumulate in the two halves of a packed
+// FMA (adjacent weights = an SGPR pair, the two tile values = one ds_read2st64_b32) and are added at the end.
+template <int K, int CIN, bool PK = false>
 __device__ __forceinline__ void wave_conv1x1(const float* __restrict__ w, int row0, const float* T, float (&acc)[K]) {
     const int lane = threadIdx.x & 63;
     const float* wr = w + (size_t)row0 * CIN;
+    if (PK) {
+        blk_v2f a2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a2[k] = blk_v2f{0.f, 0.f};
+#pragma unroll 4
+        for (int c = 0; c < CIN; c += 2) {
+            const blk_v2f t2 = {T[c * 64 + lane], T[(c + 1) * 64 + lane]};
+#pragma unroll
+            for (int k = 0; k < K; ++k) a2[k] = blk_pk_fma(blk_v2f{wr[k * CIN + c], wr[k * CIN + c + 1]}, t2, a2[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = a2[k].x + a2[k].y;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
     // (8 input channels per batch of scalar loads; 16 for the four-row phases measured slower: 2.188 vs 2.171 ms/step)
@@ -131,7 +156,7 @@ __device__ __forceinline__ void wave_conv1x1(const float* __restrict__ w, int ro
 }
 
 // One AxialAttention_wopos layer on the tile A (CW x 64) -> A (in place), through Q (2CW x 64).  AXIS 0: along H, 1: along W.
-template <int CW, int GP, int AXIS, bool RELU>
+template <int CW, int GP, int AXIS, bool RELU, bool PK>
 __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, float* A, float* Q, const float* prm_q,
                                                const float* prm_s, const float* prm_o, double* part_q, double* part_s,
                                                double* part_o, float* qkv_raw, float* stacked, float* lse, float* y, int n0,
@@ -142,7 +167,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
     // 1. qkv_transform rows wv*CB .. +CB, bn_qkv                                             (axialnet.py:228)
     {
         float acc[CB], sc[CB], sh[CB];
-        wave_conv1x1<CB, CW>(w_qkv, wv * CB, A, acc);
+        wave_conv1x1<CB, CW, PK>(w_qkv, wv * CB, A, acc);
 #pragma unroll
         for (int k = 0; k < CB; ++k) qkv_raw[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = acc[k];
         wave_bn<CB>(acc, prm_q, part_q, wv * CB, training, eps, sc, sh);
@@ -224,7 +249,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
     BLK_STAMP(stamp0 + 2);                             // bn_output + tile
 }
 
-template <int CI, int CW, int GP>
+template <int CI, int CW, int GP, bool PK>
 __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
                                                                const float* __restrict__ w_qh, const float* __restrict__ w_qw,
                                                                const float* __restrict__ w_up, BlkArgs a) {
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
     // ---- conv_down + bn1 + ReLU                                                              (axialnet.py:373-375)
     {
         float acc[CA], sc[CA], sh[CA];
-        wave_conv1x1<CA, CI>(w_down, wv * CA, X, acc);
+        wave_conv1x1<CA, CI, PK>(w_down, wv * CA, X, acc);
 #pragma unroll
         for (int k = 0; k < CA; ++k) a.z1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
         wave_bn<CA>(acc, prm + poff[0], a.part[0] ? a.part[0] + (size_t)grp * CW * 2 : nullptr, wv * CA, a.training, a.eps, sc, sh);
@@ -299,16 +324,16 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
     MEDT_LDS_BARRIER();
     BLK_STAMP(2);                                       // conv_down + bn1 + ReLU
     // ---- height layer, width layer (+ ReLU)                                                   (:377-379)
-    wave_attention<CW, GP, 0, false>(w_qh, A, Q, prm + poff[1], prm + poff[2], prm + poff[3],
+    wave_attention<CW, GP, 0, false, PK>(w_qh, A, Q, prm + poff[1], prm + poff[2], prm + poff[3],
                                      a.part[1] + (size_t)grp * 2 * CW * 2, a.part[2] + (size_t)grp * G * 2,
                                      a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h, a.y_h, n0, a.training, a.eps, wv, 3);
-    wave_attention<CW, GP, 1, true>(w_qw, A, Q, prm + poff[4], prm + poff[5], prm + poff[6],
+    wave_attention<CW, GP, 1, true, PK>(w_qw, A, Q, prm + poff[4], prm + poff[5], prm + poff[6],
                                     a.part[4] + (size_t)grp * 2 * CW * 2, a.part[5] + (size_t)grp * G * 2,
                                     a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w, a.y_w, n0, a.training, a.eps, wv, 6);
     // ---- conv_up + bn2 + identity + ReLU                                                       (:381-389)
     {
         float acc[CF], sc[CF], sh[CF];
-        wave_conv1x1<CF, CW>(w_up, wv * CF, A, acc);
+        wave_conv1x1<CF, CW, PK>(w_up, wv * CF, A, acc);
 #pragma unroll
         for (int k = 0; k < CF; ++k) a.z2[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = acc[k];
         wave_bn<CF>(acc, prm + poff[7], a.part[7] + (size_t)grp * CI * 2, wv * CF, a.training, a.eps, sc, sh);
@@ -319,6 +344,12 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
         }
     }
     BLK_STAMP(9);                                       // conv_up + bn2 + identity + ReLU
+}
+
+// MEDT_BLOCK_PK=1: the packed-FMA instantiations of the two block kernels (off until measured; tests/lane_emu sets it directly)
+int& block_pk_mode() {
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK_PK"); return (e && e[0] == '1') ? 1 : 0; }();
+    return mode;
 }
 
 static bool block_fused_enabled() {
@@ -366,12 +397,18 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
     const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
     static bool attr = false;
     if (!attr) {                    // more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU)
-        (void)hipFuncSetAttribute((const void*)wopos_block_fwd_kernel<128, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)wopos_block_fwd_kernel<128, 64, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wopos_block_fwd_kernel<128, 64, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((wopos_block_fwd_kernel<128, 64, 8>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.w_down,
-                       p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+    if (block_pk_mode())
+        hipLaunchKernelGGL((wopos_block_fwd_kernel<128, 64, 8, true>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.w_down,
+                           p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+    else
+        hipLaunchKernelGGL((wopos_block_fwd_kernel<128, 64, 8, false>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.w_down,
+                           p.height.w_qkv, p.width.w_qkv, p.w_up, a);
     return launch_status("wopos_block_fwd");
 }
 
@@ -453,10 +490,28 @@ __device__ __forceinline__ void wave_bn_bwd(const float (&g)[K], const float (&x
 }
 
 // out[k] = sum_o w[o * CIN + col0 + k] * T[o * 64 + lane]: K input channels of a 1x1 backward-data over the LDS tile T of the
-// COUT output-channel gradients; the K weights of a row are adjacent (one scalar load of K dwords per o)
-template <int K, int COUT, int CIN>
+// COUT output-channel gradients; the K weights of a row are adjacent (one scalar load of K dwords per o).  PK: outputs k, k + 1
+// in the two halves of a packed FMA (their weights are an SGPR pair, the tile value feeds both halves) -- the same sums, bit for bit.
+template <int K, int COUT, int CIN, bool PK = false>
 __device__ __forceinline__ void wave_dgrad1x1(const float* __restrict__ w, int col0, const float* T, float (&acc)[K]) {
     const int lane = threadIdx.x & 63;
+    if (PK) {
+        static_assert(K % 2 == 0, "pairs of outputs");
+        blk_v2f a2[K / 2];
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) a2[k] = blk_v2f{0.f, 0.f};
+#pragma unroll 8
+        for (int o = 0; o < COUT; ++o) {
+            const float t = T[o * 64 + lane];
+            const blk_v2f t2 = {t, t};
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k)
+                a2[k] = blk_pk_fma(blk_v2f{w[o * CIN + col0 + 2 * k], w[o * CIN + col0 + 2 * k + 1]}, t2, a2[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) { acc[2 * k] = a2[k].x; acc[2 * k + 1] = a2[k].y; }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
 #pragma unroll 8
@@ -470,7 +525,7 @@ __device__ __forceinline__ void wave_dgrad1x1(const float* __restrict__ w, int c
 // Backward of one AxialAttention_wopos layer: gio = gradient at the layer's output (channels wv * CW/16 ..) on entry, at its
 // input on return.  Q | D | S: tiles of the normalised q|k|v, of d(sv) and of sv; DZ: the gradient tile behind bn_qkv's backward;
 // E: this wave's private 4 x 64 strip.
-template <int CW, int GP, int AXIS, bool RELU>
+template <int CW, int GP, int AXIS, bool RELU, bool PK>
 __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_qkv, float (&gio)[CW / 16], float* Q, float* D,
                                                    float* S, float* DZ, float* E, const BlkBnB& bq, const BlkBnB& bs,
                                                    const BlkBnB& bo, const float* __restrict__ qkv_raw,
@@ -603,11 +658,11 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
     MEDT_LDS_BARRIER();                                   // the gradient at the qkv_transform output in LDS
     BLK_STAMP(stamp0 + 3);                                // bn_qkv backward + tile
     // 5. qkv_transform dgrad
-    wave_dgrad1x1<HV, 2 * CW, CW>(w_qkv, wv * HV, DZ, gio);
+    wave_dgrad1x1<HV, 2 * CW, CW, PK>(w_qkv, wv * HV, DZ, gio);
     BLK_STAMP(stamp0 + 4);                                // projection dgrad
 }
 
-template <int CI, int CW, int GP>
+template <int CI, int CW, int GP, bool PK>
 __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __restrict__ w_down, const float* __restrict__ w_qh,
                                                                const float* __restrict__ w_qw, const float* __restrict__ w_up,
                                                                BlkBwdArgs a) {
@@ -653,14 +708,14 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     BLK_STAMP(11);                                      // loads, mask, bn2 backward, tile
     // ---- conv_up dgrad                                                                            (:385)
     float gio[CA];
-    wave_dgrad1x1<CA, CI, CW>(w_up, wv * CA, BA, gio);
+    wave_dgrad1x1<CA, CI, CW, PK>(w_up, wv * CA, BA, gio);
     BLK_STAMP(12);                                      // conv_up dgrad
     // ---- width layer (behind the block's ReLU), height layer                                      (:377-383)
-    wave_attention_bwd<CW, GP, 1, true>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, bqw, bsw, bow, a.qkv[1], a.stk[1], a.lse[1], a.y_w,
+    wave_attention_bwd<CW, GP, 1, true, PK>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, bqw, bsw, bow, a.qkv[1], a.stk[1], a.lse[1], a.y_w,
                                         a.dqkv[1], a.coef_q[1], part + blk_part_off(4, gs, CW, CI, G),
                                         part + blk_part_off(5, gs, CW, CI, G), part + blk_part_off(6, gs, CW, CI, G), grp, n0,
                                         a.training, wv, 13);
-    wave_attention_bwd<CW, GP, 0, false>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, bqh, bsh, boh, a.qkv[0], a.stk[0], a.lse[0], nullptr,
+    wave_attention_bwd<CW, GP, 0, false, PK>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, bqh, bsh, boh, a.qkv[0], a.stk[0], a.lse[0], nullptr,
                                          a.dqkv[0], a.coef_q[0], part + blk_part_off(1, gs, CW, CI, G),
                                          part + blk_part_off(2, gs, CW, CI, G), part + blk_part_off(3, gs, CW, CI, G), grp, n0,
                                          a.training, wv, 18);
@@ -691,7 +746,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     // ---- conv_down dgrad + identity + deposit                                                     (:371, :387)
     {
         float dxv[CF];
-        wave_dgrad1x1<CF, CW, CI>(w_down, wv * CF, Q, dxv);
+        wave_dgrad1x1<CF, CW, CI, PK>(w_down, wv * CF, Q, dxv);
 #pragma unroll
         for (int k = 0; k < CF; ++k) a.dx[ei + k * HW] = dxv[k] + add[k];
     }
@@ -759,12 +814,18 @@ int wopos_block_bwd_launch(const medt_block_desc& d, const medt_block_params& p,
     const size_t lds = ((size_t)(d.C + 2 * d.width + 2 * d.width) * 64 + 16 * 4 * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wopos_block_bwd_kernel<128, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)wopos_block_bwd_kernel<128, 64, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wopos_block_bwd_kernel<128, 64, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((wopos_block_bwd_kernel<128, 64, 8>), dim3(d.bn_groups), dim3(1024), lds, s, p.w_down, p.height.w_qkv,
-                       p.width.w_qkv, p.w_up, a);
+    if (block_pk_mode())
+        hipLaunchKernelGGL((wopos_block_bwd_kernel<128, 64, 8, true>), dim3(d.bn_groups), dim3(1024), lds, s, p.w_down, p.height.w_qkv,
+                           p.width.w_qkv, p.w_up, a);
+    else
+        hipLaunchKernelGGL((wopos_block_bwd_kernel<128, 64, 8, false>), dim3(d.bn_groups), dim3(1024), lds, s, p.w_down, p.height.w_qkv,
+                           p.width.w_qkv, p.w_up, a);
     return launch_status("wopos_block_bwd");
 }
 

@@ -11,12 +11,15 @@ echo "== parity, MEDT_BLOCK_BWD=1" >> $out
 MEDT_BLOCK_BWD=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py tests/test_dist_gpu.py -m gpu -x -q 2>&1 | tail -15 >> $out
 echo "== smoke, MEDT_BLOCK_BWD=1" >> $out
 MEDT_BLOCK_BWD=1 timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -4 >> $out
+echo "== parity, MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (packed-FMA instantiations of both block kernels)" >> $out
+MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -5 >> $out
 for rep in 1 2; do
-  for v in 0 1; do
-    echo "== bench MEDT_BLOCK_BWD=$v (rep $rep)" >> $out
-    MEDT_BLOCK_BWD=$v timeout 600 python bench.py --steps 200 --warmup 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
+  for v in "0 0" "0 1" "1 0" "1 1"; do
+    set -- $v
+    echo "== bench MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 (rep $rep)" >> $out
+    MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 timeout 600 python bench.py --steps 200 --warmup 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
   done
 done
 echo "== phase stamps of the block kernels (libmedt_stamps.so must have been built here: python scripts/phase_stamps.py --build)" >> $out
-MEDT_BLOCK_BWD=1 timeout 300 python scripts/phase_stamps.py 2>&1 | tail -28 >> $out
+for pk in 0 1; do echo "-- MEDT_BLOCK_PK=$pk" >> $out; MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=$pk timeout 300 python scripts/phase_stamps.py 2>&1 | tail -28 >> $out; done
 cat $out
