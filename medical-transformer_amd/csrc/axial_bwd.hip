@@ -57,7 +57,7 @@ struct Sw {
     static_assert(L % LS == 0 && (LS == 8 || LS == 16), "lanes per sequence");
 };
 
-typedef float f4 __attribute__((ext_vector_type(4)));
+typedef medt_f4 f4;
 
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ float dpp(float old, float src) {
@@ -119,6 +119,14 @@ __device__ __forceinline__ float seqs_sum(float v) {
 // there is no branch: the row steps of an iteration stay one scheduling region, and the LDS pipe sees 4 lanes instead of 64.
 template <int STRIDE_BYTES>
 __device__ __forceinline__ void lds_store4_masked(unsigned addr, float v0, float v1, float v2, float v3, unsigned long long mask) {
+#ifdef MEDT_LANE_EMU              // (CPU lane emulator: the same stores, lane by lane; addr is a byte offset into the LDS array)
+    if ((mask >> (threadIdx.x & 63)) & 1) {
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+        float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + addr);
+        p[0] = v0; p[STRIDE_BYTES / 4] = v1; p[2 * STRIDE_BYTES / 4] = v2; p[3 * STRIDE_BYTES / 4] = v3;
+    }
+    return;
+#endif
     unsigned long long save;
     asm volatile("s_mov_b64 %0, exec\n\t"
                  "s_and_b64 exec, exec, %1\n\t"
@@ -388,7 +396,11 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
                 }
         }
         float* waccw = wacc + wave * 2 * NT * L + cb;
+#ifdef MEDT_LANE_EMU
+        const unsigned park_addr = (unsigned)(reinterpret_cast<const char*>(crow) - reinterpret_cast<const char*>(smem));
+#else
         const unsigned park_addr = (unsigned)(size_t)crow;     // LDS byte address (low half of the flat pointer)
+#endif
         // the row record (and the table entry that enters the chain behind it) of row i + 1 is fetched while row i is
         // computed: the loads sit in front of the row's exit store, whose address the compiler cannot tell apart
         constexpr bool PREFETCH = GP == 2 && MEDT_ABL != 5;                   // (gp = 4: the 20 extra registers spill)
@@ -639,7 +651,7 @@ constexpr int FIX_PPT = 4;
 template <int HQ>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
     constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), NR = HQ + NP;
-    __shared__ float red[MEDT_WAVES * 4 * HQ];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * 4 * HQ];
     const AxialGeom& g = a.g;
     const int grp = blockIdx.x / a.fparts, part = blockIdx.x - grp * a.fparts, hg = blockIdx.y;
     const int per_group = g.npg * g.HW;
@@ -824,7 +836,7 @@ __device__ __forceinline__ void relfix_body(const RelfixArgs& a, const int blk, 
 template <int HQ>
 __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixArgs a) {
     extern __shared__ float pgs[];
-    __shared__ double gred[RELFIX_THREADS / 64][4];
+    MEDT_STATIC_SHARED double gred[RELFIX_THREADS / 64][4];
     relfix_body<HQ>(a, blockIdx.x, pgs, gred);
 }
 
@@ -833,7 +845,7 @@ using RelfixBatch = JobBatch<RelfixJob, 16>;
 static_assert(sizeof(RelfixBatch) <= 4000, "job table must fit the kernel-argument block");
 __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_grouped_kernel(RelfixBatch b) {
     extern __shared__ float pgs[];
-    __shared__ double gred[RELFIX_THREADS / 64][4];
+    MEDT_STATIC_SHARED double gred[RELFIX_THREADS / 64][4];
     const int j = find_job(b, blockIdx.x);
     const RelfixJob& a = b.job[j];
     if (a.hq == 1) relfix_body<1>(a, blockIdx.x - b.start[j], pgs, gred);

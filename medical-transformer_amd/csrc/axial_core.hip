@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ coef, float* __restrict__ dweight,
                                                               float* __restrict__ dbias, TablesJob tj) {
     if ((int)blockIdx.x >= SC) {         // appended blocks: sliding-window table sums for the fix kernel of axial_bwd.hip
-        __shared__ float lds[512];
+        MEDT_STATIC_SHARED float lds[512];
         sim_tables_block(blockIdx.x - SC, tj.relative, tj.tables, tj.HQ, tj.L, lds);
         return;
     }

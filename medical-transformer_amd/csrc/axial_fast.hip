@@ -177,8 +177,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4_kernel(AxialGeom g, co
 // fetched for the height axis are SS*4 bytes long instead of S_T*4; (2) bn_qkv's affine is applied while
 // staging; (3) all LDS addresses are base + immediate (RS, CS, L are constants), the j-loop is unrolled.
 // --------------------------------------------------------------------------- //
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
+typedef medt_f2 f2;
+typedef medt_f4 f4;
 
 // Column-ordered tables for the compile-time-L kernels: U[y] = T[TL-1-y] with T the table indexed by
 // d = i-j+L-1, so the four entries a lane needs for columns j0..j0+3 sit at ascending addresses

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom 
                                                                       GatePtrs gates, float* __restrict__ partials,
                                                                       int sparts) {
     constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NCH = 4 * HQ, L = 16 * V;
-    __shared__ double red[MEDT_WAVES * 8];
+    MEDT_STATIC_SHARED double red[MEDT_WAVES * 8];
     const int grp = blockIdx.x / sparts, tile = blockIdx.x - grp * sparts, hg = blockIdx.y;
     const int seq0 = tile * 64, nseq = min(64, g.spg - seq0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, p0 = (lane & 15) * V;

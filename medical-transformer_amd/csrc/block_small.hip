@@ -115,11 +115,10 @@ __device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, d
 
 // Two FMAs per lane and instruction (v_pk_fma_f32 with the weights as an SGPR pair: the kernels are VALU-issue-bound on the one CU a
 // patch group gets, and two thirds of their instructions are these FMAs).  PK variants: MEDT_BLOCK_PK=1, off until measured.
+typedef medt_f2 blk_v2f;
 #ifdef MEDT_LANE_EMU
-struct blk_v2f { float x, y; };
 __device__ __forceinline__ blk_v2f blk_pk_fma(blk_v2f a, blk_v2f b, blk_v2f c) { return blk_v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 #else
-typedef float blk_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ blk_v2f blk_pk_fma(blk_v2f a, blk_v2f b, blk_v2f c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 
@@ -753,7 +752,6 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     BLK_STAMP(24);                                      // conv_down dgrad + identity + deposit
 }
 
-#ifndef MEDT_LANE_EMU          // (tests/lane_emu compiles the kernels and the launch function only)
 // Workspace of the backward, in floats: the gradient tensors the recorded weight-gradient jobs read, bn_qkv's coefficients, the
 // partial rows of the eight BatchNorms, the coefficient outputs of bn1 / bn2's finalisation, the weight-gradient scratch slabs.
 struct BlkBwdWs {
@@ -776,22 +774,19 @@ struct BlkBwdWs {
     }
 };
 
-#endif
-
-static bool block_bwd_enabled() {
+int& block_bwd_mode() {
     // default OFF until the kernel has been run and timed on the GPU (it is checked on the CPU lane emulator only so far)
-    static const bool on = [] { const char* e = getenv("MEDT_BLOCK_BWD"); return e && e[0] == '1'; }();
-    return on;
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK_BWD"); return (e && e[0] == '1') ? 1 : 0; }();
+    return mode;
 }
+static bool block_bwd_enabled() { return block_bwd_mode() != 0; }
 bool wopos_block_bwd_ok(const medt_block_desc& d) { return block_bwd_enabled() && wopos_block_ok(d); }
 
-#ifndef MEDT_LANE_EMU
 size_t wopos_block_bwd_ws_bytes(const medt_block_desc& d) {
     Carver c(nullptr, 0);
     BlkBwdWs w(c, d);
     return align_up(c.off, 256) + 256;
 }
-#endif
 
 // the kernel launch alone (device or -- tests/lane_emu -- emulated).  stats: stats1 | the height layer's block | the width
 // layer's block | stats2 (medt_block_saved); part: blk_part_off(8, ...) floats
@@ -829,7 +824,6 @@ int wopos_block_bwd_launch(const medt_block_desc& d, const medt_block_params& p,
     return launch_status("wopos_block_bwd");
 }
 
-#ifndef MEDT_LANE_EMU
 // launch + the jobs nothing in the gradient chain waits for (recorded when a queue is bound to the stream, else issued now)
 int wopos_block_bwd(const medt_block_desc& d, const medt_block_params& p, const float* x, const float* y, const float* dy,
                     const float* dx_add, const medt_block_saved& sv, float* dx, const medt_block_grads& gr, void* ws,
@@ -880,7 +874,6 @@ int wopos_block_bwd(const medt_block_desc& d, const medt_block_params& p, const 
                                 d.N, CW, d.H, d.W, 2 * CW, 1, 1, 0, gs, s, q))) return rc;
     return conv2d_bwd_weight(w.dz1, nullptr, nullptr, x, gr.w_down, w.dw_scratch[0], d.N, CI, d.H, d.W, CW, 1, 1, 0, 1, s, q);
 }
-#endif
 
 }  // namespace medt
 

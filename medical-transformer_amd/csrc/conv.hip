@@ -23,7 +23,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
     int npg, int y_bf16) {
     constexpr int KK = K * K;
-    __shared__ float red[MEDT_WAVES * OT * 2 * 2];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * OT * 2 * 2];
     const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * OT;
     const int q = part * MEDT_THREADS + threadIdx.x;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_ws_kernel(
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
     int npg, int y_bf16) {
     constexpr int KK = K * K;
-    __shared__ float red[3][OT][64];
+    MEDT_STATIC_SHARED float red[3][OT][64];
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [OT][Cin][KK]: rows o0 .. o0+OT-1 of w, as stored
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + 63) / 64;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int H, int W,
     int Cout, int Ho, int Wo, int stride, int pad, const float* __restrict__ add, int stage_dy) {
     constexpr int KK = K * K;
-    __shared__ float red[3][CT][64];
+    MEDT_STATIC_SHARED float red[3][CT][64];
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CT][KK]: this workgroup's weight slice
     // stage_dy: the output gradient of the images this workgroup touches fits in LDS too ([image][Cout][Ho*Wo], after the
     // weights): the contraction loop then has no global loads at all (decoder1_p: 2x2 -> 1x1 maps, 16 images per workgroup)
@@ -565,8 +565,8 @@ __device__ __forceinline__ void conv_wgrad_body(
     constexpr int KK = K * K, RO = TO / 16, RC = TC / 16;
     // row stride 68: 16-byte aligned rows for ds_read_b128 along the position index, and 68 mod 64 = 4 puts the 16
     // B rows a wave reads at once on disjoint 4-bank groups
-    __shared__ __attribute__((aligned(16))) float A[TO][68];
-    __shared__ __attribute__((aligned(16))) float B[TC][68];
+    MEDT_STATIC_SHARED __attribute__((aligned(16))) float A[TO][68];
+    MEDT_STATIC_SHARED __attribute__((aligned(16))) float B[TC][68];
     const int Ktot = Cin * KK, HoWo = Ho * Wo;
     const int o0 = bx * TO, k0 = by * TC;
     const long NP = (long)N * HoWo;
@@ -772,7 +772,7 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
 #define CS_SPLITS 16
 __device__ __forceinline__ void channel_sum_body(const float* __restrict__ x, float* __restrict__ part, int N, int C,
                                                  int HW, int c, int sp) {
-    __shared__ float red[MEDT_WAVES];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES];
     float v[1] = {0.f};
     const long total = (long)N * HW;
     const long per = (total + CS_SPLITS - 1) / CS_SPLITS, beg = sp * per, end = beg + per < total ? beg + per : total;

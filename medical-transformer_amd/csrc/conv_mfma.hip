@@ -19,7 +19,7 @@
 
 namespace medt {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef medt_f4 f32x4;
 
 // Measured on MI355X (profiles/, round 1): the MFMA tile kernel beats the VALU direct kernel only for the 3x3
 // layers with a deep contraction AND enough 64x64 tiles to occupy the chip -- conv2_p 64->128 (55 vs 76 us),
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_mfma_fwd_kernel(
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
     int npg, int kchunk, float* __restrict__ ksplit_out) {
     constexpr int KK = K * K;
-    __shared__ float As[64][17];
-    __shared__ float Bs[16][65];
+    MEDT_STATIC_SHARED float As[64][17];
+    MEDT_STATIC_SHARED float Bs[16][65];
     const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + 63) / 64, Ktot = Cin * KK;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -176,8 +176,8 @@ bool conv_rows16_ok(int Cin, int H, int W, int K, int stride, int pad) {
 __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ partials, int Cin, int H, int Cout, int relu) {
-    __shared__ float As[64 * R16_AST];
-    __shared__ float Ps[16 * R16_CST];
+    MEDT_STATIC_SHARED float As[64 * R16_AST];
+    MEDT_STATIC_SHARED float Ps[16 * R16_CST];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tpi = H >> 2;                                        // 4-row tiles per image
     const int n = blockIdx.x / tpi, r0 = (blockIdx.x - n * tpi) * 4, o0 = blockIdx.y * 64;
@@ -381,8 +381,8 @@ __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int
 // waiting for the next tile; side by side they fill each other's gaps (46 + 46 us back to back before).
 using R16WBatch = JobBatch<R16WJob, 4>;
 __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(R16WBatch b) {
-    __shared__ float Ds[64 * R16_DST];
-    __shared__ float Ps[16 * R16_WCST];
+    MEDT_STATIC_SHARED float Ds[64 * R16_DST];
+    MEDT_STATIC_SHARED float Ps[16 * R16_WCST];
     const int j = find_job(b, blockIdx.x);
     const R16WJob& jb = b.job[j];
     const int r = blockIdx.x - b.start[j], bx = r % jb.gx, by = (r / jb.gx) % jb.gy, bz = r / (jb.gx * jb.gy);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(R16W
 __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
     const float* __restrict__ slices, int nslices, size_t slice_stride, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ partials, int Cout, int HoWo, int npg, int ppg64, int relu) {
-    __shared__ float red[MEDT_WAVES * 2 * 2];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * 2 * 2];
     const int per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o = blockIdx.y;
     const int q = part * MEDT_THREADS + threadIdx.x;
@@ -698,8 +698,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ x, float* __restrict__ scratch, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
     int stride, int pad, int QS, int npg) {
-    __shared__ float A[64][65];
-    __shared__ float B[64][65];
+    MEDT_STATIC_SHARED float A[64][65];
+    MEDT_STATIC_SHARED float B[64][65];
     conv_wgrad_mfma_body<K>(dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, blockIdx.x,
                             blockIdx.y, blockIdx.z, A, B);
 }
@@ -713,8 +713,8 @@ struct MWJob {
 };
 using MWBatch = JobBatch<MWJob, 4>;
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_batch_kernel(MWBatch b) {
-    __shared__ float A[64][65];
-    __shared__ float B[64][65];
+    MEDT_STATIC_SHARED float A[64][65];
+    MEDT_STATIC_SHARED float B[64][65];
     const int j = find_job(b, blockIdx.x);
     const MWJob& m = b.job[j];
     const int r = blockIdx.x - b.start[j], bx = r % m.gx, by = (r / m.gx) % m.gy, bz = r / (m.gx * m.gy);
@@ -766,8 +766,8 @@ using WBatch = JobBatch<WJobP, 42>;
 static_assert(sizeof(WBatch) <= 4000, "job table must fit the kernel-argument block");
 template <int TO>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(WBatch b) {
-    __shared__ float A[TO][65];
-    __shared__ float B[64][65];
+    MEDT_STATIC_SHARED float A[TO][65];
+    MEDT_STATIC_SHARED float B[64][65];
     const int j = find_job(b, blockIdx.x);
     const WJobP& w = b.job[j];
     const int local = blockIdx.x - b.start[j];

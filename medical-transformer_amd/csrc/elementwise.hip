@@ -51,7 +51,7 @@ struct BnFinApplyArgs {
 };
 constexpr int BFA_PER_THREAD = 16;
 __global__ __launch_bounds__(MEDT_THREADS) void bn_fin_apply_kernel(BnFinApplyArgs a) {
-    __shared__ double redd[2 * MEDT_WAVES];
+    MEDT_STATIC_SHARED double redd[2 * MEDT_WAVES];
     const int grp = blockIdx.x / a.parts, part = blockIdx.x - grp * a.parts, c = blockIdx.y, tid = threadIdx.x;
     const int gc = grp * a.C + c;
     const float gam = a.weight[c], bet = a.bias[c];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_stats_kernel(const fl
                                                                         float* __restrict__ g,
                                                                         float* __restrict__ partials, int C, int HW,
                                                                         int npg, int relu) {
-    __shared__ float red[MEDT_WAVES * 2];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * 2];
     const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, c = blockIdx.y;
     const int q = part * MEDT_THREADS + threadIdx.x;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void ce_fwd_kernel(const float* __res
                                                               const int64_t* __restrict__ target,
                                                               float* __restrict__ partials, int K, int HW, int ignore,
                                                               size_t total) {
-    __shared__ float red[MEDT_WAVES * 3];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * 3];
     const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;     // over N*HW
     float v[3] = {0.f, 0.f, 0.f};
     if (idx < total) {

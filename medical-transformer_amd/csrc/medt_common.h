@@ -16,9 +16,13 @@
 // address space and also waits for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)), which nothing inside that kernel
 // depends on.  (Measured: no difference -- 2.2052 vs 2.2106 ms/step with __syncthreads() in every fused small-layer kernel;
 // the store round trips overlap with the next phase's issue either way.  Kept in the one kernel that has eight barriers.)
-// (tests/lane_emu -- the CPU lane emulator the one-workgroup kernels are also compiled for -- supplies its own of these two)
+// (tests/lane_emu -- the CPU lane emulator the kernel sources are also compiled for -- supplies its own of these)
 #ifndef MEDT_STATIC_SHARED
 #define MEDT_STATIC_SHARED __shared__      // a statically sized LDS array declared inside a kernel
+#endif
+#ifndef MEDT_VEC_TYPES                    // clang's OpenCL-style vectors (swizzles, splat casts, element-wise operators)
+typedef float medt_f2 __attribute__((ext_vector_type(2)));
+typedef float medt_f4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef MEDT_LDS_BARRIER
 #define MEDT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")

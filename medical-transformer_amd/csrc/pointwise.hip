@@ -17,7 +17,7 @@ template <int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ partials,
     int Cin, int Cout, int HW) {
-    __shared__ float red[MEDT_WAVES * OT * 2 * 2];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * OT * 2 * 2];
     const int  p  = blockIdx.x * MEDT_THREADS + threadIdx.x;
     const int  n  = blockIdx.y;
     const int  o0 = blockIdx.z * OT;
@@ -145,7 +145,7 @@ template <int CT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv1x1_bwd_data_ws_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
     const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int Cout, int HW, int npg) {
-    __shared__ float red[3][CT][64];
+    MEDT_STATIC_SHARED float red[3][CT][64];
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CT]: this workgroup's weight slice
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long q = (long)blockIdx.x * 64 + lane;
@@ -263,7 +263,7 @@ int conv1x1_bwd_data_impl(const float* dy, const float* raw, const float* coef, 
 // --------------------------------------------------------------------------- //
 __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ in, int P, int K, float* __restrict__ out,
                                                  int block) {
-    __shared__ float red[4][64];
+    MEDT_STATIC_SHARED float red[4][64];
     const int k = block * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
     float s = 0.f;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
                                                          float* running_var, int64_t* nbt, float momentum, float eps,
                                                          int training, BnStats out, TablesJob tj) {
     if ((int)blockIdx.x >= CH) {         // appended blocks: sliding-window tables of the layer's relative table
-        __shared__ float lds[512];
+        MEDT_STATIC_SHARED float lds[512];
         sim_tables_block(blockIdx.x - CH, tj.relative, tj.tables, tj.HQ, tj.L, lds);
         return;
     }
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
                                                                            const float* __restrict__ dy, BnStats st,
                                                                            float* __restrict__ partials, int C, int H,
                                                                            int W, int OC, int stride, int npg, int bf16) {
-    __shared__ float red[MEDT_WAVES * 2];
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * 2];
     const int HW = H * W, Ho = H / stride, Wo = W / stride;
     const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, ch = blockIdx.y;

@@ -23,3 +23,4 @@ extern "C" size_t emu_wopos_block_bwd_part_floats(const medt_block_desc* d) {
     return medt::blk_part_off(8, d->bn_groups, d->width, d->C, d->G);
 }
 extern "C" void emu_set_block_pk(int on) { medt::block_pk_mode() = on ? 1 : 0; }
+extern "C" void emu_set_block_bwd(int on) { medt::block_bwd_mode() = on ? 1 : 0; }

@@ -1,20 +1,19 @@
-// emu_common.cpp -- TEST INFRASTRUCTURE: what the emulated kernel sources expect from the rest of the library
+// emu_common.cpp -- TEST INFRASTRUCTURE: the arrays that play the LDS, the emulator's switches
 #include "medt_common.h"
 
 namespace medt {
-alignas(16) float smem[160 * 1024 / 4];          // the workgroup's LDS (extern __shared__ in the kernels)
-static char g_err[256];
-void set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-int launch_status(const char*) { return MEDT_OK; }
-bool abl_skip(const char*) { return false; }
+// the workgroup's LDS: the kernels' `extern __shared__` arrays (a launch uses one of them)
+alignas(16) float smem[160 * 1024 / 4];
+alignas(16) float wl[160 * 1024 / 4];            // conv.hip, pointwise.hip
+alignas(16) float sm[160 * 1024 / 4];            // elementwise.hip
+namespace fast_f32 { alignas(16) float smem[160 * 1024 / 4]; }       // axial_fast.hip, compiled twice
+namespace fast_bf16 { alignas(16) float smem[160 * 1024 / 4]; }
 }  // namespace medt
 
-static const bool lds_registered = (lane_emu::set_lds(medt::smem, sizeof(medt::smem)), true);
+static const bool lds_registered = (lane_emu::add_lds(medt::smem, sizeof(medt::smem)), lane_emu::add_lds(medt::wl, sizeof(medt::wl)),
+                                    lane_emu::add_lds(medt::sm, sizeof(medt::sm)),
+                                    lane_emu::add_lds(medt::fast_f32::smem, sizeof(medt::fast_f32::smem)),
+                                    lane_emu::add_lds(medt::fast_bf16::smem, sizeof(medt::fast_bf16::smem)), true);
 
 extern "C" void emu_set_order(int mode, unsigned long long seed) { lane_emu::set_order(mode, seed); }
-extern "C" const char* emu_last_error() { return medt::g_err; }
+extern "C" const char* emu_last_error() { return medt_last_error(); }

@@ -100,28 +100,31 @@ uint64_t exchange(uint64_t v, int src_lane) {
     return w.slot[p][src_lane & 63];
 }
 
-// LDS discipline: before every workgroup the bytes the launch asked for are filled with signalling garbage (a kernel that reads
+// LDS discipline (every array registered with add_lds -- the kernels name their dynamic LDS differently): before every
+// workgroup the bytes the launch asked for are filled with signalling garbage (a kernel that reads
 // LDS it never wrote computes NaNs, as it would compute garbage on the GPU) and the rest of the array with a canary that must
 // survive the workgroup (a kernel that writes past its allocation faults on the GPU).
-static float* lds_base = nullptr;
-static size_t lds_total = 0;
-void set_lds(float* base, size_t bytes) { lds_base = base; lds_total = bytes; }
+struct LdsRegion { float* base; size_t bytes; };
+static std::vector<LdsRegion>& lds_regions() { static std::vector<LdsRegion> r; return r; }
+void add_lds(float* base, size_t bytes) { lds_regions().push_back(LdsRegion{base, bytes}); }
 static const uint32_t LDS_GARBAGE = 0x7FA00000u /* NaN */, LDS_CANARY = 0xC0FFEE11u;
 static void lds_prepare(size_t used) {
-    if (!lds_base) return;
-    uint32_t* w = reinterpret_cast<uint32_t*>(lds_base);
-    const size_t n = lds_total / 4, u = used / 4 < n ? used / 4 : n;
-    for (size_t i = 0; i < u; ++i) w[i] = LDS_GARBAGE;
-    for (size_t i = u; i < n; ++i) w[i] = LDS_CANARY;
+    for (const LdsRegion& r : lds_regions()) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(r.base);
+        const size_t n = r.bytes / 4, u = used / 4 < n ? used / 4 : n;
+        for (size_t i = 0; i < u; ++i) w[i] = LDS_GARBAGE;
+        for (size_t i = u; i < n; ++i) w[i] = LDS_CANARY;
+    }
 }
 static void lds_check(size_t used, unsigned bx, unsigned by) {
-    if (!lds_base) return;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(lds_base);
-    for (size_t i = (used + 3) / 4; i < lds_total / 4; ++i)
-        if (w[i] != LDS_CANARY) {
-            fprintf(stderr, "lane_emu: workgroup (%u,%u) wrote LDS byte %zu, past the %zu bytes the launch requested\n", bx, by, i * 4, used);
-            abort();
-        }
+    for (const LdsRegion& r : lds_regions()) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(r.base);
+        for (size_t i = (used + 3) / 4; i < r.bytes / 4; ++i)
+            if (w[i] != LDS_CANARY) {
+                fprintf(stderr, "lane_emu: workgroup (%u,%u) wrote LDS byte %zu, past the %zu bytes the launch requested\n", bx, by, i * 4, used);
+                abort();
+            }
+    }
 }
 
 void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>& body) {

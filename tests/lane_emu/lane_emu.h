@@ -20,7 +20,7 @@ struct Idx3 { unsigned x, y, z; };
 extern Idx3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>& body);
-void set_lds(float* base, size_t bytes);      // the array that plays the LDS (poisoned / canaried around every workgroup)
+void add_lds(float* base, size_t bytes);      // an array that plays the LDS (poisoned / canaried around every workgroup)
 void block_barrier();                         // __syncthreads / s_barrier
 void wave_barrier();                          // a point every lane of the wavefront reaches together
 uint64_t exchange(uint64_t v, int src_lane);  // every lane of the wavefront posts v and reads lane src_lane's (0..63)

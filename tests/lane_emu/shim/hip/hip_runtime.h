@@ -28,6 +28,40 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct uint2 { unsigned x, y; };
+
+// clang's OpenCL-style float vectors as far as the kernels use them: splat casts, brace initialisation, [] and .x/.y/.z/.w,
+// .lo / .hi, element-wise + - * and their compound forms
+#define MEDT_VEC_TYPES 1
+struct medt_f2 {
+    float x, y;
+    medt_f2() = default;
+    medt_f2(float s) : x(s), y(s) {}
+    medt_f2(float a, float b) : x(a), y(b) {}
+    float& operator[](int i) { return i ? y : x; }
+    float operator[](int i) const { return i ? y : x; }
+};
+#define LANE_EMU_V2_OP(op)                                                                                      \
+    static inline medt_f2 operator op(medt_f2 a, medt_f2 b) { return medt_f2(a.x op b.x, a.y op b.y); }          \
+    static inline medt_f2& operator op##=(medt_f2& a, medt_f2 b) { a.x op## = b.x; a.y op## = b.y; return a; }
+LANE_EMU_V2_OP(+) LANE_EMU_V2_OP(-) LANE_EMU_V2_OP(*)
+#undef LANE_EMU_V2_OP
+static inline medt_f2 operator-(medt_f2 a) { return medt_f2(-a.x, -a.y); }
+struct lane_emu_f2_pod {                       // (members of anonymous aggregates may not have constructors)
+    float x, y;
+    operator medt_f2() const { return medt_f2(x, y); }
+};
+struct medt_f4 {
+    union {
+        struct { float x, y, z, w; };
+        struct { lane_emu_f2_pod lo, hi; };
+    };
+    medt_f4() = default;
+    medt_f4(float s) : x(s), y(s), z(s), w(s) {}
+    medt_f4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    float& operator[](int i) { return (&x)[i]; }
+    float operator[](int i) const { return (&x)[i]; }
+};
 
 #define threadIdx lane_emu::g_threadIdx
 #define blockIdx lane_emu::g_blockIdx
@@ -41,6 +75,12 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+// (one work-item runs at a time: read-modify-write is atomic by construction; the ORDER of float atomics is the emulator's)
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...)                                                      \
     do {                                                                                                             \
@@ -64,6 +104,10 @@ static inline double __hiloint2double(int hi, int lo) {
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 #define __log2f(x) log2f(x)          // (glibc declares these names itself)
 #define __expf(x) expf(x)
+#define __logf(x) logf(x)
+#define __exp2f(x) exp2f(x)
+#define __fdividef(a, b) ((a) / (b))
+#define __frcp_rn(x) (1.f / (x))
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 
@@ -87,10 +131,11 @@ static inline int lane_emu_dpp_source(int lane, int ctrl, bool* valid) {
     abort();
 }
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-    if (row_mask != 0xf || bank_mask != 0xf) abort();
+    if (bank_mask != 0xf) abort();
     bool valid;
-    const int from = lane_emu_dpp_source(lane_emu::lane_id(), ctrl, &valid);
+    const int lane = lane_emu::lane_id(), from = lane_emu_dpp_source(lane, ctrl, &valid);
     const int v = (int)(uint32_t)lane_emu::exchange((uint32_t)src, from);
+    if (!((row_mask >> (lane >> 4)) & 1)) return old;             // rows outside row_mask keep the old value
     return valid ? v : (bound_ctrl ? 0 : old);
 }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)lane_emu::exchange((uint32_t)v, lane); }
@@ -127,6 +172,27 @@ static inline double __shfl_xor(double v, int mask, int = 64) {
     uint64_t u; memcpy(&u, &v, 8);
     u = lane_emu::exchange(u, lane_emu::lane_id() ^ mask);
     double d; memcpy(&d, &u, 8); return d;
+}
+static inline int __shfl_xor(int v, int mask, int = 64) { return (int)(uint32_t)lane_emu::exchange((uint32_t)v, lane_emu::lane_id() ^ mask); }
+static inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)lane_emu::exchange((uint32_t)v, src); }
+static inline double __shfl(double v, int src, int = 64) {
+    uint64_t u; memcpy(&u, &v, 8);
+    u = lane_emu::exchange(u, src);
+    double d; memcpy(&d, &u, 8); return d;
+}
+// v_mfma_f32_16x16x4_f32: D (16 x 16) = A (16 x 4) B (4 x 16) + C;  lane l holds a = A[l % 16][l / 16], b = B[l / 16][l % 16],
+// c / d[v] = C / D[4 (l / 16) + v][l % 16]
+static inline medt_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, medt_f4 c, int, int, int) {
+    const int lane = lane_emu::lane_id(), j = lane & 15, i0 = 4 * (lane >> 4);
+    float A[4][4], B[4];                                              // A[v][k] = A[i0 + v][k], B[k] = B[k][j]
+    for (int k = 0; k < 4; ++k) {
+        B[k] = __uint_as_float((unsigned)lane_emu::exchange(__float_as_uint(b), k * 16 + j));
+        for (int v = 0; v < 4; ++v) A[v][k] = __uint_as_float((unsigned)lane_emu::exchange(__float_as_uint(a), k * 16 + i0 + v));
+    }
+    medt_f4 d = c;
+    for (int v = 0; v < 4; ++v)
+        for (int k = 0; k < 4; ++k) d[v] = fmaf(A[v][k], B[k], d[v]);
+    return d;
 }
 static inline float __shfl(float v, int src, int = 64) {
     return __uint_as_float((unsigned)lane_emu::exchange(__float_as_uint(v), src));
