@@ -610,6 +610,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                 // the L lanes that read sequence ls are the only readers of its region: when they share a wave the
                 // in-order LDS pipe makes the overwrite safe without a barrier; L = 128 spans two waves.
                 if (L > 64) __syncthreads();
+                else MEDT_WAVE_LOCKSTEP();
                 if (active) {
 #pragma unroll
                     for (int k = 0; k < OCG; ++k) {

@@ -24,6 +24,12 @@
 typedef float medt_f2 __attribute__((ext_vector_type(2)));
 typedef float medt_f4 __attribute__((ext_vector_type(4)));
 #endif
+// Marks a point where the code relies on the lanes of a wavefront executing in lockstep (data handed from lane to lane through
+// LDS inside one wave: the in-order LDS pipe needs no barrier).  Nothing on the GPU; the lane emulator, which runs the lanes of a
+// wave one after the other between synchronisation points, makes it one.
+#ifndef MEDT_WAVE_LOCKSTEP
+#define MEDT_WAVE_LOCKSTEP() do { } while (0)
+#endif
 #ifndef MEDT_LDS_BARRIER
 #define MEDT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif

@@ -117,6 +117,7 @@ static inline void __builtin_amdgcn_wave_barrier() { lane_emu::wave_barrier(); }
 static inline void __builtin_amdgcn_s_barrier() { lane_emu::block_barrier(); }
 // (the product's LDS-only barrier is inline gfx950 assembly; medt_common.h only defines it when this is not defined)
 #define MEDT_LDS_BARRIER() lane_emu::block_barrier()
+#define MEDT_WAVE_LOCKSTEP() lane_emu::wave_barrier()
 
 // ---- cross-lane operations (gfx950 semantics) --------------------------------------------------------------------------------
 static inline int lane_emu_dpp_source(int lane, int ctrl, bool* valid) {
