@@ -11,5 +11,5 @@ def test_cpu_baseline_leg_fields():
     r = bench.cpu_baseline_leg(steps=1)
     assert set(r) >= {"value", "unit", "cores", "kind", "sample"}
     assert r["unit"] == "images/s" and r["kind"] == "port" and r["cores"] >= 1
-    assert 0.05 < r["value"] < 1000.0                       # a MedT step on CPU takes seconds, not microseconds
+    assert 0.005 < r["value"] < 1000.0                      # a MedT step on CPU takes seconds, not microseconds
     assert "MedT" in r["sample"] and "1 training steps" in r["sample"]
