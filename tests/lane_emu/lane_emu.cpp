@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <ucontext.h>
+#include <string.h>
 #include <utility>
 #include <vector>
 
@@ -13,7 +14,38 @@ Idx3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 namespace {
 constexpr size_t STACK = 256 * 1024;
+// Context switch.  x86-64: a dozen instructions (callee-saved registers + stack pointer) instead of swapcontext(), which saves the
+// signal mask with a system call on every switch -- the emulator switches ~10^8 times in a whole-network run.
+#if defined(__x86_64__)
+#define LANE_EMU_FAST_SWITCH 1
+extern "C" void lane_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl lane_emu_switch
+    .type lane_emu_switch,@function
+lane_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size lane_emu_switch, .-lane_emu_switch
+)");
+struct Lane { void* sp; bool done; int xpar; };
+void* main_sp = nullptr;
+#else
 struct Lane { ucontext_t ctx; bool done; int xpar; };
+#endif
 struct Wave { int count, gen, alive; uint64_t slot[2][64]; };
 std::vector<Lane> lanes;
 std::vector<Wave> waves;
@@ -22,7 +54,11 @@ int cur = -1, T = 0, alive = 0, bcount = 0, bgen = 0;
 long progress = 0;
 const std::function<void()>* body_fn = nullptr;
 
+#ifdef LANE_EMU_FAST_SWITCH
+void yield() { lane_emu_switch(&lanes[cur].sp, main_sp); }
+#else
 void yield() { swapcontext(&lanes[cur].ctx, &main_ctx); }
+#endif
 
 // Which work-item runs u-th in a pass over the workgroup.  Work-items only interact at the synchronisation points they yield at,
 // so a kernel without data races computes the same bits under every order; a missing barrier shows up as a difference between
@@ -61,7 +97,10 @@ void trampoline() {
     ++progress;
     release_block_if_complete();               // work-items that have exited do not take part in later barriers
     release_wave_if_complete(w);
-    // returns to main_ctx through uc_link
+#ifdef LANE_EMU_FAST_SWITCH
+    for (;;) lane_emu_switch(&me.sp, main_sp);  // (a finished work-item is never resumed)
+#endif
+    // ucontext: returns to main_ctx through uc_link
 }
 }  // namespace
 
@@ -146,11 +185,21 @@ void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>
                 for (int t = 0; t < T; ++t) {
                     Lane& l = lanes[t];
                     l.done = false; l.xpar = 0;
+#ifdef LANE_EMU_FAST_SWITCH
+                    // initial frame: six callee-saved registers + the entry point as return address; the stack pointer is
+                    // 8 mod 16 when trampoline starts, as after a call
+                    void** top = reinterpret_cast<void**>(stacks + STACK * (t + 1));
+                    void** base = top - 8;
+                    memset(base, 0, 8 * sizeof(void*));
+                    base[6] = reinterpret_cast<void*>(&trampoline);
+                    l.sp = base;
+#else
                     getcontext(&l.ctx);
                     l.ctx.uc_stack.ss_sp = stacks + STACK * t;
                     l.ctx.uc_stack.ss_size = STACK;
                     l.ctx.uc_link = &main_ctx;
                     makecontext(&l.ctx, trampoline, 0);
+#endif
                     ++waves[t >> 6].alive;
                 }
                 while (alive > 0) {
@@ -160,7 +209,11 @@ void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>
                         if (lanes[t].done) continue;
                         cur = t;
                         g_threadIdx = Idx3{(unsigned)t, 0, 0};
+#ifdef LANE_EMU_FAST_SWITCH
+                        lane_emu_switch(&main_sp, lanes[t].sp);
+#else
                         swapcontext(&main_ctx, &lanes[t].ctx);
+#endif
                     }
                     if (progress == before && alive > 0) {
                         fprintf(stderr, "lane_emu: deadlock in workgroup (%u,%u,%u): %d work-items alive, %d at the barrier\n",
