@@ -32,6 +32,17 @@ def emulated_device(emu):
         patch(torch.cuda, "synchronize", lambda *a, **k: None)
         patch(net, "TWO_STREAMS", False)                          # (streams are a scheduling matter; one queue, same arithmetic)
         patch(block, "fused_forward", lambda blk, x, g: fused(blk, x.as_subclass(DeviceTensor), g))
+        from medt_amd import optim
+        launch_adam = optim.FlatAdam._launch_adam
+
+        def launch_adam_emulated(self, g, gscale):              # FlatAdam's own device check: its flat buffers as device tensors
+            keep = g.flat_p
+            g.flat_p = keep.as_subclass(DeviceTensor)
+            try:
+                return launch_adam(self, g, gscale)
+            finally:
+                g.flat_p = keep
+        patch(optim.FlatAdam, "_launch_adam", launch_adam_emulated)
         yield
     finally:
         for obj, name, value in reversed(saved):
