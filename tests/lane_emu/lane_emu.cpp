@@ -41,10 +41,10 @@ lane_emu_switch:
     ret
     .size lane_emu_switch, .-lane_emu_switch
 )");
-struct Lane { void* sp; bool done; int xpar; };
+struct Lane { void* sp; bool done; int xpar; int wait; };     // wait: 0 running, 1 at a wavefront sync, 2 at the workgroup barrier
 void* main_sp = nullptr;
 #else
-struct Lane { ucontext_t ctx; bool done; int xpar; };
+struct Lane { ucontext_t ctx; bool done; int xpar; int wait; };
 #endif
 struct Wave { int count, gen, alive; uint64_t slot[2][64]; };
 std::vector<Lane> lanes;
@@ -116,8 +116,10 @@ void block_barrier() {
     const int gen = bgen;
     ++bcount;
     ++progress;
+    lanes[cur].wait = 2;
     release_block_if_complete();
     while (bgen == gen) yield();
+    lanes[cur].wait = 0;
 }
 
 void wave_barrier() {
@@ -125,15 +127,17 @@ void wave_barrier() {
     const int gen = w.gen;
     ++w.count;
     ++progress;
+    lanes[cur].wait = 1;
     release_wave_if_complete(w);
     while (w.gen == gen) yield();
+    lanes[cur].wait = 0;
 }
 
 uint64_t exchange(uint64_t v, int src_lane) {
-    Lane& me = lanes[cur];
     Wave& w = waves[cur >> 6];
-    const int p = me.xpar;
-    me.xpar ^= 1;                               // (two slots: a lane can be at most one operation ahead of its wavefront)
+    // two slot sets, chosen by the wavefront's synchronisation count (the same for every lane that arrives at this operation,
+    // whatever it skipped before): a lane can be at most one operation ahead of the others, who may still be reading the other set
+    const int p = w.gen & 1;
     w.slot[p][cur & 63] = v;
     wave_barrier();
     return w.slot[p][src_lane & 63];
@@ -166,6 +170,30 @@ static void lds_check(size_t used, unsigned bx, unsigned by) {
     }
 }
 
+// Divergence: a cross-lane operation inside a branch that only some lanes of a wavefront take.  On the GPU the others are masked
+// off; here they have run ahead and sit at the workgroup barrier behind the branch (or have exited), so they can never arrive at
+// this operation.  When nothing else can move, a wavefront whose remaining lanes are all at the workgroup barrier lets its waiting
+// lanes go (they read stale values for the absent lanes -- undefined on the GPU too).  Lanes of one wavefront waiting at two
+// DIFFERENT cross-lane operations cannot be told apart from a real deadlock: that aborts.
+static bool release_divergent_waves() {
+    bool any = false;
+    for (size_t wi = 0; wi < waves.size(); ++wi) {
+        Wave& w = waves[wi];
+        if (w.count == 0) continue;
+        int at_wave = 0, at_block = 0;
+        for (int t = (int)wi * 64; t < T && t < (int)wi * 64 + 64; ++t) {
+            if (lanes[t].done) continue;
+            at_wave += lanes[t].wait == 1;
+            at_block += lanes[t].wait == 2;
+        }
+        if (at_wave == w.count && at_wave + at_block == w.alive && at_block > 0) {
+            w.count = 0; ++w.gen; ++progress;
+            any = true;
+        }
+    }
+    return any;
+}
+
 void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>& body) {
     if (block.y != 1 || block.z != 1) { fprintf(stderr, "lane_emu: 1-D workgroups only\n"); abort(); }
     T = (int)block.x;
@@ -184,7 +212,7 @@ void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>
                 alive = T; bcount = 0; bgen = 0;
                 for (int t = 0; t < T; ++t) {
                     Lane& l = lanes[t];
-                    l.done = false; l.xpar = 0;
+                    l.done = false; l.xpar = 0; l.wait = 0;
 #ifdef LANE_EMU_FAST_SWITCH
                     // initial frame: six callee-saved registers + the entry point as return address; the stack pointer is
                     // 8 mod 16 when trampoline starts, as after a call
@@ -215,7 +243,7 @@ void launch(Idx3 grid, Idx3 block, size_t lds_bytes, const std::function<void()>
                         swapcontext(&main_ctx, &lanes[t].ctx);
 #endif
                     }
-                    if (progress == before && alive > 0) {
+                    if (progress == before && alive > 0 && !release_divergent_waves()) {
                         fprintf(stderr, "lane_emu: deadlock in workgroup (%u,%u,%u): %d work-items alive, %d at the barrier\n",
                                 bx, by, bz, alive, bcount);
                         abort();

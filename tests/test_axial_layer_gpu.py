@@ -37,7 +37,7 @@ def run_case(layer, st, x, dout, kind, width, stride, device, training=True, bn_
         p.grad = None
     layer.train(training)
     layer.bn_groups = bn_groups
-    xg = x.to(device).float().requires_grad_(True)
+    xg = x.to(device).float().clone().requires_grad_(True)   # (clone: under --emulate the device is the CPU and .to() is the identity)
     y = layer(xg)
     (y * dout.to(device).float()).sum().backward()
     torch.cuda.synchronize()
@@ -254,7 +254,7 @@ def test_dispatch_scale_variants_vs_oracle(width, device):
         p.requires_grad_(True)
         p.grad = None
     layer.train()
-    xg = x.to(device).requires_grad_(True)
+    xg = x.to(device).clone().requires_grad_(True)
     y = layer(xg)
     (y * dout.to(device)).sum().backward()
     torch.cuda.synchronize()
@@ -365,7 +365,7 @@ def test_layer_backward_is_bit_reproducible(case, device):
             p.requires_grad_(True)
             p.grad = None
         layer.train(True)
-        xg = x.to(device).requires_grad_(True)
+        xg = x.to(device).clone().requires_grad_(True)
         (layer(xg) * dout.to(device)).sum().backward()
         torch.cuda.synchronize()
         runs.append({"dx": xg.grad.clone(), **{k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}})
