@@ -837,6 +837,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                 }
                 // results replace this sequence's q|k|v rows in LDS: its lanes all sit in this wave and have issued
                 // every read of the sweep above (in-order LDS pipe)
+                MEDT_WAVE_LOCKSTEP();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float l = l2[r].x + l2[r].y;
