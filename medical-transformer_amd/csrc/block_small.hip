@@ -82,12 +82,83 @@ __device__ __forceinline__ void blk_scale_shift(float s, float m2, float n, cons
     shift = fmaf(-mean, scale, b);
 }
 
+// K wave sums at once by TRANSPOSITION (the second-generation instantiations, MEDT_BLOCK_PK=1): a lane swap exchanges halves
+// between two registers, so one swap + one add folds TWO values over the wave halves (value a ends up in lanes 0-31, b in 32-63),
+// the next does the same over the row pairs -- after two levels one register holds FOUR channels, one per 16-lane row, and only
+// the in-row part (four DPP adds) is paid per register instead of per channel: K = 8 costs 20 VALU instructions instead of 80.
+// Row r of w[j] holds channel 4 j + {0, 2, 1, 3}[r], the same in all 16 lanes of the row.
+__device__ __forceinline__ float blk_fold32(float a, float b) {      // lanes 0-31: a[l] + a[l + 32];  lanes 32-63: b[l - 32] + b[l]
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float blk_fold16(float a, float b) {      // rows 0, 2: a's rows (0,1) / (2,3) added;  rows 1, 3: b's
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float blk_row_sum(float v) {              // sum over the 16 lanes of a row, in all of them
+    v += blk_dpp<0xB1>(v);
+    v += blk_dpp<0x4E>(v);
+    v += blk_dpp<0x141>(v);
+    v += blk_dpp<0x140>(v);
+    return v;
+}
+template <int K>
+__device__ __forceinline__ void blk_multi_sum(const float (&v)[K], float (&w)[K / 4]) {
+    static_assert(K % 4 == 0, "four channels per register");
+#pragma unroll
+    for (int j = 0; j < K / 4; ++j)
+        w[j] = blk_row_sum(blk_fold16(blk_fold32(v[4 * j], v[4 * j + 1]), blk_fold32(v[4 * j + 2], v[4 * j + 3])));
+}
+// the value of channel k (compile-time) out of the row layout, wave-uniform
+template <int K>
+__device__ __forceinline__ float blk_multi_get(const float (&w)[K / 4], int k) {
+    return blk_lane(w[k >> 2], 16 * ((k & 3) == 1 ? 2 : ((k & 3) == 2 ? 1 : (k & 3))));
+}
+// the channel (0 .. K-1) whose value this lane's row holds in register j
+__device__ __forceinline__ int blk_multi_chan(int lane, int j) {
+    const int r = lane >> 4;
+    return 4 * j + (r == 1 ? 2 : (r == 2 ? 1 : r));
+}
+
 // BatchNorm of K channels whose 64 values (the group's positions) sit one per lane: v[k] = channel ch0 + k.
 // prm: the BatchNorm's parameter table in LDS ([CH][4]: weight, bias, running mean, running variance).
-template <int K>
+template <int K, bool V2 = false>
 __device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, double* part, int ch0, int training, float eps,
                                         float (&sc)[K], float (&sh)[K]) {
     const int lane = threadIdx.x & 63;
+    if (V2) {
+        // sums, centred sums of squares and the finalisation in the row layout (four channels per register)
+        float s[K / 4], m2[K / 4], d2[K];
+#pragma unroll
+        for (int j = 0; j < K / 4; ++j) { s[j] = 0.f; m2[j] = 0.f; }
+        if (training) {
+            blk_multi_sum<K>(v, s);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float d = v[k] - blk_multi_get<K>(s, k) * (1.f / 64.f);     // second pass about the mean
+                d2[k] = d * d;
+            }
+            blk_multi_sum<K>(d2, m2);
+        }
+        float scale[K / 4], shift[K / 4];
+#pragma unroll
+        for (int j = 0; j < K / 4; ++j) {
+            const int ch = ch0 + blk_multi_chan(lane, j);
+            blk_scale_shift(s[j], m2[j], 64.f, prm + ch * 4, eps, training, scale[j], shift[j]);
+            if (training && (lane & 15) == 0) {
+                double sd, ssd;
+                centered_to_raw(s[j], m2[j], s[j] * (1.f / 64.f), 64.0, sd, ssd);
+                part[(size_t)ch * 2] = sd;
+                part[(size_t)ch * 2 + 1] = ssd;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            sc[k] = blk_multi_get<K>(scale, k);
+            sh[k] = blk_multi_get<K>(shift, k);
+        }
+        return;
+    }
     float my_s = 0.f, my_m2 = 0.f;
     if (training) {
 #pragma unroll
@@ -114,7 +185,8 @@ __device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, d
 }
 
 // Two FMAs per lane and instruction (v_pk_fma_f32 with the weights as an SGPR pair: the kernels are VALU-issue-bound on the one CU a
-// patch group gets, and two thirds of their instructions are these FMAs).  PK variants: MEDT_BLOCK_PK=1, off until measured.
+// patch group gets, and two thirds of their instructions are these FMAs).  The second-generation instantiations (template
+// parameter PK: these FMAs + the transposed wave reductions above): MEDT_BLOCK_PK=1, off until measured.
 typedef medt_f2 blk_v2f;
 #ifdef MEDT_LANE_EMU
 __device__ __forceinline__ blk_v2f blk_pk_fma(blk_v2f a, blk_v2f b, blk_v2f c) { return blk_v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
@@ -169,7 +241,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
         wave_conv1x1<CB, CW, PK>(w_qkv, wv * CB, A, acc);
 #pragma unroll
         for (int k = 0; k < CB; ++k) qkv_raw[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = acc[k];
-        wave_bn<CB>(acc, prm_q, part_q, wv * CB, training, eps, sc, sh);
+        wave_bn<CB, PK>(acc, prm_q, part_q, wv * CB, training, eps, sc, sh);
 #pragma unroll
         for (int k = 0; k < CB; ++k) Q[(wv * CB + k) * 64 + lane] = fmaf(acc[k], sc[k], sh[k]);
     }
@@ -236,7 +308,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
     }
     if (hf == 0) lse[((size_t)(n0 + ni) * G + g) * HW + p] = m + __log2f(l);
     // 3. bn_output (+ the block's ReLU behind the width layer)                                 (:242, :381-383)
-    wave_bn<HV>(o, prm_o, part_o, g * GP + hf * HV, training, eps, sc, sh);
+    wave_bn<HV, PK>(o, prm_o, part_o, g * GP + hf * HV, training, eps, sc, sh);
 #pragma unroll
     for (int c = 0; c < HV; ++c) {
         float v = fmaf(o[c], sc[c], sh[c]);
@@ -312,7 +384,7 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
         wave_conv1x1<CA, CI, PK>(w_down, wv * CA, X, acc);
 #pragma unroll
         for (int k = 0; k < CA; ++k) a.z1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
-        wave_bn<CA>(acc, prm + poff[0], a.part[0] ? a.part[0] + (size_t)grp * CW * 2 : nullptr, wv * CA, a.training, a.eps, sc, sh);
+        wave_bn<CA, PK>(acc, prm + poff[0], a.part[0] ? a.part[0] + (size_t)grp * CW * 2 : nullptr, wv * CA, a.training, a.eps, sc, sh);
 #pragma unroll
         for (int k = 0; k < CA; ++k) {
             const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]), 0.f);
@@ -335,7 +407,7 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
         wave_conv1x1<CF, CW, PK>(w_up, wv * CF, A, acc);
 #pragma unroll
         for (int k = 0; k < CF; ++k) a.z2[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = acc[k];
-        wave_bn<CF>(acc, prm + poff[7], a.part[7] + (size_t)grp * CI * 2, wv * CF, a.training, a.eps, sc, sh);
+        wave_bn<CF, PK>(acc, prm + poff[7], a.part[7] + (size_t)grp * CI * 2, wv * CF, a.training, a.eps, sc, sh);
 #pragma unroll
         for (int k = 0; k < CF; ++k) {
             const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]) + X[(wv * CF + k) * 64 + lane], 0.f);
@@ -460,23 +532,36 @@ struct BlkBwdArgs {
 //   dz = A (g - m1 - xhat m2) (training) | A g (eval),  A = weight * rstd, m1 = mean g, m2 = mean g * xhat
 // The two sums go out as this group's partial row (what bn_bwd_finalize / wopos_small_bwd_finalize reduce over the groups into
 // the parameter gradients); coef (optional): the same backward as dz = c0 g + c1 x + c2 for the recorded weight-gradient job.
-template <int K>
+template <int K, bool V2 = false>
 __device__ __forceinline__ void wave_bn_bwd(const float (&g)[K], const float (&xr)[K], const BlkBnB& bn, int grp, int CH, int ch0,
                                             float* part, float* coef, int training, float (&dz)[K]) {
     const int lane = threadIdx.x & 63;
     float my1 = 0.f, my2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    float sums[2 * K / 4];                      // V2: the 2K sums at once (blk_multi_sum), [sum g | sum g xhat] in the row layout
+    if (V2) {
+        float val[2 * K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float mean = blk_ldu(bn.st + grp * CH + ch0 + k), rstd = blk_ldu(bn.st + bn.n + grp * CH + ch0 + k);
+            val[k] = g[k];
+            val[K + k] = g[k] * ((xr[k] - mean) * rstd);
+        }
+        blk_multi_sum<2 * K>(val, sums);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float mean = blk_ldu(bn.st + grp * CH + ch0 + k), rstd = blk_ldu(bn.st + bn.n + grp * CH + ch0 + k);
         const float A = blk_ldu(bn.gamma + ch0 + k) * rstd;
         const float xh = (xr[k] - mean) * rstd;
-        const float s1 = blk_wave_sum(g[k]), s2 = blk_wave_sum(g[k] * xh);
+        const float s1 = V2 ? blk_multi_get<2 * K>(sums, k) : blk_wave_sum(g[k]);
+        const float s2 = V2 ? blk_multi_get<2 * K>(sums, K + k) : blk_wave_sum(g[k] * xh);
         const float m1 = training ? s1 * (1.f / 64.f) : 0.f, m2 = training ? s2 * (1.f / 64.f) : 0.f;
         dz[k] = A * (g[k] - m1 - xh * m2);
         if (lane == k) {
             my1 = s1; my2 = s2;
             c0 = A; c1 = -A * rstd * m2; c2 = A * (rstd * mean * m2 - m1);
         }
+        if (V2) MEDT_SCHED_FENCE();             // one channel's wave-uniform scalars at a time (the kernel is short of SGPRs)
     }
     if (lane < K) {
         part[(unsigned)(grp * CH + ch0 + lane) * 2] = my1;
@@ -553,7 +638,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
         float gm[HV], d_o[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) gm[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : gio[k];
-        wave_bn_bwd<HV>(gm, sv, bo, grp, CW, wv * HV, part_o, nullptr, training, d_o);
+        wave_bn_bwd<HV, PK>(gm, sv, bo, grp, CW, wv * HV, part_o, nullptr, training, d_o);
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             D[(wv * HV + k) * 64 + lane] = d_o[k];
@@ -647,7 +732,7 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
     // 4. bn_qkv backward                                                                       (:228)
     {
         float dzq[CB];
-        wave_bn_bwd<CB>(gq, raw, bq, grp, 2 * CW, wv * CB, part_q, coef_q, training, dzq);
+        wave_bn_bwd<CB, PK>(gq, raw, bq, grp, 2 * CW, wv * CB, part_q, coef_q, training, dzq);
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             dqkv[eq + k * HW] = gq[k];
@@ -696,7 +781,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
             zz[k] = a.z2[ei + k * HW];
             if (!(yv > 0.f)) gy[k] = 0.f;
         }
-        wave_bn_bwd<CF>(gy, zz, bn2, grp, CI, wv * CF, part + blk_part_off(7, gs, CW, CI, G), nullptr, a.training, dz);
+        wave_bn_bwd<CF, PK>(gy, zz, bn2, grp, CI, wv * CF, part + blk_part_off(7, gs, CW, CI, G), nullptr, a.training, dz);
 #pragma unroll
         for (int k = 0; k < CF; ++k) {
             a.dz2[ei + k * HW] = dz[k];
@@ -726,7 +811,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
             zz[k] = a.z1[ew + k * HW];
             gm[k] = a.y1[ew + k * HW] > 0.f ? gio[k] : 0.f;
         }
-        wave_bn_bwd<CA>(gm, zz, bn1, grp, CW, wv * CA, part, nullptr, a.training, dz);
+        wave_bn_bwd<CA, PK>(gm, zz, bn1, grp, CW, wv * CA, part, nullptr, a.training, dz);
 #pragma unroll
         for (int k = 0; k < CA; ++k) {
             a.dz1[ew + k * HW] = dz[k];
