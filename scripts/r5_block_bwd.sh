@@ -11,7 +11,7 @@ echo "== parity, MEDT_BLOCK_BWD=1" >> $out
 MEDT_BLOCK_BWD=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py tests/test_dist_gpu.py -m gpu -x -q 2>&1 | tail -15 >> $out
 echo "== smoke, MEDT_BLOCK_BWD=1" >> $out
 MEDT_BLOCK_BWD=1 timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -4 >> $out
-echo "== parity, MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (packed-FMA instantiations of both block kernels)" >> $out
+echo "== parity, MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (second-generation instantiations of both block kernels: packed FMAs + transposed wave reductions)" >> $out
 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -5 >> $out
 for rep in 1 2; do
   for v in "0 0" "0 1" "1 0" "1 1"; do
