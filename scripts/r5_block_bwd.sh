@@ -20,6 +20,8 @@ for rep in 1 2; do
     MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 timeout 600 python bench.py --steps 200 --warmup 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
   done
 done
+echo "== per-kernel timing, all variants" >> $out
+timeout 300 python scripts/block_kernels_bench.py 2>&1 | tail -10 >> $out
 echo "== phase stamps of the block kernels (libmedt_stamps.so must have been built here: python scripts/phase_stamps.py --build)" >> $out
 for pk in 0 1; do echo "-- MEDT_BLOCK_PK=$pk" >> $out; MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=$pk timeout 300 python scripts/phase_stamps.py 2>&1 | tail -28 >> $out; done
 cat $out
