@@ -22,6 +22,12 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
+def emulating(request):
+    """True under --emulate: tests that start their own processes pass the emulated device on."""
+    return bool(request.config.getoption("--emulate"))
+
+
+@pytest.fixture(scope="session")
 def device(request):
     import torch
     if request.config.getoption("--emulate"):

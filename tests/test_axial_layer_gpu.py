@@ -278,7 +278,7 @@ def test_dispatch_scale_variants_vs_oracle(width, device):
     compare(got, want)
 
 
-def _run_layer_subprocess(env_extra):
+def _run_layer_subprocess(env_extra, emulate=False):
     import subprocess
     import sys
     code = r'''
@@ -287,6 +287,18 @@ sys.path[:0] = [os.path.join(os.environ["MEDT_ROOT"], "medical-transformer_amd")
 import lib as droplib
 from oracle import medt_oracle as O
 dev = torch.device("cuda:0")
+if os.environ.get("MEDT_TEST_EMULATE") == "1":          # pytest --emulate: the CPU lane emulator as the device (tests/emu_device.py)
+    import ctypes
+    import test_lane_emu as T
+    from emu_device import emulated_device
+    from medt_amd import _lib as L
+    emu = ctypes.CDLL(T.build_emulator())
+    for name, (res, args) in L.SIGNATURES.items():
+        fn = getattr(emu, name)
+        fn.restype, fn.argtypes = res, args
+    _emulated = emulated_device(emu)                      # (kept alive: leaving the context restores the product's device checks)
+    _emulated.__enter__()
+    dev = torch.device("cpu")
 for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, False), (16, 64, False), (16, 32, True),
                     (16, 128, False), (16, 128, True), (16, 16, True), (16, 32, False)):
     layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=width).to(dev)
@@ -303,32 +315,32 @@ for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, F
 print("layers ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MEDT_ROOT=root, **env_extra)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, MEDT_ROOT=root, MEDT_TEST_EMULATE="1" if emulate else "0", **env_extra)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=3000 if emulate else 600)
     assert r.returncode == 0 and "layers ok" in r.stdout, r.stderr[-1500:]
 
 
-def test_softmax_bound_path(device):
+def test_softmax_bound_path(device, emulating):
     """Large problems take the bound-referenced softmax kernel (softmax shifted by a cheap per-row upper bound of
     the logits instead of a running maximum).  MEDT_BOUND_PATH=1 forces it on small shapes: same results."""
-    _run_layer_subprocess({"MEDT_BOUND_PATH": "1"})
+    _run_layer_subprocess({"MEDT_BOUND_PATH": "1"}, emulating)
 
 
-def test_softmax_bound_repair_pass(device):
+def test_softmax_bound_repair_pass(device, emulating):
     """When the bound is so loose that a row's sum underflows the kernel raises a flag and the exact kernel queued
     behind it redoes the launch.  MEDT_DEBUG_BOUND_SHIFT=400 pushes every bound 400 octaves up, so every launch
     is repaired: results must not change."""
-    _run_layer_subprocess({"MEDT_BOUND_PATH": "1", "MEDT_DEBUG_BOUND_SHIFT": "400"})
+    _run_layer_subprocess({"MEDT_BOUND_PATH": "1", "MEDT_DEBUG_BOUND_SHIFT": "400"}, emulating)
 
 
 @pytest.mark.parametrize("bound,shift", [("0", "0"), ("1", "0"), ("1", "400")], ids=["exact", "bound", "repair"])
-def test_four_rows_per_lane_kernel(bound, shift, device):
+def test_four_rows_per_lane_kernel(bound, shift, device, emulating):
     """gp = 2 layers of large problems run the four-rows-per-lane forward kernel (MEDT_ROWS4=1 forces it on the
     small test shapes, ragged tiles included): exact, bound-referenced and repaired variants, both axes, L = 16..128."""
-    _run_layer_subprocess({"MEDT_ROWS4": "1", "MEDT_BOUND_PATH": bound, "MEDT_DEBUG_BOUND_SHIFT": shift})
+    _run_layer_subprocess({"MEDT_ROWS4": "1", "MEDT_BOUND_PATH": bound, "MEDT_DEBUG_BOUND_SHIFT": shift}, emulating)
 
 
-def test_layer_by_layer_fallback_of_small_layers(device):
+def test_layer_by_layer_fallback_of_small_layers(device, emulating):
     """Position-free layers / 1x1 conv blocks whose BatchNorm group fits one workgroup normally run the fused
     small-layer kernels (axial_small.hip, conv_small.hip).  MEDT_DISABLE_SMALL=1 forces the layer-by-layer path those
     shapes used before, which stays the path of larger groups: same parity tests, in a subprocess."""
@@ -338,8 +350,9 @@ def test_layer_by_layer_fallback_of_small_layers(device):
     env = dict(os.environ, MEDT_DISABLE_SMALL="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_axial_layer_gpu.py"), os.path.join(root, "tests", "test_ops_gpu.py"),
-                        "-k", "wopos or test_conv_block"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+                        "-k", "wopos or test_conv_block"] + (["--emulate"] if emulating else []), env=env, capture_output=True,
+                       text=True, timeout=7000 if emulating else 900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout and " skipped" not in r.stdout.splitlines()[-1], r.stdout[-1500:] + r.stderr[-500:]
 
 
 @pytest.mark.parametrize("case", [("dynamic", 16, 64, True, 1, 4, 64), ("dynamic", 32, 32, False, 2, 4, 32),
