@@ -606,38 +606,51 @@ __device__ __forceinline__ void wave_dgrad1x1(const float* __restrict__ w, int c
     }
 }
 
-// Backward of one AxialAttention_wopos layer: gio = gradient at the layer's output (channels wv * CW/16 ..) on entry, at its
-// input on return.  Q | D | S: tiles of the normalised q|k|v, of d(sv) and of sv; DZ: the gradient tile behind bn_qkv's backward;
-// E: this wave's private 4 x 64 strip.
+// Everything global one attention layer's backward reads, requested in one batch a phase AHEAD of its use (under the 1x1 dgrad
+// that precedes the layer: the ~1-2 us of global latency are covered by that contraction instead of opening the layer).
+template <int CW>
+struct BlkLayerLoads { float raw[2 * CW / 16], sv[CW / 16], yv[CW / 16], ls; };
+template <int CW, int GP, bool RELU>
+__device__ __forceinline__ void wave_layer_loads(BlkLayerLoads<CW>& ld, const float* __restrict__ qkv_raw,
+                                                 const float* __restrict__ stacked, const float* __restrict__ lse,
+                                                 const float* __restrict__ yl, int n0, int wv) {
+    constexpr int G = CW / GP, HW = 16, CB = 2 * CW / 16, HV = CW / 16;
+    const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
+    // (32-bit element offsets: one address register per tensor shape, the channel steps fold into the instruction offsets)
+    const unsigned eq = ((unsigned)(n0 + ni) * 2 * CW + wv * CB) * HW + p, ev = ((unsigned)(n0 + ni) * CW + wv * HV) * HW + p;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) ld.raw[k] = qkv_raw[eq + k * HW];
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        ld.sv[k] = stacked[ev + k * HW];
+        ld.yv[k] = RELU ? yl[ev + k * HW] : 1.f;
+    }
+    ld.ls = lse[((unsigned)(n0 + ni) * G + (wv >> 1)) * HW + p];
+}
+
+// Backward of one AxialAttention_wopos layer up to the gradient tile behind bn_qkv's backward (DZ, published by the closing
+// barrier; the caller contracts it with the qkv_transform weights): gin = gradient at the layer's output (channels wv * CW/16 ..).
+// Q | D | S: tiles of the normalised q|k|v, of d(sv) and of sv; E: this wave's private 4 x 64 strip.
 template <int CW, int GP, int AXIS, bool RELU, bool PK>
-__device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_qkv, float (&gio)[CW / 16], float* Q, float* D,
+__device__ __forceinline__ void wave_attention_bwd(const BlkLayerLoads<CW>& ld, const float (&gin)[CW / 16], float* Q, float* D,
                                                    float* S, float* DZ, float* E, const BlkBnB& bq, const BlkBnB& bs,
-                                                   const BlkBnB& bo, const float* __restrict__ qkv_raw,
-                                                   const float* __restrict__ stacked, const float* __restrict__ lse,
-                                                   const float* __restrict__ yl, float* dqkv, float* coef_q, float* part_q,
+                                                   const BlkBnB& bo, float* dqkv, float* coef_q, float* part_q,
                                                    float* part_s, float* part_o, int grp, int n0, int training, int wv, int stamp0) {
     constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 4, HW = 16, CB = 2 * CW / 16, HV = CW / 16;
     static_assert(CB == NCH / 2 && HV * 2 == GP && 2 * HQ == CB, "two waves per head: q | k and v");
     const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
     const int g = wv >> 1, hf = wv & 1;
-    // everything global this layer needs, in one batch
-    // (32-bit element offsets: one address register per tensor shape, the channel steps fold into the instruction offsets)
-    const unsigned eq = ((unsigned)(n0 + ni) * 2 * CW + wv * CB) * HW + p, ev = ((unsigned)(n0 + ni) * CW + wv * HV) * HW + p;
-    float raw[CB], sv[HV], yv[HV];
-#pragma unroll
-    for (int k = 0; k < CB; ++k) raw[k] = qkv_raw[eq + k * HW];
-#pragma unroll
-    for (int k = 0; k < HV; ++k) {
-        sv[k] = stacked[ev + k * HW];
-        yv[k] = RELU ? yl[ev + k * HW] : 1.f;
-    }
-    const float ls = lse[((unsigned)(n0 + ni) * G + g) * HW + p];
+    const unsigned eq = ((unsigned)(n0 + ni) * 2 * CW + wv * CB) * HW + p;
+    const float (&raw)[CB] = ld.raw;
+    const float (&sv)[HV] = ld.sv;
+    const float (&yv)[HV] = ld.yv;
+    const float ls = ld.ls;
     MEDT_SCHED_FENCE();
     // 1. [ReLU mask,] bn_output backward; tiles                                               (axialnet.py:242, :381-383)
     {
         float gm[HV], d_o[HV];
 #pragma unroll
-        for (int k = 0; k < HV; ++k) gm[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : gio[k];
+        for (int k = 0; k < HV; ++k) gm[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : gin[k];
         wave_bn_bwd<HV, PK>(gm, sv, bo, grp, CW, wv * HV, part_o, nullptr, training, d_o);
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
@@ -741,9 +754,6 @@ __device__ __forceinline__ void wave_attention_bwd(const float* __restrict__ w_q
     }
     MEDT_LDS_BARRIER();                                   // the gradient at the qkv_transform output in LDS
     BLK_STAMP(stamp0 + 3);                                // bn_qkv backward + tile
-    // 5. qkv_transform dgrad
-    wave_dgrad1x1<HV, 2 * CW, CW, PK>(w_qkv, wv * HV, DZ, gio);
-    BLK_STAMP(stamp0 + 4);                                // projection dgrad
 }
 
 template <int CI, int CW, int GP, bool PK>
@@ -790,26 +800,38 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     }
     MEDT_LDS_BARRIER();
     BLK_STAMP(11);                                      // loads, mask, bn2 backward, tile
-    // ---- conv_up dgrad                                                                            (:385)
+    // ---- conv_up dgrad, with the width layer's global reads in flight under it                         (:385)
     float gio[CA];
+    BlkLayerLoads<CW> ldw, ldh;
+    wave_layer_loads<CW, GP, true>(ldw, a.qkv[1], a.stk[1], a.lse[1], a.y_w, n0, wv);
+    MEDT_SCHED_FENCE();
     wave_dgrad1x1<CA, CI, CW, PK>(w_up, wv * CA, BA, gio);
     BLK_STAMP(12);                                      // conv_up dgrad
     // ---- width layer (behind the block's ReLU), height layer                                      (:377-383)
-    wave_attention_bwd<CW, GP, 1, true, PK>(w_qw, gio, Q, D, S, BA, E + wv * 4 * 64, bqw, bsw, bow, a.qkv[1], a.stk[1], a.lse[1], a.y_w,
-                                        a.dqkv[1], a.coef_q[1], part + blk_part_off(4, gs, CW, CI, G),
-                                        part + blk_part_off(5, gs, CW, CI, G), part + blk_part_off(6, gs, CW, CI, G), grp, n0,
-                                        a.training, wv, 13);
-    wave_attention_bwd<CW, GP, 0, false, PK>(w_qh, gio, Q, D, S, BA, E + wv * 4 * 64, bqh, bsh, boh, a.qkv[0], a.stk[0], a.lse[0], nullptr,
-                                         a.dqkv[0], a.coef_q[0], part + blk_part_off(1, gs, CW, CI, G),
-                                         part + blk_part_off(2, gs, CW, CI, G), part + blk_part_off(3, gs, CW, CI, G), grp, n0,
-                                         a.training, wv, 18);
+    wave_attention_bwd<CW, GP, 1, true, PK>(ldw, gio, Q, D, S, BA, E + wv * 4 * 64, bqw, bsw, bow, a.dqkv[1], a.coef_q[1],
+                                            part + blk_part_off(4, gs, CW, CI, G), part + blk_part_off(5, gs, CW, CI, G),
+                                            part + blk_part_off(6, gs, CW, CI, G), grp, n0, a.training, wv, 13);
+    wave_layer_loads<CW, GP, false>(ldh, a.qkv[0], a.stk[0], a.lse[0], nullptr, n0, wv);
+    MEDT_SCHED_FENCE();
+    wave_dgrad1x1<CA, 2 * CW, CW, PK>(w_qw, wv * CA, BA, gio);          // width layer's qkv_transform dgrad
+    BLK_STAMP(17);
+    wave_attention_bwd<CW, GP, 0, false, PK>(ldh, gio, Q, D, S, BA, E + wv * 4 * 64, bqh, bsh, boh, a.dqkv[0], a.coef_q[0],
+                                             part + blk_part_off(1, gs, CW, CI, G), part + blk_part_off(2, gs, CW, CI, G),
+                                             part + blk_part_off(3, gs, CW, CI, G), grp, n0, a.training, wv, 18);
+    // bn1's reads in flight under the height layer's qkv_transform dgrad
+    float z1v[CA], y1v[CA];
+#pragma unroll
+    for (int k = 0; k < CA; ++k) { z1v[k] = a.z1[ew + k * HW]; y1v[k] = a.y1[ew + k * HW]; }
+    MEDT_SCHED_FENCE();
+    wave_dgrad1x1<CA, 2 * CW, CW, PK>(w_qh, wv * CA, BA, gio);          // height layer's qkv_transform dgrad
+    BLK_STAMP(22);
     // ---- bn1 backward behind the ReLU mask                                                        (:373-375)
     {
         float gm[CA], zz[CA], dz[CA];
 #pragma unroll
         for (int k = 0; k < CA; ++k) {
-            zz[k] = a.z1[ew + k * HW];
-            gm[k] = a.y1[ew + k * HW] > 0.f ? gio[k] : 0.f;
+            zz[k] = z1v[k];
+            gm[k] = y1v[k] > 0.f ? gio[k] : 0.f;
         }
         wave_bn_bwd<CA, PK>(gm, zz, bn1, grp, CW, wv * CA, part, nullptr, a.training, dz);
 #pragma unroll

@@ -74,8 +74,8 @@ for n, v in zip(BNAMES, best):
 # ---- ... and its one-launch backward (MEDT_BLOCK_BWD=1), stamps 10 .. 24 of the same array ----
 from medt_amd import block  # noqa: E402
 if block.BWD_ENABLED:
-    WN = ["loads, [mask,] bn_output backward, tiles", "softmax + bn_similarity backward", "dq | dk | dv", "bn_qkv backward + tile",
-          "projection dgrad"]
+    WN = ["[mask,] bn_output backward, tiles", "softmax + bn_similarity backward", "dq | dk | dv", "bn_qkv backward + tile",
+          "projection dgrad (next phase's global reads in flight)"]
     GNAMES = ["loads, mask, bn2 backward, tile", "conv_up dgrad"] + ["width: " + n for n in WN] + ["height: " + n for n in WN] + \
              ["bn1 backward + tile, identity gradient loaded", "conv_down dgrad + identity + deposit"]
     best = None
