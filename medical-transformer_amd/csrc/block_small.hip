@@ -437,6 +437,7 @@ static bool block_fused_enabled() {
 bool wopos_block_ok(const medt_block_desc& d) {
     if (!block_fused_enabled()) return false;
     if (d.N <= 0 || d.bn_groups <= 0 || d.N != 4 * d.bn_groups || d.H != 4 || d.W != 4 || d.G != 8) return false;
+    if (d.bn_groups > 4096) return false;            // (the backward kernel indexes its tensors with 32-bit element offsets)
     return d.C == 128 && d.width == 64;
 }
 
