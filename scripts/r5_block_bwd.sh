@@ -17,7 +17,7 @@ for rep in 1 2; do
   for v in "0 0" "0 1" "1 0" "1 1"; do
     set -- $v
     echo "== bench MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 (rep $rep)" >> $out
-    MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 timeout 600 python bench.py --steps 200 --warmup 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
+    MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 timeout 600 python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d.get('launches'))" >> $out
   done
 done
 echo "== per-kernel timing, all variants" >> $out
