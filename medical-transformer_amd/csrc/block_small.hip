@@ -67,11 +67,18 @@ __device__ __forceinline__ float blk_lane(float v, int k) {     // the value of 
 // for 4-8 useful lanes); running statistics in eval mode.  The (sum, sum of squares) pair the recorded finalisation
 // (saved statistics, running-stat recurrence: bn_finalize, pointwise.hip) reads is written in double, exactly as the
 // per-stage kernels do (centered_to_raw).
+template <bool FAST = false>
 __device__ __forceinline__ void blk_scale_shift(float s, float m2, float n, const float* prm, float eps, int training,
                                                 float& scale, float& shift) {
     const float g = prm[0], b = prm[1];
     float mean, rstd;
-    if (training) {
+    if (FAST) {
+        // second-generation instantiations: v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the IEEE division and square-root sequences
+        // (~10 instructions each, 13 of them per wave)
+        const float inv_n = __builtin_amdgcn_rcpf(n);
+        mean = training ? s * inv_n : prm[2];
+        rstd = __builtin_amdgcn_rsqf((training ? m2 * inv_n : prm[3]) + eps);
+    } else if (training) {
         mean = s / n;
         rstd = 1.f / sqrtf(m2 / n + eps);
     } else {
@@ -144,7 +151,7 @@ __device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, d
 #pragma unroll
         for (int j = 0; j < K / 4; ++j) {
             const int ch = ch0 + blk_multi_chan(lane, j);
-            blk_scale_shift(s[j], m2[j], 64.f, prm + ch * 4, eps, training, scale[j], shift[j]);
+            blk_scale_shift<true>(s[j], m2[j], 64.f, prm + ch * 4, eps, training, scale[j], shift[j]);
             if (training && (lane & 15) == 0) {
                 double sd, ssd;
                 centered_to_raw(s[j], m2[j], s[j] * (1.f / 64.f), 64.0, sd, ssd);
@@ -276,7 +283,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
             m2 = blk_wave_sum(v1);
         }
         float scale, shift;
-        blk_scale_shift(s1, m2, 64.f * L, prm_s + g * 4, eps, training, scale, shift);
+        blk_scale_shift<PK>(s1, m2, 64.f * L, prm_s + g * 4, eps, training, scale, shift);
         if (training && hf == 0 && lane == 0) {
             double sd, ssd;
             centered_to_raw(s1, m2, s1 * (1.f / (64.f * L)), 64.0 * L, sd, ssd);
@@ -299,7 +306,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
         for (int c = 0; c < HV; ++c) acc[c] = fmaf(pj, Qh[(GP + hf * HV + c) * 64 + base + j * sj], acc[c]);
     }
     BLK_STAMP(stamp0 + 1);                             // logits, bn_similarity, softmax, P.V
-    const float inv = 1.f / l;
+    const float inv = PK ? __builtin_amdgcn_rcpf(l) : 1.f / l;
     float o[HV], sc[HV], sh[HV];
 #pragma unroll
     for (int c = 0; c < HV; ++c) {

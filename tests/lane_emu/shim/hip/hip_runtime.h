@@ -109,6 +109,7 @@ static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 #define __fdividef(a, b) ((a) / (b))
 #define __frcp_rn(x) (1.f / (x))
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.f / sqrtf(x); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // ---- synchronisation -------------------------------------------------------------------------------------------------------
