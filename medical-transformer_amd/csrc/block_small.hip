@@ -61,6 +61,12 @@ __device__ __forceinline__ float blk_lane(float v, int k) {     // the value of 
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
 }
 
+// Element offsets into the block's tensors: 64-bit in the first-generation instantiations (kept bit for bit: their device code is
+// the GPU-verified one), 32-bit in the second generation (one address register per tensor shape, the channel steps fold into the
+// instructions' immediate offsets; wopos_block_ok bounds the tensors far below 2^32 elements).
+template <bool V2> struct BlkIdx { typedef size_t type; };
+template <> struct BlkIdx<true> { typedef unsigned type; };
+
 // scale / shift of one BatchNorm channel from its centred sums (s = sum x, m2 = sum (x - s/n)^2, both float32: the values
 // were in registers for a second pass about the mean, so the variance is m2 / n without cancellation and needs no
 // double-precision division / square root -- ~100 f64 instructions per call that every one of the 16 waves would execute
@@ -247,7 +253,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
         float acc[CB], sc[CB], sh[CB];
         wave_conv1x1<CB, CW, PK>(w_qkv, wv * CB, A, acc);
 #pragma unroll
-        for (int k = 0; k < CB; ++k) qkv_raw[((size_t)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = acc[k];
+        for (int k = 0; k < CB; ++k) qkv_raw[((typename BlkIdx<PK>::type)(n0 + ni) * 2 * CW + wv * CB + k) * HW + p] = acc[k];
         wave_bn<CB, PK>(acc, prm_q, part_q, wv * CB, training, eps, sc, sh);
 #pragma unroll
         for (int k = 0; k < CB; ++k) Q[(wv * CB + k) * 64 + lane] = fmaf(acc[k], sc[k], sh[k]);
@@ -311,9 +317,9 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
 #pragma unroll
     for (int c = 0; c < HV; ++c) {
         o[c] = acc[c] * inv;
-        stacked[((size_t)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = o[c];
+        stacked[((typename BlkIdx<PK>::type)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = o[c];
     }
-    if (hf == 0) lse[((size_t)(n0 + ni) * G + g) * HW + p] = m + __log2f(l);
+    if (hf == 0) lse[((typename BlkIdx<PK>::type)(n0 + ni) * G + g) * HW + p] = m + __log2f(l);
     // 3. bn_output (+ the block's ReLU behind the width layer)                                 (:242, :381-383)
     wave_bn<HV, PK>(o, prm_o, part_o, g * GP + hf * HV, training, eps, sc, sh);
 #pragma unroll
@@ -321,7 +327,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
         float v = fmaf(o[c], sc[c], sh[c]);
         if (RELU) v = fmaxf(v, 0.f);
         A[(g * GP + hf * HV + c) * 64 + lane] = v;
-        y[((size_t)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = v;
+        y[((typename BlkIdx<PK>::type)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = v;
     }
     MEDT_LDS_BARRIER();                                   // the layer's output tile in A; Q is free
     BLK_STAMP(stamp0 + 2);                             // bn_output + tile
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < NX4; ++k) {
             const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4);
-            xv[k] = *reinterpret_cast<const float4*>(x + ((size_t)(n0 + img) * CI) * HW + (size_t)rem * 4);
+            xv[k] = *reinterpret_cast<const float4*>(x + ((typename BlkIdx<PK>::type)(n0 + img) * CI) * HW + (typename BlkIdx<PK>::type)rem * 4);
         }
         float pv[4] = {0.f, 0.f, 0.f, 1.f};
         int pdst = -1;
@@ -390,13 +396,13 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
         float acc[CA], sc[CA], sh[CA];
         wave_conv1x1<CA, CI, PK>(w_down, wv * CA, X, acc);
 #pragma unroll
-        for (int k = 0; k < CA; ++k) a.z1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
+        for (int k = 0; k < CA; ++k) a.z1[((typename BlkIdx<PK>::type)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
         wave_bn<CA, PK>(acc, prm + poff[0], a.part[0] ? a.part[0] + (size_t)grp * CW * 2 : nullptr, wv * CA, a.training, a.eps, sc, sh);
 #pragma unroll
         for (int k = 0; k < CA; ++k) {
             const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]), 0.f);
             A[(wv * CA + k) * 64 + lane] = v;
-            a.y1[((size_t)(n0 + ni) * CW + wv * CA + k) * HW + p] = v;
+            a.y1[((typename BlkIdx<PK>::type)(n0 + ni) * CW + wv * CA + k) * HW + p] = v;
         }
     }
     MEDT_LDS_BARRIER();
@@ -413,12 +419,12 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
         float acc[CF], sc[CF], sh[CF];
         wave_conv1x1<CF, CW, PK>(w_up, wv * CF, A, acc);
 #pragma unroll
-        for (int k = 0; k < CF; ++k) a.z2[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = acc[k];
+        for (int k = 0; k < CF; ++k) a.z2[((typename BlkIdx<PK>::type)(n0 + ni) * CI + wv * CF + k) * HW + p] = acc[k];
         wave_bn<CF, PK>(acc, prm + poff[7], a.part[7] + (size_t)grp * CI * 2, wv * CF, a.training, a.eps, sc, sh);
 #pragma unroll
         for (int k = 0; k < CF; ++k) {
             const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]) + X[(wv * CF + k) * 64 + lane], 0.f);
-            a.y[((size_t)(n0 + ni) * CI + wv * CF + k) * HW + p] = v;
+            a.y[((typename BlkIdx<PK>::type)(n0 + ni) * CI + wv * CF + k) * HW + p] = v;
         }
     }
     BLK_STAMP(9);                                       // conv_up + bn2 + identity + ReLU
