@@ -436,6 +436,292 @@ int& block_pk_mode() {
     return mode;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------ //
+// The same block on 8x8 MAPS (layer2_p.1 of MedT at 128 px: 64 -> 32 -> 64 channels, 4 images per patch group = 256 positions),
+// end of round 4: compiled, verified on the CPU lane emulator, NOT yet run on the GPU -- opt-in, MEDT_BLOCK8=1.
+// A wave = ONE IMAGE's 64 positions (lane = position) x a quarter of the output channels, so a 1x1 contraction only ever reads
+// its own image's columns of the tile and a wave's attention needs nothing but the q | k | v rows it has just produced (two heads
+// per wave).  What crosses waves is (a) each BatchNorm's statistics -- every wave reduces its image in registers (transposed
+// multi-sums, centred about its own mean), the four partials per channel meet in LDS behind one barrier and are merged with the
+// pairwise-update formula (no cancellation, no double precision) -- and (b) the activation tile between the stages.
+// Twelve barriers; the per-wave arithmetic is that of the 4x4 kernel (the contractions are the same 2.1 MMAC per group).
+// ------------------------------------------------------------------------------------------------------------------------ //
+// out[k] = sum_c w[(row0 + k) * CIN + c] * T[c * 256 + lane], T = the tile's columns of this wave's image
+template <int K, int CIN>
+__device__ __forceinline__ void wave8_conv1x1(const float* __restrict__ w, int row0, const float* T, float (&acc)[K]) {
+    const int lane = threadIdx.x & 63;
+    const float* wr = w + row0 * CIN;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < CIN; ++c) {
+        const float t = T[c * 256 + lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(wr[k * CIN + c], t, acc[k]);
+    }
+}
+
+// BatchNorm of this wave's K channels (ch0 ..) over the GROUP (its image's 64 values per channel are in v[k]; the other three
+// images' in the sibling waves): partial (sum, centred sum of squares) per image -> R[ch][4][2] -> barrier -> merge.
+// Every wave of the workgroup calls this at the same point (it contains a workgroup barrier).
+template <int K>
+__device__ __forceinline__ void blk8_bn(const float (&v)[K], float* R, const float* prm, double* part, int ch0, int img,
+                                        int training, float eps, float (&sc)[K], float (&sh)[K]) {
+    const int lane = threadIdx.x & 63;
+    if (training) {
+        float s[K / 4], m2[K / 4], d2[K];
+        blk_multi_sum<K>(v, s);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = v[k] - blk_multi_get<K>(s, k) * (1.f / 64.f);
+            d2[k] = d * d;
+        }
+        blk_multi_sum<K>(d2, m2);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < K / 4; ++j) {
+                float* r = R + ((ch0 + blk_multi_chan(lane, j)) * 4 + img) * 2;
+                r[0] = s[j];
+                r[1] = m2[j];
+            }
+        }
+    }
+    MEDT_LDS_BARRIER();
+    float my_s = 0.f, my_m2 = 0.f;
+    const int ch = ch0 + min(lane, K - 1);
+    if (training) {
+        const float* r = R + ch * 8;
+        my_s = (r[0] + r[2]) + (r[4] + r[6]);
+        const float mean = my_s * (1.f / 256.f);
+        my_m2 = (r[1] + r[3]) + (r[5] + r[7]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dm = r[2 * i] * (1.f / 64.f) - mean;             // merging (n, mean, M2) records: M2 += n_i (mean_i - mean)^2
+            my_m2 = fmaf(64.f * dm, dm, my_m2);
+        }
+    }
+    float scale, shift;
+    blk_scale_shift(my_s, my_m2, 256.f, prm + ch * 4, eps, training, scale, shift);
+    if (training && img == 0 && lane < K) {
+        double sd, ssd;
+        centered_to_raw(my_s, my_m2, my_s * (1.f / 256.f), 256.0, sd, ssd);
+        part[(size_t)(ch0 + lane) * 2] = sd;
+        part[(size_t)(ch0 + lane) * 2 + 1] = ssd;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        sc[k] = blk_lane(scale, k);
+        sh[k] = blk_lane(shift, k);
+    }
+}
+
+// One AxialAttention_wopos layer: A (tile, CW x 256) -> A in place, through this wave's rows / columns of Q (2CW x 256).
+template <int CW, int GP, int AXIS, bool RELU>
+__device__ __forceinline__ void wave8_attention(const float* __restrict__ w_qkv, float* A, float* Q, float* Rq, float* Rs, float* Ro,
+                                                const float* prm_q, const float* prm_s, const float* prm_o, double* part_q,
+                                                double* part_s, double* part_o, float* qkv_raw, float* stacked, float* lse, float* y,
+                                                int n, int img, int sl, int training, float eps) {
+    constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 8, KQ = 2 * CW / 4, KO = CW / 4;
+    static_assert(KQ == 2 * NCH && KO == 2 * GP, "two heads per wave");
+    const int lane = threadIdx.x & 63;
+    // 1. qkv_transform rows sl * KQ .. of this image, bn_qkv                                           (axialnet.py:228)
+    {
+        float acc[KQ], sc[KQ], sh[KQ];
+        wave8_conv1x1<KQ, CW>(w_qkv, sl * KQ, A + img * 64, acc);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) qkv_raw[((size_t)n * 2 * CW + sl * KQ + k) * 64 + lane] = acc[k];
+        blk8_bn<KQ>(acc, Rq, prm_q, part_q, sl * KQ, img, training, eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) Q[(sl * KQ + k) * 256 + img * 64 + lane] = fmaf(acc[k], sc[k], sh[k]);
+    }
+    MEDT_WAVE_LOCKSTEP();                                  // these rows x columns of Q are read by this wave only
+    // 2. logits of this lane's row for the wave's two heads, bn_similarity over the group            (:232-236)
+    const int i = AXIS == 1 ? (lane & 7) : (lane >> 3), sj = AXIS == 1 ? 1 : 8, base = lane - i * sj;
+    float z[2][L];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const float* Qh = Q + (sl * KQ + hh * NCH) * 256 + img * 64;
+        float qv[HQ], v0 = 0.f;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 256 + lane];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float qk = 0.f;
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) qk = fmaf(qv[c], Qh[(HQ + c) * 256 + base + j * sj], qk);
+            z[hh][j] = qk;
+            v0 += qk;
+        }
+        if (training) {
+            const float s1 = blk_wave_sum(v0), mw = s1 * (1.f / (64.f * L));
+            float v1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < L; ++j) v1 = fmaf(z[hh][j] - mw, z[hh][j] - mw, v1);
+            const float m2 = blk_wave_sum(v1);
+            if (lane == 0) {
+                float* r = Rs + ((2 * sl + hh) * 4 + img) * 2;
+                r[0] = s1;
+                r[1] = m2;
+            }
+        }
+    }
+    MEDT_LDS_BARRIER();
+    float o2[KO];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int g = 2 * sl + hh;
+        const float* Qh = Q + (sl * KQ + hh * NCH) * 256 + img * 64;
+        float s1 = 0.f, m2 = 0.f;
+        if (training) {
+            const float* r = Rs + g * 8;
+            s1 = (r[0] + r[2]) + (r[4] + r[6]);
+            const float mean = s1 * (1.f / (256.f * L));
+            m2 = (r[1] + r[3]) + (r[5] + r[7]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dm = r[2 * q] * (1.f / (64.f * L)) - mean;
+                m2 = fmaf(64.f * L * dm, dm, m2);
+            }
+        }
+        float scale, shift;
+        blk_scale_shift(s1, m2, 256.f * L, prm_s + g * 4, eps, training, scale, shift);
+        if (training && img == 0 && lane == 0) {
+            double sd, ssd;
+            centered_to_raw(s1, m2, s1 * (1.f / (256.f * L)), 256.0 * L, sd, ssd);
+            part_s[(size_t)g * 2] = sd;
+            part_s[(size_t)g * 2 + 1] = ssd;
+        }
+        // 3. softmax (the shift is constant along a row), P.V                                         (:237-241)
+        const float a_qk = scale * MEDT_LOG2E;
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < L; ++j) { z[hh][j] *= a_qk; m = fmaxf(m, z[hh][j]); }
+        float l = 0.f, acc[GP];
+#pragma unroll
+        for (int c = 0; c < GP; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const float pj = __builtin_amdgcn_exp2f(z[hh][j] - m);
+            l += pj;
+#pragma unroll
+            for (int c = 0; c < GP; ++c) acc[c] = fmaf(pj, Qh[(GP + c) * 256 + base + j * sj], acc[c]);
+        }
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int c = 0; c < GP; ++c) {
+            o2[hh * GP + c] = acc[c] * inv;
+            stacked[((size_t)n * CW + g * GP + c) * 64 + lane] = o2[hh * GP + c];
+        }
+        lse[((size_t)n * G + g) * 64 + lane] = m + __log2f(l);
+    }
+    // 4. bn_output (+ the block's ReLU behind the width layer), tile                                  (:242, :381-383)
+    {
+        float sc[KO], sh[KO];
+        blk8_bn<KO>(o2, Ro, prm_o, part_o, sl * KO, img, training, eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < KO; ++k) {
+            float v = fmaf(o2[k], sc[k], sh[k]);
+            if (RELU) v = fmaxf(v, 0.f);
+            A[(sl * KO + k) * 256 + img * 64 + lane] = v;
+            y[((size_t)n * CW + sl * KO + k) * 64 + lane] = v;
+        }
+    }
+    MEDT_LDS_BARRIER();                                    // the layer's output tile
+}
+
+template <int CI, int CW, int GP>
+__global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
+                                                                const float* __restrict__ w_qh, const float* __restrict__ w_qw,
+                                                                const float* __restrict__ w_up, BlkArgs a) {
+    constexpr int G = CW / GP, KD = CW / 4, KU = CI / 4;
+    constexpr int CHS[8] = {CW, 2 * CW, G, CW, 2 * CW, G, CW, CI};
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A = smem;                                    // [CW][256]   the running activation tile (column = image * 64 + position)
+    float* Q = A + CW * 256;                            // [2CW][256]  normalised q | k | v of the current attention layer
+    float* prm = Q + 2 * CW * 256;                      // BatchNorm parameters, [CH][4] each
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = wv & 3, sl = wv >> 2, n = grp * 4 + img;
+    int poff[8], roff[8], ptot = 0;
+    {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { poff[b] = ptot; ptot += CHS[b] * 4; }
+    }
+    float* R = prm + ptot;                              // per-image statistics records of the eight BatchNorms, [CH][4][2] each
+    {
+        int o = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { roff[b] = o; o += CHS[b] * 8; }
+    }
+    // BatchNorm parameters -> LDS
+    {
+        float pv[4] = {0.f, 0.f, 0.f, 1.f};
+        int pdst = -1, o = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (tid >= o && tid < o + CHS[b]) {
+                const int ch = tid - o;
+                pv[0] = a.bn[b].weight[ch];
+                pv[1] = a.bn[b].bias[ch];
+                if (!a.training) { pv[2] = a.bn[b].rmean[ch]; pv[3] = a.bn[b].rvar[ch]; }
+                pdst = poff[b] + ch * 4;
+            }
+            o += CHS[b];
+        }
+        if (pdst >= 0) { prm[pdst] = pv[0]; prm[pdst + 1] = pv[1]; prm[pdst + 2] = pv[2]; prm[pdst + 3] = pv[3]; }
+    }
+    // ---- conv_down straight from global memory (the four channel-quarter waves of an image read the same rows: L2) + bn1 + ReLU
+    {
+        float acc[KD], sc[KD], sh[KD];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) acc[k] = 0.f;
+        const float* xi = x + (size_t)n * CI * 64 + lane;
+        const float* wr = w_down + sl * KD * CI;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CI; c0 += 16) {
+            float xr[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) xr[u] = xi[(c0 + u) * 64];
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int k = 0; k < KD; ++k) acc[k] = fmaf(wr[k * CI + c0 + u], xr[u], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KD; ++k) a.z1[((size_t)n * CW + sl * KD + k) * 64 + lane] = acc[k];
+        MEDT_LDS_BARRIER();                             // (the parameter table)
+        blk8_bn<KD>(acc, R + roff[0], prm + poff[0], a.part[0] + (size_t)grp * CW * 2, sl * KD, img, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]), 0.f);
+            A[(sl * KD + k) * 256 + img * 64 + lane] = v;
+            a.y1[((size_t)n * CW + sl * KD + k) * 64 + lane] = v;
+        }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- height layer, width layer (+ ReLU)
+    wave8_attention<CW, GP, 0, false>(w_qh, A, Q, R + roff[1], R + roff[2], R + roff[3], prm + poff[1], prm + poff[2], prm + poff[3],
+                                      a.part[1] + (size_t)grp * 2 * CW * 2, a.part[2] + (size_t)grp * G * 2,
+                                      a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h, a.y_h, n, img, sl, a.training, a.eps);
+    wave8_attention<CW, GP, 1, true>(w_qw, A, Q, R + roff[4], R + roff[5], R + roff[6], prm + poff[4], prm + poff[5], prm + poff[6],
+                                     a.part[4] + (size_t)grp * 2 * CW * 2, a.part[5] + (size_t)grp * G * 2,
+                                     a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w, a.y_w, n, img, sl, a.training, a.eps);
+    // ---- conv_up + bn2 + identity + ReLU
+    {
+        float acc[KU], sc[KU], sh[KU], idv[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) idv[k] = x[((size_t)n * CI + sl * KU + k) * 64 + lane];      // the identity, again from global
+        MEDT_SCHED_FENCE();
+        wave8_conv1x1<KU, CW>(w_up, sl * KU, A + img * 64, acc);
+#pragma unroll
+        for (int k = 0; k < KU; ++k) a.z2[((size_t)n * CI + sl * KU + k) * 64 + lane] = acc[k];
+        blk8_bn<KU>(acc, R + roff[7], prm + poff[7], a.part[7] + (size_t)grp * CI * 2, sl * KU, img, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < KU; ++k) a.y[((size_t)n * CI + sl * KU + k) * 64 + lane] = fmaxf(fmaf(acc[k], sc[k], sh[k]) + idv[k], 0.f);
+    }
+}
+
 static bool block_fused_enabled() {
     static const bool on = [] {
         const char* e = getenv("MEDT_BLOCK_FUSED");
@@ -445,14 +731,24 @@ static bool block_fused_enabled() {
     return on;
 }
 
-// Shapes the fused kernel is built for: 4-image BatchNorm groups on 4x4 maps (64 positions = one wave), 8 heads,
-// (C, width) = (128, 64) -- layer3_p.1-3 of MedT at 128 px, BASELINE.json's batch size.
-bool wopos_block_ok(const medt_block_desc& d) {
-    if (!block_fused_enabled()) return false;
-    if (d.N <= 0 || d.bn_groups <= 0 || d.N != 4 * d.bn_groups || d.H != 4 || d.W != 4 || d.G != 8) return false;
-    if (d.bn_groups > 4096) return false;            // (the backward kernel indexes its tensors with 32-bit element offsets)
-    return d.C == 128 && d.width == 64;
+// MEDT_BLOCK8=1: the 8x8-map kernel (off until measured; tests/lane_emu sets it directly)
+int& block8_mode() {
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK8"); return (e && e[0] == '1') ? 1 : 0; }();
+    return mode;
 }
+
+// Shapes the fused kernels are built for: 4-image BatchNorm groups, 8 heads, and
+//   1: 4x4 maps, (C, width) = (128, 64) -- layer3_p.1-3 of MedT at 128 px, BASELINE.json's batch size (forward and backward)
+//   2: 8x8 maps, (C, width) = (64, 32)  -- layer2_p.1 (forward only, MEDT_BLOCK8=1)
+static int wopos_block_shape(const medt_block_desc& d) {
+    if (!block_fused_enabled()) return 0;
+    if (d.N <= 0 || d.bn_groups <= 0 || d.N != 4 * d.bn_groups || d.G != 8) return 0;
+    if (d.bn_groups > 4096) return 0;                // (the backward kernel indexes its tensors with 32-bit element offsets)
+    if (d.H == 4 && d.W == 4 && d.C == 128 && d.width == 64) return 1;
+    if (d.H == 8 && d.W == 8 && d.C == 64 && d.width == 32 && block8_mode()) return 2;
+    return 0;
+}
+bool wopos_block_ok(const medt_block_desc& d) { return wopos_block_shape(d) != 0; }
 
 size_t wopos_block_part_doubles(const medt_block_desc& d) {
     return (size_t)d.bn_groups * 2 * (d.width + 2 * (2 * d.width + d.G + d.width) + d.C);
@@ -479,6 +775,18 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
     a.eps = d.eps;
     size_t nprm = 0;
     for (int b = 0; b < 8; ++b) nprm += (size_t)chs[b] * 4;
+    if (wopos_block_shape(d) == 2) {                // 8x8 maps: tile + q|k|v tile + parameters + per-image statistics records
+        const size_t lds8 = ((size_t)3 * d.width * 256 + nprm + 2 * nprm) * sizeof(float);
+        static bool attr8 = false;
+        if (!attr8) {
+            (void)hipFuncSetAttribute((const void*)wopos_block8_fwd_kernel<64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr8 = true;
+        }
+        hipLaunchKernelGGL((wopos_block8_fwd_kernel<64, 32, 4>), dim3(d.bn_groups), dim3(1024), lds8, s, x, p.w_down,
+                           p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+        return launch_status("wopos_block8_fwd");
+    }
     const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
     static bool attr = false;
     if (!attr) {                    // more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU)
@@ -901,7 +1209,7 @@ int& block_bwd_mode() {
     return mode;
 }
 static bool block_bwd_enabled() { return block_bwd_mode() != 0; }
-bool wopos_block_bwd_ok(const medt_block_desc& d) { return block_bwd_enabled() && wopos_block_ok(d); }
+bool wopos_block_bwd_ok(const medt_block_desc& d) { return block_bwd_enabled() && wopos_block_shape(d) == 1; }
 
 size_t wopos_block_bwd_ws_bytes(const medt_block_desc& d) {
     Carver c(nullptr, 0);

@@ -176,6 +176,12 @@ def block_forward(blk, x, bn_groups: int, sink):
     """The block as ONE autograd node (one-launch forward and backward), or None when that path is not taken."""
     if not BWD_ENABLED or not torch.is_grad_enabled():
         return None
+    # (the one-launch backward exists for fewer shapes than the forward: ask before committing this block to the one-node path)
+    N, Cc, H, W = x.shape
+    desc = L.BlockDesc(N, Cc, blk.conv_down.weight.shape[0], H, W, blk.hight_block.groups, int(blk.bn1.training), bn_groups,
+                       blk.bn1.eps, float(blk.bn1.momentum if blk.bn1.momentum is not None else 0.1))
+    if L.lib().medt_wopos_block_bwd_workspace_bytes(C.byref(desc)) == 0:
+        return None
     pre = fused_forward(blk, x, bn_groups)
     if pre is None:
         return None

@@ -13,7 +13,13 @@ echo "== smoke, MEDT_BLOCK_BWD=1" >> $out
 MEDT_BLOCK_BWD=1 timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -4 >> $out
 echo "== parity, MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (second-generation instantiations of both block kernels: packed FMAs + transposed wave reductions)" >> $out
 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -5 >> $out
+echo "== parity, MEDT_BLOCK8=1 (8x8-map block forward)" >> $out
+MEDT_BLOCK8=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py -m gpu -x -q -k "block8 or test_model_vs_reference_fixture" 2>&1 | tail -5 >> $out
 for rep in 1 2; do
+  echo "== bench MEDT_BLOCK8=1 alone (rep $rep)" >> $out
+  MEDT_BLOCK8=1 timeout 600 python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" >> $out
+  echo "== bench everything on: MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (rep $rep)" >> $out
+  MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 timeout 600 python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" >> $out
   for v in "0 0" "0 1" "1 0" "1 1"; do
     set -- $v
     echo "== bench MEDT_BLOCK_BWD=$1 MEDT_BLOCK_PK=$2 (rep $rep)" >> $out

@@ -24,3 +24,4 @@ extern "C" size_t emu_wopos_block_bwd_part_floats(const medt_block_desc* d) {
 }
 extern "C" void emu_set_block_pk(int on) { medt::block_pk_mode() = on ? 1 : 0; }
 extern "C" void emu_set_block_bwd(int on) { medt::block_bwd_mode() = on ? 1 : 0; }
+extern "C" void emu_set_block8(int on) { medt::block8_mode() = on ? 1 : 0; }

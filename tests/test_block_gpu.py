@@ -193,3 +193,47 @@ def test_block_backward_is_one_launch_and_takes_the_deposit(device):
     (y * dout).sum().backward()
     torch.cuda.synchronize()
     assert H.rel_err(x.grad, dx_plain + extra) < 1e-6
+
+
+# ---- the 8x8-map block kernel (layer2_p.1 of MedT-128), opt-in like the one-launch backward: MEDT_BLOCK8=1 for the whole process
+block8_opt_in = pytest.mark.skipif(__import__("os").environ.get("MEDT_BLOCK8", "0") != "1",
+                                   reason="8x8-map one-launch block forward is opt-in: MEDT_BLOCK8=1")
+
+
+@block8_opt_in
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_block8_fused_equals_stagewise(training, device):
+    """wopos_block8_fwd_kernel (a wave = one image x a quarter of the channels; BatchNorm statistics merged across the four
+    image-waves) against the four per-stage launches on layer2_p.1's shape; verified on the CPU lane emulator against the oracle
+    (tests/test_lane_emu.py::test_block8_forward_kernel_on_the_emulator)."""
+    import lib as droplib
+    from medt_amd import _lib, block
+    import ctypes
+    d = _lib.BlockDesc(64, 64, 32, 8, 8, 8, int(training), 16, 1e-5, 0.1)
+    assert _lib.lib().medt_wopos_block_workspace_bytes(ctypes.byref(d)) > 0
+    torch.manual_seed(6)
+    blk = droplib.models.axialnet.AxialBlock_wopos(64, 32, groups=8, base_width=64, kernel_size=8)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    blk = blk.to(device)
+    x = torch.randn(64, 64, 8, 8, device=device).relu_()
+    dout = torch.randn(64, 64, 8, 8, device=device)
+    y0, dx0, g0, b0 = run(blk, x, dout, False, training)
+    y1, dx1, g1, b1 = run(blk, x, dout, True, training)
+    assert H.rel_err(y1, y0) < 2e-5, H.rel_err(y1, y0)
+    assert H.rel_err(dx1, dx0) < 2e-4, H.rel_err(dx1, dx0)
+    assert g0.keys() == g1.keys() and len(g0) == 20
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err < 5e-4 * max(g0[k].abs().max().item(), 1e-3 * gmax), (k, err)
+    for k in b0:
+        if "num_batches" in k:
+            assert int(b0[k]) == int(b1[k])
+        else:
+            assert H.rel_err(b1[k], b0[k]) < 1e-5, k
