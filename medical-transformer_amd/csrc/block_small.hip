@@ -447,10 +447,24 @@ int& block_pk_mode() {
 // Twelve barriers; the per-wave arithmetic is that of the 4x4 kernel (the contractions are the same 2.1 MMAC per group).
 // ------------------------------------------------------------------------------------------------------------------------ //
 // out[k] = sum_c w[(row0 + k) * CIN + c] * T[c * 256 + lane], T = the tile's columns of this wave's image
-template <int K, int CIN>
+template <int K, int CIN, bool PK = false>
 __device__ __forceinline__ void wave8_conv1x1(const float* __restrict__ w, int row0, const float* T, float (&acc)[K]) {
     const int lane = threadIdx.x & 63;
     const float* wr = w + row0 * CIN;
+    if (PK) {                                            // packed FMAs: even / odd input channels in the two halves (wave_conv1x1)
+        blk_v2f a2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a2[k] = blk_v2f{0.f, 0.f};
+#pragma unroll 2
+        for (int c = 0; c < CIN; c += 2) {
+            const blk_v2f t2 = {T[c * 256 + lane], T[(c + 1) * 256 + lane]};
+#pragma unroll
+            for (int k = 0; k < K; ++k) a2[k] = blk_pk_fma(blk_v2f{wr[k * CIN + c], wr[k * CIN + c + 1]}, t2, a2[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = a2[k].x + a2[k].y;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
 #pragma unroll 4
@@ -516,7 +530,7 @@ __device__ __forceinline__ void blk8_bn(const float (&v)[K], float* R, const flo
 }
 
 // One AxialAttention_wopos layer: A (tile, CW x 256) -> A in place, through this wave's rows / columns of Q (2CW x 256).
-template <int CW, int GP, int AXIS, bool RELU>
+template <int CW, int GP, int AXIS, bool RELU, bool PK>
 __device__ __forceinline__ void wave8_attention(const float* __restrict__ w_qkv, float* A, float* Q, float* Rq, float* Rs, float* Ro,
                                                 const float* prm_q, const float* prm_s, const float* prm_o, double* part_q,
                                                 double* part_s, double* part_o, float* qkv_raw, float* stacked, float* lse, float* y,
@@ -527,7 +541,7 @@ __device__ __forceinline__ void wave8_attention(const float* __restrict__ w_qkv,
     // 1. qkv_transform rows sl * KQ .. of this image, bn_qkv                                           (axialnet.py:228)
     {
         float acc[KQ], sc[KQ], sh[KQ];
-        wave8_conv1x1<KQ, CW>(w_qkv, sl * KQ, A + img * 64, acc);
+        wave8_conv1x1<KQ, CW, PK>(w_qkv, sl * KQ, A + img * 64, acc);
 #pragma unroll
         for (int k = 0; k < KQ; ++k) qkv_raw[((size_t)n * 2 * CW + sl * KQ + k) * 64 + lane] = acc[k];
         blk8_bn<KQ>(acc, Rq, prm_q, part_q, sl * KQ, img, training, eps, sc, sh);
@@ -629,7 +643,7 @@ __device__ __forceinline__ void wave8_attention(const float* __restrict__ w_qkv,
     MEDT_LDS_BARRIER();                                    // the layer's output tile
 }
 
-template <int CI, int CW, int GP>
+template <int CI, int CW, int GP, bool PK>
 __global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
                                                                 const float* __restrict__ w_qh, const float* __restrict__ w_qw,
                                                                 const float* __restrict__ w_up, BlkArgs a) {
@@ -673,8 +687,9 @@ __global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __r
     // ---- conv_down straight from global memory (the four channel-quarter waves of an image read the same rows: L2) + bn1 + ReLU
     {
         float acc[KD], sc[KD], sh[KD];
+        blk_v2f acc2[KD];
 #pragma unroll
-        for (int k = 0; k < KD; ++k) acc[k] = 0.f;
+        for (int k = 0; k < KD; ++k) { acc[k] = 0.f; acc2[k] = blk_v2f{0.f, 0.f}; }
         const float* xi = x + (size_t)n * CI * 64 + lane;
         const float* wr = w_down + sl * KD * CI;
 #pragma unroll 1
@@ -683,10 +698,22 @@ __global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __r
 #pragma unroll
             for (int u = 0; u < 16; ++u) xr[u] = xi[(c0 + u) * 64];
             MEDT_SCHED_FENCE();
+            if (PK) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 16; u += 2)
 #pragma unroll
-                for (int k = 0; k < KD; ++k) acc[k] = fmaf(wr[k * CI + c0 + u], xr[u], acc[k]);
+                    for (int k = 0; k < KD; ++k)
+                        acc2[k] = blk_pk_fma(blk_v2f{wr[k * CI + c0 + u], wr[k * CI + c0 + u + 1]}, blk_v2f{xr[u], xr[u + 1]}, acc2[k]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) acc[k] = fmaf(wr[k * CI + c0 + u], xr[u], acc[k]);
+            }
+        }
+        if (PK) {
+#pragma unroll
+            for (int k = 0; k < KD; ++k) acc[k] = acc2[k].x + acc2[k].y;
         }
 #pragma unroll
         for (int k = 0; k < KD; ++k) a.z1[((size_t)n * CW + sl * KD + k) * 64 + lane] = acc[k];
@@ -701,10 +728,10 @@ __global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __r
     }
     MEDT_LDS_BARRIER();
     // ---- height layer, width layer (+ ReLU)
-    wave8_attention<CW, GP, 0, false>(w_qh, A, Q, R + roff[1], R + roff[2], R + roff[3], prm + poff[1], prm + poff[2], prm + poff[3],
+    wave8_attention<CW, GP, 0, false, PK>(w_qh, A, Q, R + roff[1], R + roff[2], R + roff[3], prm + poff[1], prm + poff[2], prm + poff[3],
                                       a.part[1] + (size_t)grp * 2 * CW * 2, a.part[2] + (size_t)grp * G * 2,
                                       a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h, a.y_h, n, img, sl, a.training, a.eps);
-    wave8_attention<CW, GP, 1, true>(w_qw, A, Q, R + roff[4], R + roff[5], R + roff[6], prm + poff[4], prm + poff[5], prm + poff[6],
+    wave8_attention<CW, GP, 1, true, PK>(w_qw, A, Q, R + roff[4], R + roff[5], R + roff[6], prm + poff[4], prm + poff[5], prm + poff[6],
                                      a.part[4] + (size_t)grp * 2 * CW * 2, a.part[5] + (size_t)grp * G * 2,
                                      a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w, a.y_w, n, img, sl, a.training, a.eps);
     // ---- conv_up + bn2 + identity + ReLU
@@ -713,7 +740,7 @@ __global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < KU; ++k) idv[k] = x[((size_t)n * CI + sl * KU + k) * 64 + lane];      // the identity, again from global
         MEDT_SCHED_FENCE();
-        wave8_conv1x1<KU, CW>(w_up, sl * KU, A + img * 64, acc);
+        wave8_conv1x1<KU, CW, PK>(w_up, sl * KU, A + img * 64, acc);
 #pragma unroll
         for (int k = 0; k < KU; ++k) a.z2[((size_t)n * CI + sl * KU + k) * 64 + lane] = acc[k];
         blk8_bn<KU>(acc, R + roff[7], prm + poff[7], a.part[7] + (size_t)grp * CI * 2, sl * KU, img, a.training, a.eps, sc, sh);
@@ -779,12 +806,18 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
         const size_t lds8 = ((size_t)3 * d.width * 256 + nprm + 2 * nprm) * sizeof(float);
         static bool attr8 = false;
         if (!attr8) {
-            (void)hipFuncSetAttribute((const void*)wopos_block8_fwd_kernel<64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute((const void*)wopos_block8_fwd_kernel<64, 32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wopos_block8_fwd_kernel<64, 32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
             attr8 = true;
         }
-        hipLaunchKernelGGL((wopos_block8_fwd_kernel<64, 32, 4>), dim3(d.bn_groups), dim3(1024), lds8, s, x, p.w_down,
-                           p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+        if (block_pk_mode())
+            hipLaunchKernelGGL((wopos_block8_fwd_kernel<64, 32, 4, true>), dim3(d.bn_groups), dim3(1024), lds8, s, x, p.w_down,
+                               p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+        else
+            hipLaunchKernelGGL((wopos_block8_fwd_kernel<64, 32, 4, false>), dim3(d.bn_groups), dim3(1024), lds8, s, x, p.w_down,
+                               p.height.w_qkv, p.width.w_qkv, p.w_up, a);
         return launch_status("wopos_block8_fwd");
     }
     const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
