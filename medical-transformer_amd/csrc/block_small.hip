@@ -1214,6 +1214,324 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
     BLK_STAMP(24);                                      // conv_down dgrad + identity + deposit
 }
 
+// ------------------------------------------------------------------------------------------------------------------------ //
+// BACKWARD of the 8x8-map block in one workgroup per patch group (MEDT_BLOCK8=1 + MEDT_BLOCK_BWD=1; emulator-verified, unmeasured).
+// The forward's mapping -- a wave = one image x a quarter of the channels -- keeps the whole attention backward of a wave's two
+// heads inside the wave (its own q | k | v rows, its own d(sv) rows, strips of its own for the transposed accesses); what crosses
+// waves is each BatchNorm backward's two sums (four per-image records per channel, merged behind one barrier) and the gradient
+// tiles in front of the four 1x1 backward-data contractions.  Twelve barriers.
+// LDS: T [64][256] (dz2, then d(sv) [32][256] + the waves' strips, then the gradient tiles behind bn_qkv / bn1), Q [64][256]
+// (normalised q | k | v), the records.  A tile is only ever written behind the barrier that follows its last readers' phase.
+// ------------------------------------------------------------------------------------------------------------------------ //
+// The two sums of a BatchNorm backward over the GROUP for this wave's K channels: g and g * xhat of its image -> per-image records
+// R[ch][4][2] -> barrier -> totals, wave-uniform.  Every wave calls this at the same point (workgroup barrier inside).
+template <int K>
+__device__ __forceinline__ void blk8_bwd_sums(const float (&g)[K], const float (&xh)[K], float* R, int ch0, int img,
+                                              float& t1, float& t2) {      // totals of channel ch0 + k in lane k
+    const int lane = threadIdx.x & 63;
+    float val[2 * K], w[2 * K / 4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { val[k] = g[k]; val[K + k] = g[k] * xh[k]; }
+    blk_multi_sum<2 * K>(val, w);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * K / 4; ++j) {
+            const int v = blk_multi_chan(lane, j);                       // value index 0 .. 2K-1: [sum g | sum g xhat]
+            R[((ch0 + (v < K ? v : v - K)) * 4 + img) * 2 + (v < K ? 0 : 1)] = w[j];
+        }
+    }
+    MEDT_LDS_BARRIER();
+    const float* r = R + (ch0 + min(lane, K - 1)) * 8;
+    t1 = (r[0] + r[2]) + (r[4] + r[6]);
+    t2 = (r[1] + r[3]) + (r[5] + r[7]);
+}
+
+// BatchNorm backward of this wave's K channels over the group: dz = A (g - m1 - xhat m2) | A g (eval); the partial row
+// [sum g, sum g xhat] and (optional) the coefficients c0, c1, c2 are written by the image-0 wave of the channel quarter.
+template <int K>
+__device__ __forceinline__ void blk8_bn_bwd(const float (&g)[K], const float (&xr)[K], const BlkBnB& bn, int grp, int CH, int ch0,
+                                            int img, float* R, float* part, float* coef, int training, float (&dz)[K]) {
+    const int lane = threadIdx.x & 63;
+    float xh[K], t1, t2;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        xh[k] = (xr[k] - blk_ldu(bn.st + grp * CH + ch0 + k)) * blk_ldu(bn.st + bn.n + grp * CH + ch0 + k);
+    blk8_bwd_sums<K>(g, xh, R, ch0, img, t1, t2);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {                          // one channel's wave-uniform scalars at a time (SGPR budget)
+        const float mean = blk_ldu(bn.st + grp * CH + ch0 + k), rstd = blk_ldu(bn.st + bn.n + grp * CH + ch0 + k);
+        const float A = blk_ldu(bn.gamma + ch0 + k) * rstd;
+        const float m1 = training ? blk_lane(t1, k) * (1.f / 256.f) : 0.f, m2 = training ? blk_lane(t2, k) * (1.f / 256.f) : 0.f;
+        dz[k] = A * (g[k] - m1 - xh[k] * m2);
+        if (lane == k) { c0 = A; c1 = -A * rstd * m2; c2 = A * (rstd * mean * m2 - m1); }
+        MEDT_SCHED_FENCE();
+    }
+    if (img == 0 && lane < K) {
+        part[(unsigned)(grp * CH + ch0 + lane) * 2] = t1;
+        part[(unsigned)(grp * CH + ch0 + lane) * 2 + 1] = t2;
+        if (coef) {
+            float* cf = coef + (unsigned)(grp * CH + ch0 + lane) * 3;
+            cf[0] = c0; cf[1] = c1; cf[2] = c2;
+        }
+    }
+}
+
+// out[k] = sum_o w[o * CIN + col0 + k] * T[o * 256 + lane], T = the gradient tile's columns of this wave's image
+template <int K, int COUT, int CIN>
+__device__ __forceinline__ void wave8_dgrad1x1(const float* __restrict__ w, int col0, const float* T, float (&acc)[K]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll 4
+    for (int o = 0; o < COUT; ++o) {
+        const float t = T[o * 256 + lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(w[o * CIN + col0 + k], t, acc[k]);
+    }
+}
+
+// Backward of one attention layer up to the gradient tile behind bn_qkv's backward (T, all 2CW rows, published by the closing
+// barrier): gin = gradient at the layer's output, this wave's CW/4 channels of its image.
+template <int CW, int GP, int AXIS, bool RELU>
+__device__ __forceinline__ void wave8_attention_bwd(const float (&gin)[CW / 4], float* Q, float* T, float* E, float* Rq, float* Rs,
+                                                    float* Ro, const BlkBnB& bq, const BlkBnB& bs, const BlkBnB& bo,
+                                                    const float* __restrict__ qkv_raw, const float* __restrict__ stacked,
+                                                    const float* __restrict__ lse, const float* __restrict__ yl, float* dqkv,
+                                                    float* coef_q, float* part_q, float* part_s, float* part_o, int grp, int n,
+                                                    int img, int sl, int training) {
+    constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 8, KQ = 2 * CW / 4, KO = CW / 4;
+    static_assert(KQ == 2 * NCH && KO == 2 * GP, "two heads per wave");
+    const int lane = threadIdx.x & 63;
+    const unsigned eq = ((unsigned)n * 2 * CW + sl * KQ) * 64 + lane, ev = ((unsigned)n * CW + sl * KO) * 64 + lane;
+    float sv[KO], gm[KO], d_o[KO], ls[2];
+    {
+        float raw[KQ];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) raw[k] = qkv_raw[eq + k * 64];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+            Q[(sl * KQ + k) * 256 + img * 64 + lane] = fmaf(raw[k], blk_ldu(bq.st + 2 * bq.n + grp * 2 * CW + sl * KQ + k),
+                                                            blk_ldu(bq.st + 3 * bq.n + grp * 2 * CW + sl * KQ + k));
+    }
+#pragma unroll
+    for (int k = 0; k < KO; ++k) {
+        sv[k] = stacked[ev + k * 64];
+        const float yv = RELU ? yl[ev + k * 64] : 1.f;
+        gm[k] = (RELU && !(yv > 0.f)) ? 0.f : gin[k];
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) ls[hh] = lse[((unsigned)n * G + 2 * sl + hh) * 64 + lane];
+    // 1. [ReLU mask,] bn_output backward over the group; this wave's d(sv) rows and normalised q | k | v rows
+    blk8_bn_bwd<KO>(gm, sv, bo, grp, CW, sl * KO, img, Ro, part_o, nullptr, training, d_o);
+    float* D = T;                                          // [CW][256], rows sl * KO .. of this image: this wave's
+#pragma unroll
+    for (int k = 0; k < KO; ++k) D[(sl * KO + k) * 256 + img * 64 + lane] = d_o[k];
+    MEDT_WAVE_LOCKSTEP();
+    // 2. softmax backward of this lane's rows, both heads; bn_similarity's two sums over the group
+    const int i = AXIS == 1 ? (lane & 7) : (lane >> 3), sj = AXIS == 1 ? 1 : 8, base = lane - i * sj;
+    // (the logits, probabilities and dZ are recomputed behind the barrier -- a dozen FMAs per pair -- instead of being held in
+    //  48 registers across it)
+    auto pair = [&](const float* Qh, const float (&qv)[HQ], const float* dl, float dlt, float a_qk, float lsv, int kj, float& S,
+                    float& P, float& dZv) {
+        float qk = 0.f, dP = 0.f;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qk = fmaf(qv[c], Qh[(HQ + c) * 256 + kj], qk);
+#pragma unroll
+        for (int c = 0; c < GP; ++c) dP = fmaf(dl[c], Qh[(GP + c) * 256 + kj], dP);
+        S = qk;
+        P = __builtin_amdgcn_exp2f(fmaf(qk, a_qk, -lsv));
+        dZv = P * (dP - dlt);
+    };
+    float dlt[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const float* Qh = Q + (sl * KQ + hh * NCH) * 256 + img * 64;
+        const float a_qk = blk_ldu(bs.st + 2 * bs.n + grp * G + 2 * sl + hh) * MEDT_LOG2E;
+        float qv[HQ], v0 = 0.f, v1 = 0.f;
+        dlt[hh] = 0.f;
+#pragma unroll
+        for (int c = 0; c < GP; ++c) dlt[hh] = fmaf(d_o[hh * GP + c], sv[hh * GP + c], dlt[hh]);
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 256 + lane];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float S, P, dZv;
+            pair(Qh, qv, d_o + hh * GP, dlt[hh], a_qk, ls[hh], base + j * sj, S, P, dZv);
+            v0 += dZv;
+            v1 = fmaf(dZv, S, v1);
+        }
+        const float a0 = blk_wave_sum(v0), ax = blk_wave_sum(v1);
+        if (lane == 0) {
+            float* r = Rs + ((2 * sl + hh) * 4 + img) * 2;
+            r[0] = a0;
+            r[1] = ax;
+        }
+    }
+    MEDT_LDS_BARRIER();
+    // 3. dq | dk | dv of the two heads; the transposed accesses go through this wave's strip
+    float gq[KQ];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int g = 2 * sl + hh;
+        const float* Qh = Q + (sl * KQ + hh * NCH) * 256 + img * 64;
+        const float* Dh = D + (sl * KO + hh * GP) * 256 + img * 64;
+        const float* r = Rs + g * 8;
+        const float a0 = (r[0] + r[2]) + (r[4] + r[6]), ax = (r[1] + r[3]) + (r[5] + r[7]);
+        if (img == 0 && lane == 0) {
+            float* ps = part_s + (unsigned)(grp * G + g) * 4;
+            ps[0] = a0; ps[1] = ax; ps[2] = 0.f; ps[3] = 0.f;
+        }
+        const float mean = blk_ldu(bs.st + grp * G + g), rstd = blk_ldu(bs.st + bs.n + grp * G + g);
+        const float ce = blk_ldu(bs.gamma + g) * rstd;
+        float cu = 0.f, cw = 0.f;
+        if (training) {
+            const float icnt = 1.f / (256.f * L), m1 = a0 * icnt, m2 = rstd * (ax - mean * a0) * icnt;
+            cu = -ce * rstd * m2;
+            cw = -ce * m1 - cu * mean;
+        }
+        const float a_qk = blk_ldu(bs.st + 2 * bs.n + grp * G + g) * MEDT_LOG2E;
+        float qv[HQ], dS[L], Pj[L];
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 256 + lane];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float S, dZv;
+            pair(Qh, qv, d_o + hh * GP, dlt[hh], a_qk, ls[hh], base + j * sj, S, Pj[j], dZv);
+            dS[j] = fmaf(ce, dZv, fmaf(cu, S, cw));
+            E[j * 64 + lane] = dS[j];
+        }
+        MEDT_WAVE_LOCKSTEP();
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) gq[hh * NCH + k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int o = base + j * sj;
+            const float dT = E[i * 64 + o];                                  // o as query, this lane as key
+#pragma unroll
+            for (int c = 0; c < HQ; ++c) {
+                gq[hh * NCH + c] = fmaf(dS[j], Qh[(HQ + c) * 256 + o], gq[hh * NCH + c]);
+                gq[hh * NCH + HQ + c] = fmaf(dT, Qh[c * 256 + o], gq[hh * NCH + HQ + c]);
+            }
+        }
+        MEDT_WAVE_LOCKSTEP();                              // (all reads of dS done before the strip takes P)
+#pragma unroll
+        for (int j = 0; j < L; ++j) E[j * 64 + lane] = Pj[j];
+        MEDT_WAVE_LOCKSTEP();
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int o = base + j * sj;
+            const float pT = E[i * 64 + o];
+#pragma unroll
+            for (int c = 0; c < GP; ++c) gq[hh * NCH + GP + c] = fmaf(pT, Dh[c * 256 + o], gq[hh * NCH + GP + c]);
+        }
+        MEDT_WAVE_LOCKSTEP();
+    }
+    // 4. bn_qkv backward over the group; the gradient tile (computed behind that barrier: every wave's attention is over)
+    {
+        float dzq[KQ], raw[KQ];                             // (qkv_raw again: L2; not held across the attention)
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) raw[k] = qkv_raw[eq + k * 64];
+        blk8_bn_bwd<KQ>(gq, raw, bq, grp, 2 * CW, sl * KQ, img, Rq, part_q, coef_q, training, dzq);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            dqkv[eq + k * 64] = gq[k];
+            T[(sl * KQ + k) * 256 + img * 64 + lane] = dzq[k];
+        }
+    }
+    MEDT_LDS_BARRIER();
+}
+
+template <int CI, int CW, int GP>
+__global__ __launch_bounds__(1024) void wopos_block8_bwd_kernel(const float* __restrict__ w_down, const float* __restrict__ w_qh,
+                                                                const float* __restrict__ w_qw, const float* __restrict__ w_up,
+                                                                BlkBwdArgs a) {
+    constexpr int G = CW / GP, KD = CW / 4, KU = CI / 4;
+    constexpr int CHS[8] = {CW, 2 * CW, G, CW, 2 * CW, G, CW, CI};
+    static_assert(CI == 2 * CW, "tile sizes below");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;                                    // [CI][256]
+    float* Q = T + CI * 256;                            // [2CW][256]
+    float* R = Q + 2 * CW * 256;                        // per-image records of the eight BatchNorm backwards, [CH][4][2] each
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = wv & 3, sl = wv >> 2, n = grp * 4 + img;
+    float* E = T + CW * 256 + wv * 8 * 64;              // this wave's strip, in the half of T the d(sv) rows leave free
+    int roff[8];
+    {
+        int o = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { roff[b] = o; o += CHS[b] * 8; }
+    }
+    const int gs = gridDim.x, nq = gs * 2 * CW, ns = gs * G, no = gs * CW;
+    const BlkBnB bn1{a.stats[0], gs * CW, a.gamma[0]}, bn2{a.stats[3], gs * CI, a.gamma[7]};
+    const BlkBnB bqh{a.stats[1], nq, a.gamma[1]}, bsh{a.stats[1] + 4 * nq, ns, a.gamma[2]}, boh{a.stats[1] + 4 * (nq + ns), no, a.gamma[3]};
+    const BlkBnB bqw{a.stats[2], nq, a.gamma[4]}, bsw{a.stats[2] + 4 * nq, ns, a.gamma[5]}, bow{a.stats[2] + 4 * (nq + ns), no, a.gamma[6]};
+    float* const part = a.part;
+    const unsigned ei = ((unsigned)n * CI + sl * KU) * 64 + lane, ew = ((unsigned)n * CW + sl * KD) * 64 + lane;
+    // ---- bn2 backward behind the ReLU mask -> dz2 (global + tile)
+    {
+        float gy[KU], zz[KU], dz[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const float yv = a.y[ei + k * 64];
+            gy[k] = a.dy[ei + k * 64];
+            zz[k] = a.z2[ei + k * 64];
+            if (!(yv > 0.f)) gy[k] = 0.f;
+        }
+        blk8_bn_bwd<KU>(gy, zz, bn2, grp, CI, sl * KU, img, R + roff[7], part + blk_part_off(7, gs, CW, CI, G), nullptr, a.training, dz);
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            a.dz2[ei + k * 64] = dz[k];
+            T[(sl * KU + k) * 256 + img * 64 + lane] = dz[k];
+        }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_up dgrad, width layer, its qkv_transform dgrad, height layer, its qkv_transform dgrad
+    float gio[KD];
+    wave8_dgrad1x1<KD, CI, CW>(w_up, sl * KD, T + img * 64, gio);
+    // (the d(sv) rows and strips reuse T: written behind bn_output's barrier, which every wave reaches after this dgrad)
+    wave8_attention_bwd<CW, GP, 1, true>(gio, Q, T, E, R + roff[4], R + roff[5], R + roff[6], bqw, bsw, bow, a.qkv[1], a.stk[1],
+                                         a.lse[1], a.y_w, a.dqkv[1], a.coef_q[1], part + blk_part_off(4, gs, CW, CI, G),
+                                         part + blk_part_off(5, gs, CW, CI, G), part + blk_part_off(6, gs, CW, CI, G), grp, n, img,
+                                         sl, a.training);
+    wave8_dgrad1x1<KD, 2 * CW, CW>(w_qw, sl * KD, T + img * 64, gio);
+    wave8_attention_bwd<CW, GP, 0, false>(gio, Q, T, E, R + roff[1], R + roff[2], R + roff[3], bqh, bsh, boh, a.qkv[0], a.stk[0],
+                                          a.lse[0], nullptr, a.dqkv[0], a.coef_q[0], part + blk_part_off(1, gs, CW, CI, G),
+                                          part + blk_part_off(2, gs, CW, CI, G), part + blk_part_off(3, gs, CW, CI, G), grp, n, img,
+                                          sl, a.training);
+    wave8_dgrad1x1<KD, 2 * CW, CW>(w_qh, sl * KD, T + img * 64, gio);
+    // ---- bn1 backward behind the ReLU mask -> dz1 (global + tile: behind bn1's barrier, i.e. behind every wave's dgrad above)
+    {
+        float gm[KD], zz[KD], dz[KD];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            zz[k] = a.z1[ew + k * 64];
+            gm[k] = a.y1[ew + k * 64] > 0.f ? gio[k] : 0.f;
+        }
+        blk8_bn_bwd<KD>(gm, zz, bn1, grp, CW, sl * KD, img, R + roff[0], part, nullptr, a.training, dz);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            a.dz1[ew + k * 64] = dz[k];
+            T[(sl * KD + k) * 256 + img * 64 + lane] = dz[k];
+        }
+    }
+    float add[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+        const float yv = a.y[ei + k * 64], d = a.dy[ei + k * 64];
+        add[k] = (yv > 0.f ? d : 0.f) + (a.dx_add ? a.dx_add[ei + k * 64] : 0.f);
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_down dgrad + identity + deposit
+    {
+        float dxv[KU];
+        wave8_dgrad1x1<KU, CW, CI>(w_down, sl * KU, T + img * 64, dxv);
+#pragma unroll
+        for (int k = 0; k < KU; ++k) a.dx[ei + k * 64] = dxv[k] + add[k];
+    }
+}
+
 // Workspace of the backward, in floats: the gradient tensors the recorded weight-gradient jobs read, bn_qkv's coefficients, the
 // partial rows of the eight BatchNorms, the coefficient outputs of bn1 / bn2's finalisation, the weight-gradient scratch slabs.
 struct BlkBwdWs {
@@ -1242,7 +1560,7 @@ int& block_bwd_mode() {
     return mode;
 }
 static bool block_bwd_enabled() { return block_bwd_mode() != 0; }
-bool wopos_block_bwd_ok(const medt_block_desc& d) { return block_bwd_enabled() && wopos_block_shape(d) == 1; }
+bool wopos_block_bwd_ok(const medt_block_desc& d) { return block_bwd_enabled() && wopos_block_shape(d) != 0; }
 
 size_t wopos_block_bwd_ws_bytes(const medt_block_desc& d) {
     Carver c(nullptr, 0);
@@ -1268,6 +1586,21 @@ int wopos_block_bwd_launch(const medt_block_desc& d, const medt_block_params& p,
     a.dz2 = dz2; a.dz1 = dz1; a.dx = dx;
     for (int l = 0; l < 2; ++l) { a.dqkv[l] = dqkv[l]; a.coef_q[l] = coef_q[l]; }
     a.training = d.training ? 1 : 0;
+    if (wopos_block_shape(d) == 2) {                // 8x8 maps
+        const int chs8[8] = {d.width, 2 * d.width, d.G, d.width, 2 * d.width, d.G, d.width, d.C};
+        size_t nrec = 0;
+        for (int b = 0; b < 8; ++b) nrec += (size_t)chs8[b] * 8;
+        const size_t lds8 = ((size_t)(d.C + 2 * d.width) * 256 + nrec) * sizeof(float);
+        static bool attr8 = false;
+        if (!attr8) {
+            (void)hipFuncSetAttribute((const void*)wopos_block8_bwd_kernel<64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr8 = true;
+        }
+        hipLaunchKernelGGL((wopos_block8_bwd_kernel<64, 32, 4>), dim3(d.bn_groups), dim3(1024), lds8, s, p.w_down, p.height.w_qkv,
+                           p.width.w_qkv, p.w_up, a);
+        return launch_status("wopos_block8_bwd");
+    }
     const size_t lds = ((size_t)(d.C + 2 * d.width + 2 * d.width) * 64 + 16 * 4 * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {

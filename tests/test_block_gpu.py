@@ -237,3 +237,38 @@ def test_block8_fused_equals_stagewise(training, device):
             assert int(b0[k]) == int(b1[k])
         else:
             assert H.rel_err(b1[k], b0[k]) < 1e-5, k
+
+
+@block8_opt_in
+@bwd_opt_in
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_block8_backward_one_launch_equals_stagewise(training, device):
+    """wopos_block8_bwd_kernel (MEDT_BLOCK8=1 + MEDT_BLOCK_BWD=1) against the six per-stage backward launches on layer2_p.1's shape;
+    verified on the CPU lane emulator against the oracle (tests/test_lane_emu.py::test_block8_backward_kernel_on_the_emulator)."""
+    import lib as droplib
+    from medt_amd import block
+    torch.manual_seed(6)
+    blk = droplib.models.axialnet.AxialBlock_wopos(64, 32, groups=8, base_width=64, kernel_size=8)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    blk = blk.to(device)
+    x = torch.randn(64, 64, 8, 8, device=device).relu_()
+    dout = torch.randn(64, 64, 8, 8, device=device)
+    block.BWD_ENABLED = False
+    try:
+        y0, dx0, g0, b0 = run(blk, x, dout, True, training)
+    finally:
+        block.BWD_ENABLED = True
+    y1, dx1, g1, b1 = run(blk, x, dout, True, training)
+    assert torch.equal(y1, y0)
+    assert H.rel_err(dx1, dx0) < 2e-5, H.rel_err(dx1, dx0)
+    assert g0.keys() == g1.keys() and len(g0) == 20
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err < 5e-5 * max(g0[k].abs().max().item(), 1e-2 * gmax), (k, err)
