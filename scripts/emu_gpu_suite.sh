@@ -19,7 +19,8 @@ run() { # name, env, pytest args...
 run ops ""                      tests/test_ops_gpu.py
 run block "MEDT_BLOCK_BWD=1"    tests/test_block_gpu.py
 run block_v2 "MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1" tests/test_block_gpu.py
+run block8 "MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1" tests/test_block_gpu.py
 run layers ""                   tests/test_axial_layer_gpu.py
 run models ""                   tests/test_model_gpu.py -k "test_model_vs_reference_fixture and (axialunet_S64 or S128_N2 or logo)"
-run medt_n4_new_kernels "MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1" tests/test_model_gpu.py -k "test_model_vs_reference_fixture and MedT_S128_N4"
+run medt_n4_new_kernels "MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1" tests/test_model_gpu.py -k "test_model_vs_reference_fixture and MedT_S128_N4"
 wait
