@@ -15,7 +15,7 @@ echo "== parity, MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (second-generation instantiati
 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -5 >> $out
 echo "== parity, MEDT_BLOCK8=1 (8x8-map block forward)" >> $out
 MEDT_BLOCK8=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py -m gpu -x -q -k "block8 or test_model_vs_reference_fixture" 2>&1 | tail -5 >> $out
-for rep in 1 2; do
+for rep in 1; do
   echo "== bench MEDT_BLOCK8=1 alone (rep $rep)" >> $out
   MEDT_BLOCK8=1 timeout 600 python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" >> $out
   echo "== bench everything on: MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1 (rep $rep)" >> $out
