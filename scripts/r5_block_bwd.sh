@@ -7,6 +7,12 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/r5_block_bwd.txt
 : > $out
+# first, under SHORT timeouts, the new kernels alone (they have never run on a GPU: a hang must not eat the box) -- stop if they fail
+for env in "MEDT_BLOCK_BWD=1" "MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1" "MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1" "MEDT_BLOCK8=1 MEDT_BLOCK_BWD=1 MEDT_BLOCK_PK=1"; do
+  echo "== block kernels alone: $env" >> $out
+  if ! env $env timeout 240 python -m pytest tests/test_block_gpu.py -m gpu -x -q 2>&1 | tail -3 >> $out; then echo "STOP: $env failed" >> $out; cat $out; exit 1; fi
+  if ! tail -1 $out | grep -q " passed"; then echo "STOP: $env did not pass" >> $out; cat $out; exit 1; fi
+done
 echo "== parity, MEDT_BLOCK_BWD=1" >> $out
 MEDT_BLOCK_BWD=1 timeout 900 python -m pytest tests/test_block_gpu.py tests/test_model_gpu.py tests/test_dist_gpu.py -m gpu -x -q 2>&1 | tail -15 >> $out
 echo "== smoke, MEDT_BLOCK_BWD=1" >> $out
