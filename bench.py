@@ -361,17 +361,30 @@ def main():
         "collective_in_graph": bool(getattr(train_step, "collective_in_graph", False)) if distributed else None,
     }
     if rank == 0 and world == 1:
+        # BASELINE's second figure, "fwd ms/image": the eval-mode forward of reference test.py:106-119, replayed as a
+        # hipGraph (medt_amd.trainer.InferStep, what test.py runs) at the bench batch and at test.py's batch of 1;
+        # the eager launch-by-launch forward (host-bound) is reported beside it
+        from medt_amd.trainer import InferStep
         model.eval()
-        with torch.no_grad():
+        infer = InferStep(model)
+
+        def time_fwd(fn, xin, reps):
             for _ in range(3):
-                model(x)
+                fn(xin)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(10):
-                model(x)
+            for _ in range(reps):
+                fn(xin)
             torch.cuda.synchronize()
-            result["fwd_ms_per_image"] = (time.perf_counter() - t1) / 10 / args.batch * 1e3
-        log(f"eval fwd {result['fwd_ms_per_image']:.3f} ms/image")
+            return (time.perf_counter() - t1) / reps / xin.shape[0] * 1e3
+
+        with torch.no_grad():
+            result["fwd_ms_per_image"] = time_fwd(infer, x, 50)
+            result["fwd_ms_per_image_bs1"] = time_fwd(infer, x[:1].contiguous(), 50)
+            result["fwd_ms_per_image_eager"] = time_fwd(model, x, 10)
+            result["fwd_path"] = "hipGraph replay of the eval-mode forward (InferStep); eager = one Python-issued launch per kernel"
+        log(f"eval fwd {result['fwd_ms_per_image']:.3f} ms/image replayed (bs {args.batch}), {result['fwd_ms_per_image_bs1']:.3f} at bs 1, "
+            f"{result['fwd_ms_per_image_eager']:.3f} eager")
         if not args.no_roofline:
             result["roofline"] = roofline_leg(device)
             # SURVEY.md 8(d)'s second scaled shape (256-px inputs: C=32, gp=4, L=128), reported beside the headline one

@@ -51,6 +51,15 @@ def fused_forward(blk, x, bn_groups: int):
     width = blk.conv_down.weight.shape[0]
     if blk.conv_up.weight.shape[0] != Cc:
         return None
+    # geometry the C side cannot see (it gets N, C, width, H, W, G only): the reference block's and nothing else
+    for cv, cin, cout in ((blk.conv_down, Cc, width), (blk.conv_up, width, Cc)):
+        if (tuple(cv.kernel_size) != (1, 1) or tuple(cv.stride) != (1, 1) or tuple(cv.padding) != (0, 0) or cv.groups != 1
+                or cv.in_channels != cin or cv.out_channels != cout):
+            return None
+    if h.width or not w.width or h.groups != w.groups or h.training != training or w.training != training or blk.training != training:
+        return None
+    if h.qkv_transform.weight.shape[:2] != (2 * width, width) or w.qkv_transform.weight.shape[:2] != (2 * width, width):
+        return None
     lib = L.lib()
     desc = L.BlockDesc(N, Cc, width, H, W, h.groups, int(training), bn_groups, blk.bn1.eps, float(blk.bn1.momentum))
     ws_bytes = lib.medt_wopos_block_workspace_bytes(C.byref(desc))
@@ -154,7 +163,7 @@ class WoposBlockFn(torch.autograd.Function):
                              L.AxialSaved(qh.data_ptr(), sh.data_ptr(), lh.data_ptr(), sth.data_ptr()), yh.data_ptr(),
                              L.AxialSaved(qw.data_ptr(), sw.data_ptr(), lw.data_ptr(), stw.data_ptr()), yw.data_ptr(),
                              z2.data_ptr(), stats2.data_ptr())
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, device=dev, dtype=torch.float32)
         # fan-in of d(x): this node is conv_down AND the identity path; what other consumers deposited is added in the kernel
         xs = ctx.sink if ctx.needs_input_grad[0] else None
         dep = xs.take() if xs is not None else None
@@ -182,6 +191,7 @@ def block_forward(blk, x, bn_groups: int, sink):
                        blk.bn1.eps, float(blk.bn1.momentum if blk.bn1.momentum is not None else 0.1))
     if L.lib().medt_wopos_block_bwd_workspace_bytes(C.byref(desc)) == 0:
         return None
+    x = x.contiguous()                     # the backward reads x (and writes dx) as dense NCHW through raw pointers
     pre = fused_forward(blk, x, bn_groups)
     if pre is None:
         return None

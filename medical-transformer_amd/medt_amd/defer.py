@@ -4,7 +4,8 @@ While a StepQueue is `active()`, the layer entry points record weight / bias gra
 statistics bookkeeping of the fused small-layer kernels instead of launching them; `flush()` issues everything recorded
 as a few grouped launches.  The recorded jobs point into tensors of the Python call that recorded them (workspace,
 inputs, saved activations, gradient outputs), so the queue holds a reference to each of them until the flush.
-Only medt_amd.trainer.TrainStep uses this: it flushes after the forward pass and after the backward pass.
+medt_amd.trainer.TrainStep flushes after the forward pass and after the backward pass; InferStep (no backward) drops the
+bookkeeping of an eval-mode forward altogether (`drop`).
 """
 from __future__ import annotations
 
@@ -28,6 +29,7 @@ class StepQueue:
         self._keep = {}                # handle -> tensors the recorded jobs point into
         self._bound = set()
         self.issued = 0                # jobs handed to grouped launches so far (tests: the forward flushes per branch)
+        self.drop = False              # True: every flush discards instead (InferStep in eval mode: bookkeeping nobody reads)
 
     def __del__(self):
         try:
@@ -59,6 +61,8 @@ class StepQueue:
 
     def flush(self):
         """Issue everything recorded so far on the current stream (all recording streams must have been joined into it)."""
+        if self.drop:
+            return self.discard()
         cur = torch.cuda.current_stream().cuda_stream
         for h in self._handles.values():
             self.issued += int(L.lib().medt_queue_pending(h))
@@ -71,7 +75,10 @@ class StepQueue:
             return
         cur = torch.cuda.current_stream().cuda_stream
         h = self._handles.get(cur)
-        if h is not None:
+        if h is not None and self.drop:
+            L.lib().medt_queue_discard(h)
+            self._keep[h].clear()
+        elif h is not None:
             self.issued += int(L.lib().medt_queue_pending(h))
             L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
             self._keep[h].clear()

@@ -176,3 +176,95 @@ class TrainStep:
             self.opt.allreduce()
             self.opt.apply(_world())
         return static_loss
+
+
+class InferStep:
+    """`with torch.no_grad(): y = model(x)` -- the loop body of reference test.py:106-119 and of train.py's periodic
+    validation (train.py:174-184) -- as a replayable HIP graph per input shape, optionally with the device-side
+    segmentation counts (ops.seg_counts) behind it.
+
+    An eager forward is ~110 dependent launches of 5-25 us kernels issued from Python: it is host-bound (0.7 ms/image at
+    batch 4 -- longer than the whole replayed TRAINING step that contains the same forward).  Replayed, the forward costs
+    what its two kernel chains cost.  Semantics kept:
+
+      * model.eval(): BatchNorm is a per-channel affine of the running statistics.  The statistics bookkeeping the
+        fused small-layer kernels record (saved mean / rstd blocks that only a backward pass reads) is DROPPED from the
+        graph (StepQueue.discard) -- nothing in a no-grad forward reads it;
+      * model.train() under no_grad (what the reference's validation loop does, train.py:174-184: the model is never
+        switched to eval there): batch statistics, and every replay applies the running-statistics update and bumps
+        num_batches_tracked once, like the eager call; the recorded bookkeeping is flushed inside the graph.
+
+    The returned tensors are the graph's static outputs: valid until the next call with the same signature (clone to
+    keep).  Parameters and buffers are read through their storage at replay time, so optimizer updates between replays
+    are seen; re-pointing parameter storage (FlatAdam adoption on the first training step, load_state_dict keeps
+    storage) changes the signature and triggers a fresh capture.
+    """
+
+    def __init__(self, model, use_graph: bool = True, warmup: int = 2, threshold: float = 0.5):
+        self.model, self.use_graph, self.warmup, self.threshold = model, use_graph, max(1, warmup), threshold
+        self._graphs = {}
+        self._queue = None
+
+    def _forward(self, x, target):
+        with torch.no_grad():
+            if not x.is_cuda:
+                out = self.model(x)
+            else:
+                if self._queue is None:
+                    self._queue = StepQueue()
+                # eval mode: what gets recorded are saved-statistics blocks for a backward pass that never comes
+                self._queue.drop = not self.model.training
+                with self._queue.active():
+                    out = self.model(x)
+            counts = None
+            if target is not None:
+                from .ops import seg_counts
+                counts = seg_counts(out, target, self.threshold)
+        return out, counts
+
+    def _signature(self, x, target):
+        # (storage addresses: a captured graph holds raw pointers to every parameter and buffer)
+        ptrs = hash(tuple(t.data_ptr() for t in list(self.model.parameters()) + list(self.model.buffers())))
+        return (tuple(x.shape), x.dtype, None if target is None else tuple(target.shape), self.model.training, ptrs)
+
+    def _capture(self, x, target):
+        from .data import GPU_CAPTURE_LOCK
+        with GPU_CAPTURE_LOCK:
+            static_x = x.clone()
+            static_t = target.clone() if target is not None else None
+            snap = None
+            if self.model.training:            # warm-up forwards must not leave extra running-statistics updates behind
+                bufs = list(self.model.buffers())
+                snap = [b.detach().clone() for b in bufs]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._forward(static_x, static_t)
+                if snap is not None:
+                    with torch.no_grad():
+                        for b, v in zip(bufs, snap):
+                            b.copy_(v)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out, counts = self._forward(static_x, static_t)
+            return graph, static_x, static_t, out, counts
+
+    def __call__(self, x, target=None):
+        """-> logits, or (logits, counts) when integer label maps `target` (N,H,W) are given."""
+        if not (self.use_graph and x.is_cuda):
+            out, counts = self._forward(x, target)
+            return out if target is None else (out, counts)
+        sig = self._signature(x, target)
+        entry = self._graphs.get(sig)
+        if entry is None:
+            if len(self._graphs) >= 8:         # stale captures (old parameter storage, other shapes) hold memory pools
+                self._graphs.clear()
+            entry = self._graphs[sig] = self._capture(x, target)
+        graph, static_x, static_t, out, counts = entry
+        static_x.copy_(x)
+        if static_t is not None:
+            static_t.copy_(target)
+        graph.replay()
+        return out if target is None else (out, counts)

@@ -14,6 +14,7 @@ import lib
 import medt_amd
 import metrics
 from medt_amd.data import imwrite
+from medt_amd.trainer import InferStep
 
 parser = argparse.ArgumentParser(description='MedT')
 parser.add_argument('-j', '--workers', default=16, type=int, metavar='N', help='number of data loading workers (default: 8)')
@@ -62,12 +63,15 @@ def main():
     fulldir = args.direc + "/"
     os.makedirs(fulldir, exist_ok=True)
     scores = []
+    # forward + the device-side counts as ONE replayed hipGraph per image shape (medt_amd.trainer.InferStep): an eager
+    # forward is ~110 dependent launches issued from Python and is host-bound
+    infer = InferStep(model)
     for batch_idx, (X_batch, y_batch, *rest) in enumerate(valloader):
         image_filename = rest[0][0] if isinstance(rest[0][0], str) else '%s.png' % str(batch_idx + 1).zfill(3)
-        with torch.no_grad():
-            y_out = model(X_batch.to(device))
-            # what performancemetrics_*.m computes offline from the PNGs, counted on the device
-            scores.append(medt_amd.seg_counts(y_out, y_batch.to(device).long().reshape(y_out.shape[0], *y_out.shape[2:])))
+        X_batch = X_batch.to(device)
+        # what performancemetrics_*.m computes offline from the PNGs, counted on the device
+        y_out, counts = infer(X_batch, y_batch.to(device).long().reshape(X_batch.shape[0], *X_batch.shape[2:]))
+        scores.append(counts.clone())
         yHaT = (y_out.detach().cpu().numpy() >= 0.5).astype(np.uint8) * 255
         imwrite(fulldir + image_filename, yHaT[0, 1, :, :])
     if scores:

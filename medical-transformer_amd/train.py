@@ -26,7 +26,7 @@ from metrics import LogNLLLoss
 from medt_amd import dp
 from medt_amd.data import DevicePrefetcher, imwrite, make_synthetic_dataset
 from medt_amd.optim import FlatAdam
-from medt_amd.trainer import TrainStep
+from medt_amd.trainer import InferStep, TrainStep
 
 parser = argparse.ArgumentParser(description='MedT')
 parser.add_argument('-j', '--workers', default=16, type=int, metavar='N', help='number of data loading workers (default: 8)')
@@ -107,6 +107,7 @@ def main():
     criterion = LogNLLLoss()
     optimizer = FlatAdam(list(model.parameters()), lr=args.learning_rate, weight_decay=1e-5)
     train_step = TrainStep(model, optimizer, criterion, use_graph=not args.eager)
+    infer_step = InferStep(model, use_graph=not args.eager)
     if rank == 0:
         print("Total_params: {}".format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
 
@@ -137,8 +138,9 @@ def main():
             os.makedirs(fulldir, exist_ok=True)
             for batch_idx, (X_batch, y_batch, *rest) in enumerate(valloader):
                 image_filename = rest[0][0] if isinstance(rest[0][0], str) else '%s.png' % str(batch_idx + 1).zfill(3)
-                with torch.no_grad():                 # the model stays in train mode here, as in the reference (:174-184)
-                    y_out = model(X_batch.to(device))
+                # the model stays in train mode here, as in the reference (:174-184): batch statistics, and every forward
+                # updates the running statistics; replayed as one hipGraph per image shape (InferStep)
+                y_out = infer_step(X_batch.to(device))
                 yHaT = (y_out.detach().cpu().numpy() >= 0.5).astype(np.uint8) * 255
                 imwrite(fulldir + image_filename, yHaT[0, 1, :, :])
             torch.save(model.state_dict(), fulldir + args.modelname + ".pth")
