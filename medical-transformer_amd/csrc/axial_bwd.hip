@@ -54,7 +54,7 @@ struct Sw {
     // row records of one sequence: + 8 floats so that the records the sequences of a wave read together (same row, one
     // broadcast address per sequence) fall into different LDS banks
     static constexpr int RS = L * RREC + 8;
-    static_assert(L % LS == 0 && (LS == 8 || LS == 16), "lanes per sequence");
+    static_assert(L % LS == 0 && (LS == 8 || LS == 16 || LS == 32), "lanes per sequence");
 };
 
 typedef medt_f4 f4;
@@ -73,11 +73,15 @@ __device__ __forceinline__ float dppv(float src) {
 // sum over the LS lanes of a sequence, result in all of them
 template <int LS>
 __device__ __forceinline__ float seq_allsum(float v) {
-    if (LS == 16) {
+    if (LS >= 16) {
         v += dppv<0x128>(v);           // row_ror:8
         v += dppv<0x124>(v);           // row_ror:4
         v += dppv<0x122>(v);           // row_ror:2
         v += dppv<0x121>(v);           // row_ror:1
+        if (LS == 32) {                // a sequence = two 16-lane rows: rows 1 <-> 0 and 3 <-> 2 trade places (gfx950 lane swap)
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
     } else {                           // LS == 8: the two halves of a 16-lane row are different sequences
         v += dppv<0xB1>(v);            // quad_perm [1,0,3,2]
         v += dppv<0x4E>(v);            // quad_perm [2,3,0,1]
@@ -89,6 +93,10 @@ __device__ __forceinline__ float seq_allsum(float v) {
 // x <- the value of the previous lane of the sequence; the first lane of every sequence takes `fresh`
 template <int LS>
 __device__ __forceinline__ float chain_shift(float x, float fresh, bool head) {
+    if (LS == 32) {                    // the chain crosses the row boundary inside a sequence: wave_shr:1 (lane 0 keeps `fresh`)
+        const float r = dpp<0x138>(fresh, x);
+        return head ? fresh : r;
+    }
     float r = dpp<0x111>(fresh, x);    // row_shr:1 (lane 0 of each 16-lane row keeps `fresh`)
     if (LS < 16) r = head ? fresh : r;
     return r;
@@ -96,6 +104,10 @@ __device__ __forceinline__ float chain_shift(float x, float fresh, bool head) {
 // the same with fresh = 0 (accumulators): bound_ctrl zero-fills lane 0 of the row, no `old` operand to set up
 template <int LS>
 __device__ __forceinline__ float chain_shift0(float x, bool head) {
+    if (LS == 32) {
+        const float r = dppv<0x138>(x);                      // wave_shr:1, lane 0 zero-filled
+        return head ? 0.f : r;
+    }
     float r = dppv<0x111>(x);
     if (LS < 16) r = head ? 0.f : r;
     return r;
@@ -106,8 +118,10 @@ template <int LS>
 __device__ __forceinline__ float seqs_sum(float v) {
     if (LS == 8) v += dppv<0x128>(v);                        // row_ror:8
     // gfx950 lane swaps (VALU, no LDS crossbar round trip): row 1 <-> row 0 / row 3 <-> row 2, then the wave halves
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    if (LS < 32) {                                           // (LS == 32: the two sequences of the wave are its halves)
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(h[0]) + __uint_as_float(h[1]);
 }
@@ -190,7 +204,8 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sg = lane / LS, cb = lane % LS;                 // sequence of the wave, column block of the sequence
     const bool head = cb == 0;
-    const unsigned long long tail_mask = LS == 16 ? 0x8000800080008000ull : 0x8080808080808080ull;   // last lane of every sequence
+    const unsigned long long tail_mask = LS == 32 ? 0x8000000080000000ull                              // last lane of every sequence
+                                         : (LS == 16 ? 0x8000800080008000ull : 0x8080808080808080ull);
     const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr), f_sve = gate(a.gates.f_sve), f_sv = gate(a.gates.f_sv);
     const float e_qk = a.ss.scale[grp * g.SC + hg], e_qr = a.ss.scale[grp * g.SC + g.G + hg],
                 e_kr = a.ss.scale[grp * g.SC + 2 * g.G + hg];
@@ -882,6 +897,9 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     int ls = 0;
     if (g.gp == 2 && (g.L == 32 || g.L == 64 || g.L == 128)) ls = g.L == 32 ? 8 : 16;
     else if (g.gp == 4 && (g.L == 32 || g.L == 64)) ls = g.L == 32 ? 8 : 16;
+    // round 5: layer2.0 of MedT / the unets at 256 px.  32 lanes per sequence (a sequence = two 16-lane rows, D = 4 key columns
+    // per lane): the register budget of <4, 64, 16>; the diagonal chain crosses the row boundary with wave_shr:1
+    else if (g.gp == 4 && g.L == 128) ls = 32;
     else if (g.gp == 8 && (g.L == 32 || g.L == 16)) ls = 16;       // round 4: the deep layers of axialunet / gatedaxialunet
     else if (g.gp == 16 && g.L == 16) ls = 16;                     // (layer4 at 128 px: 256 VGPRs + 70 AGPRs, no scratch)
     if (!ls) return false;
@@ -906,7 +924,7 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     const int hq = g.hq, np = hq * (hq + 1) / 2;
     p->npg_floats = 2 * (np + hq);
     if (g.gp == 2) p->lds = g.L == 32 ? sweep_lds_bytes<2, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<2, 64, 16>(nw) : sweep_lds_bytes<2, 128, 16>(nw));
-    else if (g.gp == 4) p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : sweep_lds_bytes<4, 64, 16>(nw);
+    else if (g.gp == 4) p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<4, 64, 16>(nw) : sweep_lds_bytes<4, 128, 32>(nw));
     else if (g.gp == 8) p->lds = g.L == 32 ? sweep_lds_bytes<8, 32, 16>(nw) : sweep_lds_bytes<8, 16, 16>(nw);
     else p->lds = sweep_lds_bytes<16, 16, 16>(nw);
     return p->lds <= 160 * 1024;
@@ -942,6 +960,7 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
     else if (g.gp == 2 && g.L == 128) MEDT_SWEEP(2, 128, 16);
     else if (g.gp == 4 && g.L == 32) MEDT_SWEEP(4, 32, 8);
     else if (g.gp == 4 && g.L == 64) MEDT_SWEEP(4, 64, 16);
+    else if (g.gp == 4 && g.L == 128) MEDT_SWEEP(4, 128, 32);
     else if (g.gp == 8 && g.L == 32) MEDT_SWEEP(8, 32, 16);
     else if (g.gp == 8 && g.L == 16) MEDT_SWEEP(8, 16, 16);
     else if (g.gp == 16 && g.L == 16) MEDT_SWEEP(16, 16, 16);

@@ -430,9 +430,10 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
     BLK_STAMP(9);                                       // conv_up + bn2 + identity + ReLU
 }
 
-// MEDT_BLOCK_PK=1: the packed-FMA instantiations of the two block kernels (off until measured; tests/lane_emu sets it directly)
+// The packed-FMA (second-generation) instantiations of the block kernels: default since round 5 (first MI355X run: parity green, the
+// step 2.139 -> 2.130 ms alone, 2.105 with the other two switches; profiles/r05_step_ab.json); MEDT_BLOCK_PK=0 = the first generation
 int& block_pk_mode() {
-    static int mode = [] { const char* e = getenv("MEDT_BLOCK_PK"); return (e && e[0] == '1') ? 1 : 0; }();
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK_PK"); return (e && e[0] == '0') ? 0 : 1; }();
     return mode;
 }
 
@@ -758,15 +759,15 @@ static bool block_fused_enabled() {
     return on;
 }
 
-// MEDT_BLOCK8=1: the 8x8-map kernel (off until measured; tests/lane_emu sets it directly)
+// The 8x8-map kernels: default since round 5 (first MI355X run: parity green, profiles/r05_step_ab.json); MEDT_BLOCK8=0 = per stage
 int& block8_mode() {
-    static int mode = [] { const char* e = getenv("MEDT_BLOCK8"); return (e && e[0] == '1') ? 1 : 0; }();
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK8"); return (e && e[0] == '0') ? 0 : 1; }();
     return mode;
 }
 
 // Shapes the fused kernels are built for: 4-image BatchNorm groups, 8 heads, and
 //   1: 4x4 maps, (C, width) = (128, 64) -- layer3_p.1-3 of MedT at 128 px, BASELINE.json's batch size (forward and backward)
-//   2: 8x8 maps, (C, width) = (64, 32)  -- layer2_p.1 (forward only, MEDT_BLOCK8=1)
+//   2: 8x8 maps, (C, width) = (64, 32)  -- layer2_p.1 (forward and backward; MEDT_BLOCK8=0 turns it off)
 static int wopos_block_shape(const medt_block_desc& d) {
     if (!block_fused_enabled()) return 0;
     if (d.N <= 0 || d.bn_groups <= 0 || d.N != 4 * d.bn_groups || d.G != 8) return 0;
@@ -804,14 +805,10 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
     for (int b = 0; b < 8; ++b) nprm += (size_t)chs[b] * 4;
     if (wopos_block_shape(d) == 2) {                // 8x8 maps: tile + q|k|v tile + parameters + per-image statistics records
         const size_t lds8 = ((size_t)3 * d.width * 256 + nprm + 2 * nprm) * sizeof(float);
-        static bool attr8 = false;
-        if (!attr8) {
-            (void)hipFuncSetAttribute((const void*)wopos_block8_fwd_kernel<64, 32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            (void)hipFuncSetAttribute((const void*)wopos_block8_fwd_kernel<64, 32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            attr8 = true;
-        }
+        static unsigned char attr8[2][64];
+        int rc8;
+        if ((rc8 = lds_opt_in((const void*)wopos_block8_fwd_kernel<64, 32, 4, false>, attr8[0], "wopos_block8_fwd")) ||
+            (rc8 = lds_opt_in((const void*)wopos_block8_fwd_kernel<64, 32, 4, true>, attr8[1], "wopos_block8_fwd"))) return rc8;
         if (block_pk_mode())
             hipLaunchKernelGGL((wopos_block8_fwd_kernel<64, 32, 4, true>), dim3(d.bn_groups), dim3(1024), lds8, s, x, p.w_down,
                                p.height.w_qkv, p.width.w_qkv, p.w_up, a);
@@ -821,14 +818,10 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
         return launch_status("wopos_block8_fwd");
     }
     const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {                    // more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU)
-        (void)hipFuncSetAttribute((const void*)wopos_block_fwd_kernel<128, 64, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wopos_block_fwd_kernel<128, 64, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr = true;
-    }
+    static unsigned char attr[2][64];
+    int rca;
+    if ((rca = lds_opt_in((const void*)wopos_block_fwd_kernel<128, 64, 8, false>, attr[0], "wopos_block_fwd")) ||
+        (rca = lds_opt_in((const void*)wopos_block_fwd_kernel<128, 64, 8, true>, attr[1], "wopos_block_fwd"))) return rca;
     if (block_pk_mode())
         hipLaunchKernelGGL((wopos_block_fwd_kernel<128, 64, 8, true>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.w_down,
                            p.height.w_qkv, p.width.w_qkv, p.w_up, a);
@@ -1555,8 +1548,9 @@ struct BlkBwdWs {
 };
 
 int& block_bwd_mode() {
-    // default OFF until the kernel has been run and timed on the GPU (it is checked on the CPU lane emulator only so far)
-    static int mode = [] { const char* e = getenv("MEDT_BLOCK_BWD"); return (e && e[0] == '1') ? 1 : 0; }();
+    // default since round 5 (first MI355X run: parity green against the reference fixture and the per-stage path, whole-model
+    // fixtures green; profiles/r05_step_ab.json); MEDT_BLOCK_BWD=0 = the six per-stage backward launches
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
     return mode;
 }
 static bool block_bwd_enabled() { return block_bwd_mode() != 0; }
@@ -1591,25 +1585,17 @@ int wopos_block_bwd_launch(const medt_block_desc& d, const medt_block_params& p,
         size_t nrec = 0;
         for (int b = 0; b < 8; ++b) nrec += (size_t)chs8[b] * 8;
         const size_t lds8 = ((size_t)(d.C + 2 * d.width) * 256 + nrec) * sizeof(float);
-        static bool attr8 = false;
-        if (!attr8) {
-            (void)hipFuncSetAttribute((const void*)wopos_block8_bwd_kernel<64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            attr8 = true;
-        }
+        static unsigned char attr8[64];
+        if (int rc8 = lds_opt_in((const void*)wopos_block8_bwd_kernel<64, 32, 4>, attr8, "wopos_block8_bwd")) return rc8;
         hipLaunchKernelGGL((wopos_block8_bwd_kernel<64, 32, 4>), dim3(d.bn_groups), dim3(1024), lds8, s, p.w_down, p.height.w_qkv,
                            p.width.w_qkv, p.w_up, a);
         return launch_status("wopos_block8_bwd");
     }
     const size_t lds = ((size_t)(d.C + 2 * d.width + 2 * d.width) * 64 + 16 * 4 * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wopos_block_bwd_kernel<128, 64, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wopos_block_bwd_kernel<128, 64, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr = true;
-    }
+    static unsigned char attr[2][64];
+    int rca;
+    if ((rca = lds_opt_in((const void*)wopos_block_bwd_kernel<128, 64, 8, false>, attr[0], "wopos_block_bwd")) ||
+        (rca = lds_opt_in((const void*)wopos_block_bwd_kernel<128, 64, 8, true>, attr[1], "wopos_block_bwd"))) return rca;
     if (block_pk_mode())
         hipLaunchKernelGGL((wopos_block_bwd_kernel<128, 64, 8, true>), dim3(d.bn_groups), dim3(1024), lds, s, p.w_down, p.height.w_qkv,
                            p.width.w_qkv, p.w_up, a);

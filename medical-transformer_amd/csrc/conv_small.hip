@@ -664,12 +664,9 @@ int bn_dgrad1x1_small(const medt_conv_desc& d, const float* dy, const float* y, 
     const dim3 grid(d.bn_groups, d.Cin / pl.CT);
 #define MEDT_BND(TT, CP)                                                                                              \
     do {                                                                                                              \
-        static bool attr = false;                                                                                     \
-        if (!attr && pl.lds > 64 * 1024) {   /* more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU) */ \
-            (void)hipFuncSetAttribute((const void*)bn_dgrad1x1_small_kernel<TT, CP>,                                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        static unsigned char attr[64];                                                                                \
+        if (pl.lds > 64 * 1024)              /* more than 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU) */ \
+            if (int rca = lds_opt_in((const void*)bn_dgrad1x1_small_kernel<TT, CP>, attr, "bn_dgrad1x1_small")) return rca; \
         hipLaunchKernelGGL((bn_dgrad1x1_small_kernel<TT, CP>), grid, dim3(TT), pl.lds, s, a);                         \
     } while (0)
 #define MEDT_BND_T(TT)                                                                                                \

@@ -16,7 +16,13 @@ void set_error(const char* fmt, ...) {
 }
 
 bool abl_skip(const char* family) {
-    static const char* env = getenv("MEDT_SKIP");
+    static const char* env = [] {
+        const char* e = getenv("MEDT_SKIP");
+        if (e && *e)
+            fprintf(stderr, "libmedt_hip: MEDT_SKIP=%s -- TIMING EXPERIMENT: these kernel families are NOT launched, every result of "
+                            "this process is garbage\n", e);
+        return e;
+    }();
     if (!env || !*env) return false;
     const size_t n = strlen(family);
     for (const char* p = env; *p;) {
@@ -26,6 +32,20 @@ bool abl_skip(const char* family) {
         p += len + (e ? 1 : 0);
     }
     return false;
+}
+
+int lds_opt_in(const void* kernel, unsigned char (&done)[64], const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev < 64 && done[dev]) return MEDT_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: opt-in for more than 64 KB of dynamic LDS refused on device %d: %s", what, dev, hipGetErrorString(e));
+        return MEDT_ELAUNCH;
+    }
+    if (dev < 64) done[dev] = 1;
+    return MEDT_OK;
 }
 
 int launch_status(const char* what) {

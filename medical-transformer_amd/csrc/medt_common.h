@@ -42,6 +42,9 @@ int  launch_status(const char* what);          // hipGetLastError -> MEDT_ELAUNC
 // TIMING EXPERIMENTS ONLY (scripts/r4_skip.sh): MEDT_SKIP=fam1,fam2 makes the host wrappers of those kernel families return
 // without launching, so the step time that disappears is the family's share of the critical path.  Results are garbage.
 bool abl_skip(const char* family);
+// More than 64 KB of dynamic LDS per workgroup needs an opt-in per kernel (gfx950: 160 KB per CU).  Once per (call site, device):
+// `done` is the call site's static flag array, one byte per device ordinal (racing first calls repeat an idempotent runtime call).
+int lds_opt_in(const void* kernel, unsigned char (&done)[64], const char* what);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int    cdiv(int a, int b) { return (a + b - 1) / b; }

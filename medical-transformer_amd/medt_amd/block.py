@@ -23,7 +23,7 @@ from . import defer as DEFER
 from .axial import _bn_ptrs
 
 ENABLED = os.environ.get("MEDT_BLOCK_FUSED", "1") != "0" and os.environ.get("MEDT_DISABLE_SMALL", "0") != "1"
-BWD_ENABLED = ENABLED and os.environ.get("MEDT_BLOCK_BWD", "0") == "1"     # (the library reads the same variable)
+BWD_ENABLED = ENABLED and os.environ.get("MEDT_BLOCK_BWD", "1") != "0"     # (the library reads the same variable)
 
 
 def _axial_params(att, training) -> L.AxialParams:

@@ -75,6 +75,7 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 // (one work-item runs at a time: read-modify-write is atomic by construction; the ORDER of float atomics is the emulator's)
 #define __HIP_MEMORY_SCOPE_AGENT 0
@@ -128,6 +129,7 @@ static inline int lane_emu_dpp_source(int lane, int ctrl, bool* valid) {
     if (ctrl >= 0x101 && ctrl <= 0x10F) { const int s = r + (ctrl & 15); *valid = s < 16; return row | (s & 15); }   // row_shl
     if (ctrl >= 0x111 && ctrl <= 0x11F) { const int s = r - (ctrl & 15); *valid = s >= 0; return row | (s & 15); }   // row_shr
     if (ctrl >= 0x121 && ctrl <= 0x12F) return row | ((r - (ctrl & 15)) & 15);                                     // row_ror
+    if (ctrl == 0x138) { *valid = lane >= 1; return (lane - 1) & 63; }                                              // wave_shr:1
     if (ctrl == 0x140) return row | (15 - r);                                                                       // row_mirror
     if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));                                                       // row_half_mirror
     abort();

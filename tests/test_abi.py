@@ -81,9 +81,14 @@ def test_block_descriptor_validation(lib):
                 _lib.BlockDesc(64, 64, 32, 4, 4, 8, 1, 16, 1e-5, 0.1)):   # other widths
         assert lib.medt_wopos_block_workspace_bytes(ctypes.byref(bad)) == 0
     assert lib.medt_wopos_block_fwd(ctypes.byref(ok), None, None, None, None, None, 0, None) < 0      # null arguments: refused
-    # the one-launch backward is off until it has been run on the GPU (MEDT_BLOCK_BWD=1): no workspace, the entry refuses
-    if os.environ.get("MEDT_BLOCK_BWD", "0") != "1":
-        assert lib.medt_wopos_block_bwd_workspace_bytes(ctypes.byref(ok)) == 0
+    fused_on = os.environ.get("MEDT_BLOCK_FUSED", "1") != "0" and os.environ.get("MEDT_DISABLE_SMALL", "0") != "1"
+    # the one-launch backward and the 8x8-map kernels: default since round 5, MEDT_BLOCK_BWD=0 / MEDT_BLOCK8=0 switch them off
+    ok8 = _lib.BlockDesc(64, 64, 32, 8, 8, 8, 1, 16, 1e-5, 0.1)            # layer2_p.1 at BASELINE's batch size
+    want_bwd = fused_on and os.environ.get("MEDT_BLOCK_BWD", "1") != "0"
+    want8 = fused_on and os.environ.get("MEDT_BLOCK8", "1") != "0"
+    assert (lib.medt_wopos_block_bwd_workspace_bytes(ctypes.byref(ok)) > 0) == want_bwd
+    assert (lib.medt_wopos_block_workspace_bytes(ctypes.byref(ok8)) > 0) == want8
+    assert (lib.medt_wopos_block_bwd_workspace_bytes(ctypes.byref(ok8)) > 0) == (want8 and want_bwd)
     assert lib.medt_wopos_block_bwd(ctypes.byref(ok), None, None, None, None, None, None, None, None, None, 0, None) < 0
 
 

@@ -105,6 +105,10 @@ CASES = [
     ("dynamic", 16, 32, True, 1, 3, 5),
     ("dynamic", 16, 32, False, 2, 2, 32),
     ("dynamic", 16, 128, False, 1, 1, 6),
+    # round 5: gp = 4 at L = 128 on the sweep (<4, 128, 32>: 32 lanes per sequence) -- layer2.0 of the 256-px networks
+    ("dynamic", 32, 128, False, 1, 2, 6),
+    ("dynamic", 32, 128, True, 2, 1, 8),
+    ("plain", 32, 128, False, 1, 1, 5),
     ("plain", 16, 64, True, 2, 2, 64),
     ("plain", 16, 64, False, 1, 3, 7),
     ("plain", 32, 64, False, 1, 1, 64),
@@ -357,7 +361,7 @@ def test_layer_by_layer_fallback_of_small_layers(device, emulating):
 
 @pytest.mark.parametrize("case", [("dynamic", 16, 64, True, 1, 4, 64), ("dynamic", 32, 32, False, 2, 4, 32),
                                   ("dynamic", 64, 16, True, 1, 2, 16), ("dynamic", 64, 32, False, 2, 2, 32),
-                                  ("dynamic", 128, 16, True, 1, 2, 16)],
+                                  ("dynamic", 128, 16, True, 1, 2, 16), ("dynamic", 32, 128, True, 2, 2, 128)],
                          ids=lambda c: "-".join(str(v) for v in c))
 def test_layer_backward_is_bit_reproducible(case, device):
     """Two runs of the same layer backward give bit-identical gradients -- every one, the relative tables included (the

@@ -136,11 +136,11 @@ def test_fused_block_is_taken_and_counts_one_launch(device):
     torch.cuda.synchronize()
 
 
-# ---- the one-launch BACKWARD (medt_wopos_block_bwd): opt-in (MEDT_BLOCK_BWD=1 for the whole process -- the library reads the
-# variable once) until it has been run and timed on the GPU; verified against the reference fixture on the CPU lane emulator
-# (tests/test_lane_emu.py).  With the variable set, test_block_vs_reference_fixture[one-launch] above also runs through it.
-bwd_opt_in = pytest.mark.skipif(__import__("os").environ.get("MEDT_BLOCK_BWD", "0") != "1",
-                                reason="one-launch block backward is opt-in: MEDT_BLOCK_BWD=1")
+# ---- the one-launch BACKWARD (medt_wopos_block_bwd): the default since round 5 (first MI355X run green; MEDT_BLOCK_BWD=0 for
+# the whole process -- the library reads the variable once -- switches it off).  test_block_vs_reference_fixture[one-launch]
+# above runs through it as well.
+bwd_opt_in = pytest.mark.skipif(__import__("os").environ.get("MEDT_BLOCK_BWD", "1") == "0",
+                                reason="one-launch block backward switched off: MEDT_BLOCK_BWD=0")
 
 
 @bwd_opt_in
@@ -195,9 +195,9 @@ def test_block_backward_is_one_launch_and_takes_the_deposit(device):
     assert H.rel_err(x.grad, dx_plain + extra) < 1e-6
 
 
-# ---- the 8x8-map block kernel (layer2_p.1 of MedT-128), opt-in like the one-launch backward: MEDT_BLOCK8=1 for the whole process
-block8_opt_in = pytest.mark.skipif(__import__("os").environ.get("MEDT_BLOCK8", "0") != "1",
-                                   reason="8x8-map one-launch block forward is opt-in: MEDT_BLOCK8=1")
+# ---- the 8x8-map block kernels (layer2_p.1 of MedT-128): the default since round 5 (MEDT_BLOCK8=0 switches them off)
+block8_opt_in = pytest.mark.skipif(__import__("os").environ.get("MEDT_BLOCK8", "1") == "0",
+                                   reason="8x8-map one-launch block kernels switched off: MEDT_BLOCK8=0")
 
 
 @block8_opt_in
