@@ -61,7 +61,10 @@ def probe_matrix(name: str, numel: int, seed: int) -> torch.Tensor:
 FULL_GRAD_KEYS = ("relative", "f_qr", "f_kr", "f_sv", "f_sve", "bn_similarity.weight", "adjust.weight", "adjust.bias")
 
 
-def _run_reference(model_name, S, N, seed, mode, dtype, variant=0):
+FACTORY_SEED = 3000      # reference train.py:118 (and bench.py): torch.manual_seed(3000) before the model is built
+
+
+def _run_reference(model_name, S, N, seed, mode, dtype, variant=0, factory_init=False):
     """mode: 'train' (batch statistics), 'eval' (no grad), 'evalgrad' (running statistics, with backward).
     variant (float32 noise sampling): 0 = as is; 1 = the images of the batch in reverse order (BatchNorm statistics and
     weight gradients are summed in another order; results are un-permuted); 2 = one host thread (other blocking of the
@@ -69,19 +72,21 @@ def _run_reference(model_name, S, N, seed, mode, dtype, variant=0):
     (x * (1 +- 2^-23) or unchanged, seeded by the variant): aten's reductions give the same bits whatever the thread count,
     so more summation orders are not available -- what IS available is the sensitivity of the float32 computation to
     perturbations of the size of its own rounding, five independent samples of it."""
-    torch.manual_seed(seed)
+    torch.manual_seed(FACTORY_SEED if factory_init else seed)
     ref = ref_loader.factory(model_name)(img_size=S, imgchan=3)
-    ref.load_state_dict(O.randomize_state(ref.state_dict(), seed))
+    if not factory_init:
+        ref.load_state_dict(O.randomize_state(ref.state_dict(), seed))
     if variant >= 3:
         g = torch.Generator().manual_seed(1000 * variant + seed)
         with torch.no_grad():
             for t in list(ref.parameters()) + [b for b in ref.buffers() if b.is_floating_point()]:
                 t.mul_(1.0 + (torch.randint(-1, 2, t.shape, generator=g).to(t.dtype) * 2.0 ** -23))
     ref = ref.to(dtype)
-    for p in ref.parameters():
-        p.requires_grad_(True)           # gates too (train.py:169-171 after epoch 10)
+    if not factory_init:                 # (factory state: the gates stay frozen, as train.py leaves them until epoch 10)
+        for p in ref.parameters():
+            p.requires_grad_(True)       # gates too (train.py:169-171 after epoch 10)
     ref.train(mode == "train")
-    x, y = seeded_input(seed + 1, N, 3, S)
+    x, y = seeded_input(FACTORY_SEED if factory_init else seed + 1, N, 3, S)     # (bench.py's batch on rank 0: the same generator calls)
     flipped = variant == 1
     xin, yin = (x.flip(0), y.flip(0)) if flipped else (x, y)
     if variant >= 3:
@@ -171,14 +176,56 @@ def model_fixture(model_name, S, N, seed, mode):
     return fx
 
 
+def factory_fixture(model_name, S, N):
+    """The state that is actually trained: FACTORY initialisation under torch.manual_seed(3000) (train.py:118 / bench.py), train
+    mode, bench.py's synthetic batch, gates frozen.  Reference float64 logits / loss / gradient summaries, the reference's own
+    float32 noise on this state (eight float32 runs), and a checksum of the initial state_dict so that a consumer can tell
+    that its own same-seed initialisation is the reference's."""
+    seed = FACTORY_SEED
+    ref, x, out, loss = _run_reference(model_name, S, N, seed, "train", torch.float64, factory_init=True)
+    runs32 = [_run_reference(model_name, S, N, seed, "train", torch.float32, v, factory_init=True) for v in range(8)]
+    torch.manual_seed(FACTORY_SEED)
+    init = ref_loader.factory(model_name)(img_size=S, imgchan=3).state_dict()
+    fx = {
+        "meta": np.array([S, N, seed, 1]),
+        "mode": np.array("train"),
+        "x_checksum": np.array([x.double().sum().item(), (x.double() ** 2).sum().item()]),
+        "state_checksum": np.array([sum(v.double().sum().item() for v in init.values() if v.is_floating_point()),
+                                    sum((v.double() ** 2).sum().item() for v in init.values() if v.is_floating_point())]),
+        "logits": out.float().numpy(),
+        "logits_noise_runs": np.array([((r[2] - out).abs().max() / out.abs().max()).item() for r in runs32]),
+        "loss": np.array([loss.item()]),
+    }
+    names, summ, noise, dots, dots_noise = [], [], [], [], []
+    p32x = [dict(r[0].named_parameters()) for r in runs32]
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.reshape(-1)
+        R = probe_matrix(k, g.numel(), seed)
+        gs = [px[k].grad.double().reshape(-1) for px in p32x]
+        names.append(k)
+        summ.append([g.norm().item(), torch.dot(g, R[0]).item()])
+        noise.append([max((gg - g).norm().item() for gg in gs), max(abs(torch.dot(gg - g, R[0]).item()) for gg in gs)])
+        dots.append((R @ g).numpy())
+        dots_noise.append(max((R @ (gg - g)).abs().max().item() for gg in gs))
+    fx["grad_names"] = np.array(names)
+    fx["grad_summary"] = np.array(summ)
+    fx["grad_noise"] = np.array(noise)
+    fx["grad_dots"] = np.array(dots)
+    fx["grad_dots_noise"] = np.array(dots_noise)
+    return fx
+
+
 def sensitivity_fixture(model_name, S, N, seed):
     """How far the REFERENCE's own float64 training-mode logits move when its input image is perturbed by one rounding of a
     given precision (relative +-eps, uniform): the conditioning of the train-mode network (batch-statistic BatchNorm through
     ~100 layers).  eps = 2^-9 is ONE bfloat16 rounding of the input -- what any bf16 storage inside the network amounts to
     at the very least; GPU tests of bf16 storage in training mode are judged against this, not against a fixed tolerance."""
-    torch.manual_seed(seed)
+    torch.manual_seed(FACTORY_SEED if factory_init else seed)
     ref = ref_loader.factory(model_name)(img_size=S, imgchan=3)
-    ref.load_state_dict(O.randomize_state(ref.state_dict(), seed))
+    if not factory_init:
+        ref.load_state_dict(O.randomize_state(ref.state_dict(), seed))
     ref = ref.double()
     ref.train()
     x, _ = seeded_input(seed + 1, N, 3, S)
@@ -340,6 +387,13 @@ def main():
         with open(os.path.join(HERE, "sensitivity_gatedaxialunet_S128_N8.json"), "w") as f:
             json.dump(sensitivity_fixture("gatedaxialunet", 128, 8, 107), f, indent=1)
         print("wrote sensitivity_gatedaxialunet_S128_N8.json")
+    # the trained state itself: factory initialisation under seed 3000, BASELINE configs[2] (MedT bs 4) and configs[1] (gated bs 8)
+    for name, S, N in (("MedT", 128, 4), ("gatedaxialunet", 128, 8)):
+        fn = f"factory_{name}_S{S}_N{N}.npz"
+        if not fn.startswith(only):
+            continue
+        np.savez_compressed(os.path.join(HERE, fn), **factory_fixture(name, S, N))
+        print("wrote", fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KB")
     for name, S, N, seed, mode in model_cases:
         fn = f"model_{name}_S{S}_N{N}_{mode}.npz"
         if not fn.startswith(only):

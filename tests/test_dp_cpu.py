@@ -219,3 +219,151 @@ def test_flatadam_backward_outside_the_slot_window_replaces_the_bucket():
     (a.sum() * 4 + b.sum() * 4).backward()
     opt.pack_gradients()
     assert torch.equal(flat, torch.tensor([4.0, 4, 4, 4, 4])), flat
+
+
+# ------------------------------------------------------------------------------------------------------------------------ #
+# The same, with a REAL model: lib.models.axialnet.gated (ResAxialAttentionUNet of AxialBlock_dynamic: position tables, gates
+# that join the trained set mid-run) at 32 px through the product's own modules,
+# autograd Functions, StepQueue, gradient slots, FlatAdam (medt_adam_step) and the C ABI on the emulated device
+# (tests/emu_device.py: libmedt_emu.so = every kernel source compiled for the CPU lane emulator), two ranks over gloo.
+# ------------------------------------------------------------------------------------------------------------------------ #
+R_STEPS, R_FLIP_AT, R_S, R_LR = 2, 1, 32, 1e-3         # (an emulated pass costs ~20 s whatever the image size: two steps, the gates join at the second)
+
+
+def _emu_lib():
+    import ctypes
+    import test_lane_emu as T
+    from medt_amd import _lib as L
+    lib = ctypes.CDLL(T.build_emulator())
+    for name, (res, args) in L.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def _real_batch(step, rank):
+    from emu_device import DeviceTensor
+    g = torch.Generator().manual_seed(8000 + 10 * step + rank)
+    x = torch.rand(2, 3, R_S, R_S, generator=g)
+    y = torch.randint(0, 2, (2, R_S, R_S), generator=g)
+    return x.as_subclass(DeviceTensor), y.as_subclass(DeviceTensor)
+
+
+def _real_model(seed):
+    import lib as droplib
+    torch.manual_seed(seed)
+    return droplib.models.axialnet.gated(img_size=R_S, imgchan=3).train()
+
+
+def _real_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import medt_amd
+    from emu_device import emulated_device
+    from medt_amd import dp
+    from medt_amd.optim import FlatAdam
+    from medt_amd.trainer import TrainStep
+    with emulated_device(_emu_lib()):
+        model = _real_model(100 + rank)                 # deliberately different replicas before the broadcast
+        dp.broadcast_parameters(model)
+        opt = FlatAdam(list(model.parameters()), lr=R_LR, weight_decay=WD)
+        step = TrainStep(model, opt, medt_amd.cross_entropy, use_graph=False)
+        trace = []
+        for s in range(R_STEPS):
+            if s == R_FLIP_AT:
+                for p in model.parameters():
+                    p.requires_grad = True              # train.py:169-171: the gates join as a second group
+            pre = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+            x, y = _real_batch(s, rank)
+            loss = float(step(x, y).detach())
+            grads = {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+            trace.append((pre, grads, loss))            # grads: the all-reduced SUM (1/world is folded into the Adam kernel)
+        sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        q.put((rank, sd, [g.numel for g in opt.groups], trace if rank == 0 else [t[2] for t in trace]))
+    dist.destroy_process_group()
+
+
+def _real_shard_job(args):
+    """One shard's gradients at the weights rank 0 had BEFORE `step`: the same emulated kernels through plain autograd (no gradient
+    slots, no recorded jobs, no bucket), the shard's own BatchNorm statistics.  (Its own process: an emulated pass takes ~20 s.)"""
+    pre, step, r = args
+    torch.set_num_threads(1)
+    import medt_amd
+    from emu_device import emulated_device
+    with emulated_device(_emu_lib()):
+        model = _real_model(0)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pre.items()})
+        for p in model.parameters():
+            p.requires_grad = True
+        x, y = _real_batch(step, r)
+        loss = medt_amd.cross_entropy(model(x), y)
+        loss.backward()
+        return {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}, float(loss.detach())
+
+
+def test_real_model_data_parallel_world2_on_the_emulated_device():
+    """Whole-network training in batch-statistics mode amplifies rounding by ~1e4 (parity floor), and Adam then turns a
+    noisy small gradient into a full lr step: comparing WEIGHTS after several steps against a separately run expectation tests
+    the conditioning of the network, not the data-parallel code.  So every step is checked on its own, at rank 0's weights:
+    (1) the all-reduced bucket == the sum of the two shards' gradients computed by a single process with plain autograd;
+    (2) the update == Adam on bucket / world (moments tracked here from the buckets), the late-joining gates starting at t = 1;
+    (3) the replicas stay bit-identical; BatchNorm running statistics stay local to the shard."""
+    import test_lane_emu as T
+    T.build_emulator()                                  # once, before the ranks race for it
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, sd0, groups0, trace), (_, sd1, groups1, losses1) = res
+    gate_names = ("f_qr", "f_kr", "f_sve", "f_sv")
+    n_gates = sum(v.size for k, v in sd0.items() if k.split(".")[-1] in gate_names)
+    n_all = sum(v.size for k, v in sd0.items() if "running" not in k and "num_batches" not in k and "flatten_index" not in k)
+    assert n_gates == 4 * 16
+    # two groups on both ranks: everything that had a gradient from step 0, then the gates (4 per attention layer).  (Tensors
+    # that never get a gradient -- MedT's conv1 / adjust_p, SURVEY Q5 -- exist only in the 128-px networks: ToyNet.unused above.)
+    assert groups0 == groups1 == [n_all - n_gates, n_gates], (groups0, n_all, n_gates)
+    for k in sd0:
+        if "running" in k:
+            assert not np.array_equal(sd0[k], sd1[k]) or np.all(sd0[k] == sd0[k].flat[0]), k     # per-shard statistics
+        elif "num_batches" not in k and "flatten_index" not in k:
+            assert np.array_equal(sd0[k], sd1[k]), k                                              # replicas bit-identical
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    m, v, t = {}, {}, {}
+    worst_g = worst_p = 0.0
+    with ctx.Pool(2 * len(trace)) as pool:              # (step, shard) jobs side by side
+        shard = pool.map(_real_shard_job, [(pre, s, r) for s, (pre, _, _) in enumerate(trace) for r in range(2)])
+    if True:
+        for s, (pre, grads, loss0) in enumerate(trace):
+            (g0, l0), (g1, l1) = shard[2 * s], shard[2 * s + 1]
+            want = {k: g0[k] + g1[k] for k in g0}
+            assert abs(l0 - loss0) < 1e-5 * abs(l0) and abs(l1 - losses1[s]) < 1e-5 * abs(l1)
+            trained = {k for k in want if s >= R_FLIP_AT or k.split(".")[-1] not in gate_names}
+            assert set(grads) == trained, set(grads) ^ trained
+            gmax = max(np.abs(want[k]).max() for k in trained)
+            post = trace[s + 1][0] if s + 1 < len(trace) else sd0
+            for k in sorted(trained):
+                # (1) bucket == sum of the shard gradients (other summation order in the recorded weight-gradient jobs: rounding)
+                err = np.abs(grads[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-3 * gmax)
+                worst_g = max(worst_g, err)
+                assert err < 1e-4, (s, k, err)
+                # (2) the Adam update of medt_adam_step on bucket / world
+                g = grads[k].astype(np.float64) / 2 + WD * pre[k].astype(np.float64)
+                m[k] = b1 * m.get(k, 0.0) + (1 - b1) * g
+                v[k] = b2 * v.get(k, 0.0) + (1 - b2) * g * g
+                t[k] = t.get(k, 0) + 1
+                upd = R_LR / (1 - b1 ** t[k]) * m[k] / (np.sqrt(v[k] / (1 - b2 ** t[k])) + eps)
+                perr = np.abs(post[k] - (pre[k] - upd)).max() / R_LR
+                worst_p = max(worst_p, perr)
+                assert perr < 2e-3, (s, k, perr)
+            for k in pre:                               # everything else is untouched by the step
+                if k not in trained and "running" not in k and "num_batches" not in k:
+                    assert np.array_equal(pre[k], post[k]), (s, k)
+    assert t["layer1.0.hight_block.f_qr"] == R_STEPS - R_FLIP_AT and t["conv1.weight"] == R_STEPS
+    print("worst bucket-vs-shard-sum gradient error %.2e (tensor scale); worst update deviation %.2e of one lr step" % (worst_g, worst_p))

@@ -543,3 +543,46 @@ def test_medt_256_train_vs_oracle(device):
     assert int(sd["layer1_p.0.bn1.num_batches_tracked"].item()) == 16
     for p in model.parameters():
         assert p.grad is None or torch.isfinite(p.grad).all()
+
+
+@pytest.mark.parametrize("name,S,N,flat", [("MedT", 128, 4, True), ("gatedaxialunet", 128, 8, False)], ids=["MedT-bs4", "gatedaxialunet-bs8"])
+def test_factory_state_train_parity(name, S, N, flat, device):
+    """Parity at the state that is actually TRAINED and BENCHMARKED: factory initialisation under torch.manual_seed(3000)
+    (reference train.py:118; bench.py), train mode (batch statistics), bench.py's synthetic batch, gates frozen -- against the
+    reference's float64 results for exactly that state (tests/golden/factory_*.npz, make_golden.py::factory_fixture).
+
+    MedT 128 bs 4 (BASELINE configs[2], the headline): logits within north_star's FLAT 1e-3 -- no noise scaling.  The
+    reference's own float32 runs sit at 2.3e-4 ... 6.1e-4 from its float64 on this state (fixture `logits_noise_runs`).
+    gatedaxialunet 128 bs 8 (configs[1]): the reference's own float32 runs are 2.6e-3 ... 4.2e-3 away from its float64 -- a
+    flat 1e-3 is not something any float32 evaluation of that network meets (finding, recorded in DESIGN.md section 4); the
+    product is held to 1.5 x the reference's float32 deviation there and the figure is printed."""
+    fx = H.load_golden(f"factory_{name}_S{S}_N{N}.npz")
+    seed = int(fx["meta"][2])
+    assert seed == 3000
+    torch.manual_seed(seed)
+    model = build(name, S, device)                    # same seed, same constructor order -> the reference's initial state
+    sd = model.state_dict()
+    cs = [sum(v.double().sum().item() for v in sd.values() if v.is_floating_point()),
+          sum((v.double() ** 2).sum().item() for v in sd.values() if v.is_floating_point())]
+    assert abs(cs[0] - fx["state_checksum"][0]) < 1e-6 * abs(fx["state_checksum"][0]) and \
+        abs(cs[1] - fx["state_checksum"][1]) < 1e-6 * fx["state_checksum"][1], "initial state differs from the reference's"
+    x, y = H.seeded_input(seed, N, 3, S)
+    assert abs(x.double().sum().item() - fx["x_checksum"][0]) < 1e-6
+    model.train()
+    out = model(x.to(device))
+    want = torch.from_numpy(fx["logits"])
+    err = H.rel_err(out, want)
+    noise = fx["logits_noise_runs"]
+    print(f"factory state {name} bs {N} train: logits rel err {err:.2e}; the reference's own float32 runs: "
+          f"{noise.min():.2e} ... {noise.max():.2e}")
+    assert err < (1e-3 if flat else max(1e-3, 1.5 * float(noise.max()))), err
+    loss = torch.nn.functional.cross_entropy(out, y.to(device))
+    assert abs(loss.item() - fx["loss"][0]) < 1e-4, (loss.item(), fx["loss"][0])
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    assert {k for k, p in params.items() if p.grad is not None} == set(fx["grad_names"].tolist())      # gates frozen, Q5 tensors unused
+    bad, ratios, _ = check_gradient_summaries(fx, params, seed, "train", KNOISE, TOL)
+    r = np.sort(np.array([v for v, _ in ratios]))
+    print(f"  product error / reference fp32 noise per gradient tensor: median {np.median(r):.2f}, max {r[-1]:.2f} (bound {KNOISE})")
+    assert not bad, bad[:8]

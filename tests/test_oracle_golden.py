@@ -164,3 +164,19 @@ def test_fast_bn_mode_is_the_same_arithmetic():
     for k in a:
         if "running" in k or "num_batches" in k:
             assert H.rel_err(b[k].double(), a[k].double()) < 1e-10, k
+
+
+def test_oracle_at_the_factory_state_matches_reference_fixture():
+    """The state that is actually trained (factory initialisation under seed 3000, train mode, bench.py's batch; fixture generated
+    from the reference by make_golden.py::factory_fixture): the product's module surface gives the reference's initial state
+    (checksum), and the oracle reproduces the reference's float64 logits and loss on it (fixture logits are stored in float32)."""
+    import lib as droplib
+    fx = H.load_golden("factory_MedT_S128_N4.npz")
+    torch.manual_seed(int(fx["meta"][2]))
+    sd = droplib.models.axialnet.MedT(img_size=128, imgchan=3).state_dict()
+    cs = sum(v.double().sum().item() for v in sd.values() if v.is_floating_point())
+    assert abs(cs - fx["state_checksum"][0]) < 1e-9 * abs(fx["state_checksum"][0])
+    x, y = H.seeded_input(3000, 4, 3, 128)
+    out = O.forward("MedT", x.double(), O.clone_state(sd, torch.float64), True)
+    assert H.rel_err(out, fx["logits"]) < 5e-7
+    assert abs(O.log_nll_loss(out, y).item() - fx["loss"][0]) < 1e-9
