@@ -152,7 +152,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
             # its closed-form bn_similarity corrections (attn_bwd_fix_kernel, attn_bwd_relfix_kernel, table sums, finalize);
             # gp > 4 / other lengths: the two generic passes (attn_bwd_stats_kernel + attn_bwd_kernel)
             "bwd_core": {"kernels": ("attn_bwd_sweep_kernel + attn_bwd_fix_kernel + attn_bwd_relfix_kernel + bwd_tables_kernel + "
-                                     "sim_bwd_finalize_kernel" if C // 8 <= 4 and L in (32, 64, 128) and not (C // 8 == 4 and L == 128)
+                                     "sim_bwd_finalize_kernel" if C // 8 <= 4 and L in (32, 64, 128)
                                      else "attn_bwd_stats_kernel + attn_bwd_kernel"),
                          "bytes_per_launch": 10 * C * e * M,
                          "achieved": 10 * C * e * M / t_bwd / 1e9, "frac": 10 * C * e * M / t_bwd / 1e9 / HBM_PEAK_GBPS,
@@ -160,9 +160,11 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
                          "with_gate_gradients": {"launch_ms": t_bwd_gates * 1e3,
                                                  "frac": 10 * C * e * M / t_bwd_gates / 1e9 / HBM_PEAK_GBPS}}}
     tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tf) and (C, L, images) == (16, 64, 256) and e == 4:
+    if os.path.exists(tf) and (C, L, images) in ((16, 64, 256), (32, 128, 128)) and e == 4:
         try:
             tj = json.load(open(tf))
+            if (C, L) == (32, 128):                           # the second shape's figures sit under their own key
+                tj = tj.get("C32_L128", {})
             roof["traffic"] = tj.get("attn_fwd_bytes_per_launch")
             # NOT measured by this run: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) of the same
             # command, collected by scripts/collect_profiles.sh and committed
@@ -295,7 +297,8 @@ def main():
     import medt_amd
     medt_amd.set_activation_dtype(args.dtype)
     if args.roofline_only:
-        print(json.dumps({"roofline": roofline_leg(device)}))
+        # both SURVEY.md 8(d) shapes (their kernels are different template instances: the PMC passes tell them apart by name)
+        print(json.dumps({"roofline": roofline_leg(device), "also": roofline_leg(device, C=32, L=128, images=128, iters=10)}))
         return
 
     from medt_amd import dp
@@ -389,7 +392,10 @@ def main():
             result["roofline"] = roofline_leg(device)
             # SURVEY.md 8(d)'s second scaled shape (256-px inputs: C=32, gp=4, L=128), reported beside the headline one
             other = roofline_leg(device, C=32, L=128, images=128, iters=10)
-            result["roofline"]["also"] = [{k: other[k] for k in ("kernel", "shape", "achieved", "frac", "launch_ms", "valu_tflops")}]
+            # (round 5: with its backward core -- attn_bwd_sweep_kernel<4,128,32>; layer2.0 of the 256-px networks ran the two generic
+            #  passes at 0.4 % of the HBM peak before)
+            result["roofline"]["also"] = [{**{k: other[k] for k in ("kernel", "shape", "achieved", "frac", "launch_ms", "valu_tflops")},
+                                           "traffic": other.get("traffic"), "bwd_core": other["bwd_core"]}]
             # the same layer at the size the timed step runs it (MedT layer1: 4 images, 256 sequences): different kernel
             # variants are dispatched there (attn_fwd3_kernel<2,AXIS,64,EXACT=true>; the scaled shape above runs the
             # 4-rows-per-lane bound-referenced attn_fwd4r_kernel) and the launch is latency-, not bandwidth-bound
