@@ -362,6 +362,9 @@ def main():
                        + ("captured in the hipGraph (with the Adam launch behind it)" if getattr(train_step, "collective_in_graph", False)
                           else "outside the graph") if distributed else None),
         "collective_in_graph": bool(getattr(train_step, "collective_in_graph", False)) if distributed else None,
+        # floats per all-reduce of each parameter group: two-branch networks have [global branch + trunk, local branch], the first
+        # all-reduced where the global branch's backward ends (medt_amd.optim.TWO_BUCKETS)
+        "gradient_buckets": [[hi - lo for lo, hi in g.bounds] for g in opt.groups],
     }
     if rank == 0 and world == 1:
         # BASELINE's second figure, "fwd ms/image": the eval-mode forward of reference test.py:106-119, replayed as a

@@ -118,10 +118,16 @@ class StepQueue:
                 k.clear()
 
 
-def flush_current_stream():
-    """Called where one branch's backward pass ends (ops.ConvBlockFn, cfg.last_of_branch)."""
-    if _current is not None:
-        _current.flush_current_stream()
+def flush_current_stream() -> bool:
+    """Called where one branch's backward pass ends (ops.ConvBlockFn, cfg.last_of_branch).  True: everything the branch
+    recorded has been issued on the current stream (or nothing is ever recorded: immediate launches) -- its parameter gradients
+    are complete in stream order.  False: one shared queue (MEDT_SPLIT_FLUSH=0), flushed at the end of the pass."""
+    if _current is None:
+        return True
+    if not SPLIT:
+        return False
+    _current.flush_current_stream()
+    return True
 
 
 def recording(allow: bool = True):

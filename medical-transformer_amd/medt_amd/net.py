@@ -37,6 +37,15 @@ def _side_stream(device):
     return _side[key]
 
 
+def join_side_stream(device):
+    """Make the current stream wait for everything issued on the branch stream so far.  A forward WITHOUT a backward behind it
+    (trainer.InferStep in train mode) leaves the local branch's recorded bookkeeping -- issued on its stream behind the event the
+    merge waits for -- unjoined; a stream capture must not end like that."""
+    side = _side.get((device.type, device.index))
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+
+
 def _require_device(x):
     if not x.is_cuda:
         raise MedtError("medt_amd runs on MI355X only: got a CPU tensor and there is no CPU fallback "

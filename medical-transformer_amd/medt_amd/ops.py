@@ -177,7 +177,8 @@ class ConvBlockFn(torch.autograd.Function):
         if dres is not None and cfg.res_sink is not None and cfg.res_sink.deposit(dres):
             dres = None
         if cfg.last_of_branch:                         # nothing else of this branch follows: its recorded jobs go out now
-            DEFER.flush_current_stream()
+            if DEFER.flush_current_stream():
+                OPT.branch_done(0)                     # ... and (data parallel) its gradient bucket goes on the wire
         return (dx, ret[0], ret[1], ret[2], ret[3], dres, None, None)
 
 

@@ -25,6 +25,12 @@ import torch.distributed as dist
 from . import _lib as L
 
 FORCE_COLLECTIVES = os.environ.get("MEDT_FORCE_DIST") == "1"      # run the all-reduce even with one rank (tests)
+# Two gradient buckets for two-branch networks (MedT's global / local branch): the global branch's backward ends first, its
+# bucket is all-reduced there, under the local branch's remaining backward chain.  MEDT_TWO_BUCKETS=0: one all-reduce per group
+# after the whole backward (rounds 1-4).
+TWO_BUCKETS = os.environ.get("MEDT_TWO_BUCKETS", "1") != "0"
+EARLY_ENABLED = True   # TrainStep clears it while capturing a graph that must not contain collectives
+_OPEN = None           # the FlatAdam whose step is open (between zero_grad() and pack_gradients()), for branch_done()
 
 
 def collectives_needed() -> bool:
@@ -73,11 +79,26 @@ def accumulate(slot: GradSlot, tmp):
     slot.view.add_(tmp)
 
 
+def branch_done(segment: int = 0):
+    """Called by the backward where one branch of a two-branch network has finished (ops.ConvBlockFn, cfg.last_of_branch,
+    after that stream's recorded weight-gradient jobs have been issued): its gradient bucket can go on the wire now."""
+    if _OPEN is not None and TWO_BUCKETS:
+        _OPEN.early_allreduce(segment)
+
+
 class _Group:
     def __init__(self, params: List[torch.nn.Parameter], owner):
         dev = params[0].device
+        # bucket layout: segment 0 (reduced early: the branch whose backward ends first + the trunk) in front, then the rest;
+        # inside a segment the order of model.parameters().  Adam is elementwise: the layout changes no result.
+        seg = owner.segment_of
+        params = sorted(params, key=seg) if seg is not None else params          # (stable)
         self.params = params
         self.numel = sum(p.numel() for p in params)
+        n0 = sum(p.numel() for p in params if seg is not None and seg(p) == 0)
+        self.bounds = [(0, self.numel)] if n0 in (0, self.numel) else [(0, n0), (n0, self.numel)]
+        self.seg_params = [[p for p in params if seg is None or (seg(p) == 0) == (k == 0)] for k in range(len(self.bounds))]
+        self.reduced = [-1] * len(self.bounds)                # optimizer stamp of the step a segment was last all-reduced in
         self.flat_p = torch.empty(self.numel, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(self.numel, device=dev, dtype=torch.float32)
@@ -101,7 +122,10 @@ class _Group:
 
 
 class FlatAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, segment_of=None):
+        """segment_of: parameter -> 0 (bucket that can be all-reduced as soon as branch_done() is called) or 1; None = one
+        bucket.  TrainStep sets it from the model (set_segments_from_model) before the first step."""
+        self.segment_of = segment_of
         self.params = [p for p in params]
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.groups: List[_Group] = []
@@ -113,10 +137,22 @@ class FlatAdam:
     def zero_grad(self, set_to_none: bool = True):
         """Start a new step: `.grad` of every parameter is reset to None, as torch.optim does.  The slot-aware backward
         kernels write into the slots; pack_gradients() then points `.grad` back at them."""
+        global _OPEN
         self.stamp += 1
         self.step_open = True
+        _OPEN = self
         for p in self.params:
             p.grad = None
+
+    def set_segments_from_model(self, model):
+        """Two-branch networks (medt_net: every module of the local branch is named *_p, reference axialnet.py:557-600): the
+        global branch and the trunk (decoderf, adjust) form segment 0, the local branch segment 1.  Must be called before the
+        first step (the flat layout is fixed when a group is adopted); single-branch networks keep one bucket."""
+        if self.groups or not TWO_BUCKETS:
+            return
+        local = {id(p) for name, m in model.named_children() if name.endswith("_p") for p in m.parameters()}
+        if local and len(local) < len(self.params):
+            self.segment_of = lambda p: 1 if id(p) in local else 0
 
     def _adopt_new(self):
         new = [p for p in self.params if p.grad is not None and id(p) not in self._member]
@@ -139,8 +175,11 @@ class FlatAdam:
             # travelled through autograd's `.grad`.  The slots still carry the PREVIOUS step's stamp and contents; a new
             # stamp makes them stale, so a fresh `.grad` tensor below REPLACES the slot instead of being added to it.
             self.stamp += 1
+        global _OPEN
         self._adopt_new()
         self.step_open = False
+        if _OPEN is self:
+            _OPEN = None
         for g in self.groups:
             src, dst = [], []
             for p in g.params:
@@ -173,7 +212,31 @@ class FlatAdam:
         """Sum the flat buckets over ranks (the 1/world factor is folded into the Adam kernel)."""
         if collectives_needed():
             for g in self.groups:
-                dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM)
+                todo = [k for k in range(len(g.bounds)) if g.reduced[k] != self.stamp]
+                if len(todo) == len(g.bounds):
+                    dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM)          # nothing went out early: one collective
+                else:
+                    for k in todo:
+                        dist.all_reduce(g.flat_g[g.bounds[k][0]:g.bounds[k][1]], op=dist.ReduceOp.SUM)
+                g.reduced = [-1] * len(g.bounds)               # (a replayed graph calls this again without a zero_grad())
+
+    def early_allreduce(self, segment: int = 0):
+        """All-reduce one segment of every bucket NOW (on the current stream, in the middle of the backward pass), provided its
+        gradients are complete: every parameter of the segment has had its slot written by a backward kernel of this step (no
+        gradient still travelling through autograd's `.grad`, no first-step adoption pending).  Otherwise nothing happens and
+        allreduce() covers the segment as before.  Every rank takes the same decision: it depends on the model only."""
+        if not (collectives_needed() and self.step_open and EARLY_ENABLED):
+            return
+        # (parameters that join this step -- the gates at epoch 10 -- form a NEW group at pack_gradients(); the existing groups'
+        #  layout does not change, and allreduce() covers whatever did not go out here)
+        for g in self.groups:
+            if len(g.bounds) < 2 or g.reduced[segment] == self.stamp:
+                continue
+            if any(p._medt_gslot.stamp != self.stamp or p.grad is not None for p in g.seg_params[segment]):
+                continue
+            lo, hi = g.bounds[segment]
+            dist.all_reduce(g.flat_g[lo:hi], op=dist.ReduceOp.SUM)
+            g.reduced[segment] = self.stamp
 
     # ---- update ----------------------------------------------------------------------
     def _launch_adam(self, g: _Group, gscale: float):

@@ -36,6 +36,8 @@ class TrainStep:
             raise ValueError("TrainStep: at least one warm-up step is needed before capture (FlatAdam adopts the "
                              "parameters and re-points their storage on the first step)")
         self.model, self.opt = model, optimizer
+        if hasattr(optimizer, "set_segments_from_model"):
+            optimizer.set_segments_from_model(model)          # two-branch networks: two gradient buckets (optim.TWO_BUCKETS)
         self.criterion = criterion if criterion is not None else cross_entropy
         self.use_graph = use_graph
         self.warmup = warmup
@@ -130,8 +132,10 @@ class TrainStep:
         # INTO the graph: one replay per step, no host round trip between backward, collective and update.
         # MEDT_GRAPH_COLLECTIVE=0, or a process group whose collectives cannot be captured (gloo), leaves them outside.
         in_graph = single or (os.environ.get("MEDT_GRAPH_COLLECTIVE", "1") != "0" and self._collective_capturable())
+        from . import optim as OPT
         for attempt in (0, 1):
             graph = torch.cuda.CUDAGraph()
+            OPT.EARLY_ENABLED = in_graph                      # no early bucket all-reduce inside a graph without collectives
             try:
                 # thread_local: runtime calls of OTHER host threads (a data-loader / pin-memory thread of the caller's own)
                 # do not invalidate this capture; the prefetcher of medt_amd.data additionally holds GPU_CAPTURE_LOCK
@@ -148,6 +152,8 @@ class TrainStep:
                 in_graph = False                              # the collective refused capture: keep it outside the graph
                 torch.cuda.synchronize()
                 self._restore(snap)
+            finally:
+                OPT.EARLY_ENABLED = True
         self.collective_in_graph = in_graph and not single
         return graph, static_x, static_y, loss.detach(), in_graph, getattr(loss, "_medt_ce_out", None)
 
@@ -216,6 +222,9 @@ class InferStep:
                 self._queue.drop = not self.model.training
                 with self._queue.active():
                     out = self.model(x)
+                if self.model.training:        # the branch stream's running-statistics launches: joined (no backward does it)
+                    from .net import join_side_stream
+                    join_side_stream(x.device)
             counts = None
             if target is not None:
                 from .ops import seg_counts

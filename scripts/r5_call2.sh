@@ -20,7 +20,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m256 -- p
 cp $(ls -S $O/m256/*/*_kernel_stats.csv | head -1) $O/m256_kernel_stats.csv; rm -rf $O/m256
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -- python bench.py --roofline-only > $O/roofline_prof.log 2>&1
 cp $(ls -S $O/roofline/*/*_kernel_stats.csv | head -1) $O/roofline_kernel_stats.csv; rm -rf $O/roofline
-tail -1 $O/roofline_prof.log > $O/roofline_only.json
+grep '^{"roofline' $O/roofline_prof.log | tail -1 > $O/roofline_only.json
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --roofline-only > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --roofline-only > $O/pmc_write.log 2>&1
 python scripts/r5_traffic.py $O/pmc_fetch $O/pmc_write $O/roofline_only.json "$(cat .commit_stamp 2>/dev/null)" > $O/roofline_traffic.json 2>$O/traffic.err; tail -2 $O/traffic.err

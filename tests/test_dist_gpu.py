@@ -43,6 +43,9 @@ def test_forced_collectives_over_rccl_match_single_process():
                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", *ARGS], env)
     assert plain["collective"] is None and "nccl" in dist_["collective"]
     assert dist_["collective_in_graph"] is True, dist_["collective"]       # RCCL all-reduce + Adam are graph nodes
+    # round 5: two buckets -- [global branch + trunk | local branch] -- the first all-reduced where the global backward ends
+    if os.environ.get("MEDT_TWO_BUCKETS", "1") != "0":
+        assert len(dist_["gradient_buckets"][0]) == 2 and sum(dist_["gradient_buckets"][0]) == 1524546, dist_["gradient_buckets"]
     # the collective costs one more graph node, not a host round trip: the forced-RCCL step stays within 4 % of the plain one
     # (measured 1.9 % in round 3; both are medians of five 20-step windows on the same box)
     assert dist_["ms_per_step"] <= 1.04 * plain["ms_per_step"], (plain["ms_per_step"], dist_["ms_per_step"])
@@ -117,7 +120,9 @@ for mode in ("graph_refused", "graph_in", "eager"):
     if mode == "graph_refused":
         assert calls["refused"] == 1, calls                    # the first capture attempt hit the refusal ...
         assert step.collective_in_graph is False               # ... the second left the collective outside the graph
-        assert calls["eager"] == 2 + 3, calls                  # warm-up steps + one per replayed step, behind the replay
+        # warm-up: the adoption step (one collective) + one step with two buckets (global segment early, local segment late);
+        # then one per replayed step, behind the replay (no early all-reduce inside a graph that must not hold collectives)
+        assert calls["eager"] == (3 if OPT.TWO_BUCKETS else 2) + 3, calls
     if mode == "graph_in":
         assert step.collective_in_graph is True
     g = opt.groups[0]

@@ -367,3 +367,102 @@ def test_real_model_data_parallel_world2_on_the_emulated_device():
                     assert np.array_equal(pre[k], post[k]), (s, k)
     assert t["layer1.0.hight_block.f_qr"] == R_STEPS - R_FLIP_AT and t["conv1.weight"] == R_STEPS
     print("worst bucket-vs-shard-sum gradient error %.2e (tensor scale); worst update deviation %.2e of one lr step" % (worst_g, worst_p))
+
+
+# ------------------------------------------------------------------------------------------------------------------------ #
+# Two gradient buckets (optim.TWO_BUCKETS): a two-branch network whose backward functions follow the gradient-slot protocol of
+# medt_amd.ops (claim the slot, write the parameter gradient directly, call branch_done() where the first branch ends), two
+# ranks over gloo: the early all-reduce of segment 0 + the late one of segment 1 == one all-reduce of everything.
+# ------------------------------------------------------------------------------------------------------------------------ #
+class _SlotLinearFn(torch.autograd.Function):
+    """y = x @ w.T with the weight gradient written straight into FlatAdam's slot when one is live (what ConvBlockFn does)."""
+
+    @staticmethod
+    def forward(ctx, x, w, last_of_branch):
+        from medt_amd import optim as OPT
+        ctx.save_for_backward(x, w)
+        ctx.slot, ctx.last = OPT.grad_slot(w), last_of_branch
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from medt_amd import optim as OPT
+        x, w = ctx.saved_tensors
+        dw, ret = dy.t() @ x, None
+        slot = OPT.live(ctx.slot)
+        if slot is not None:
+            dst, direct = OPT.claim(slot)
+            dst.copy_(dw) if direct else OPT.accumulate(slot, dw)
+        else:
+            ret = dw
+        if ctx.last:
+            OPT.branch_done(0)
+        return dy @ w, ret, None
+
+
+class _TwoBranch(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a1, self.a2 = torch.nn.Linear(6, 6, bias=False), torch.nn.Linear(6, 3, bias=False)          # "global" branch
+        self.b1_p, self.b2_p = torch.nn.Linear(6, 6, bias=False), torch.nn.Linear(6, 3, bias=False)      # "local" branch (*_p)
+        self.trunk = torch.nn.Linear(3, 2, bias=False)
+
+    def forward(self, x):
+        xa = x.clone().requires_grad_(True)              # (so that a1's backward -- the last node of its branch -- runs)
+        ga = _SlotLinearFn.apply(torch.tanh(_SlotLinearFn.apply(xa, self.a1.weight, True)), self.a2.weight, False)
+        gb = _SlotLinearFn.apply(torch.tanh(_SlotLinearFn.apply(x.clone().requires_grad_(True), self.b1_p.weight, False)), self.b2_p.weight, False)
+        return _SlotLinearFn.apply(ga + gb, self.trunk.weight, False)
+
+
+def _two_bucket_worker(rank, world, port, q, two):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from medt_amd import dp, optim as OPT
+    from medt_amd.trainer import TrainStep
+    OPT.TWO_BUCKETS = two
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, op=None, **k: (calls.append(t.numel()), real(t, op=op, **k))[1]
+    torch.manual_seed(5)
+    model = _TwoBranch()
+    dp.broadcast_parameters(model)
+    opt = _make_cpu_adam()(list(model.parameters()), lr=LR, weight_decay=WD)
+    step = TrainStep(model, opt, F.cross_entropy, use_graph=False)
+    per_step = []
+    for s in range(3):
+        g = torch.Generator().manual_seed(900 + 10 * s + rank)
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 2, (8,), generator=g)
+        calls.clear()
+        step(x, y)
+        per_step.append(list(calls))
+    q.put((rank, {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}, per_step,
+           [tuple(g.bounds) for g in opt.groups]))
+    dist.destroy_process_group()
+
+
+def _run_two_bucket(two):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_bucket_worker, args=(r, 2, port, q, two)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_gradient_buckets_early_allreduce_world2():
+    one, two = _run_two_bucket(False), _run_two_bucket(True)
+    n_a, n_b, n_t = 36 + 18, 36 + 18, 6
+    # one bucket: a single collective of everything per step
+    assert one[0][2] == one[1][2] == [[n_a + n_b + n_t]] * 3 and one[0][3] == [((0, n_a + n_b + n_t),)]
+    # two buckets: layout [global + trunk | local]; step 0 adopts (gradients through autograd: one collective); from step 1 on
+    # the global segment goes out first (branch_done in a1's backward), the local one after the backward
+    assert two[0][3] == two[1][3] == [((0, n_a + n_t), (n_a + n_t, n_a + n_b + n_t))]
+    assert two[0][2] == two[1][2] == [[n_a + n_b + n_t], [n_a + n_t, n_b], [n_a + n_t, n_b]], two[0][2]
+    for k in one[0][1]:
+        assert np.array_equal(two[0][1][k], two[1][1][k]), k                     # replicas bit-identical
+        assert np.array_equal(two[0][1][k], one[0][1][k]), k                     # == the single-bucket run, bit for bit
