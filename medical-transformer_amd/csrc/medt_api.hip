@@ -377,13 +377,22 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
                                  gr->bn_sim_weight, gr->bn_sim_bias, s, relfix_q))) return rc;
     // bn_qkv backward, qkv_transform backward
-    if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
-                              w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
-    if (g.bf16) {       // bf16 storage: materialise the bn_qkv backward in fp32, then the plain 1x1 dgrad / wgrad
-        if ((rc = bn_bwd_apply_raw_bf16(w.dqkv, qkv_raw, w.coef_qkv, g.N, 2 * g.C, g.HW, g.groups, s))) return rc;
+    static const bool bf16_fused = [] { const char* e = getenv("MEDT_BF16_FIN_APPLY"); return !(e && e[0] == '0'); }();
+    if (g.bf16 && bf16_fused && (long)g.N * 2 * g.C <= 65535) {
+        // bf16 storage: the finalisation and the bn_qkv backward materialised in fp32 in ONE launch, then the plain 1x1 dgrad / wgrad
+        if ((rc = bn_bwd_fin_apply_bf16(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
+                                        w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, w.dqkv, qkv_raw, g.N, g.HW, s))) return rc;
         bq_raw = nullptr;
         bq_coef = nullptr;
+    } else {
+        if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
+                                  w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
+        if (g.bf16) {   // (MEDT_BF16_FIN_APPLY=0: round 4's two launches)
+            if ((rc = bn_bwd_apply_raw_bf16(w.dqkv, qkv_raw, w.coef_qkv, g.N, 2 * g.C, g.HW, g.groups, s))) return rc;
+            bq_raw = nullptr;
+            bq_coef = nullptr;
+        }
     }
     if ((rc = conv1x1_bwd_data(w.dqkv, bq_raw, bq_coef, p->w_qkv, dx, g.N, g.C, 2 * g.C, g.HW, g.groups, s)))
         return rc;

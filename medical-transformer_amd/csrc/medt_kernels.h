@@ -37,6 +37,9 @@ int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, fl
 // d[i] = c0*d[i] + c1*raw[i] + c2 per (group, channel) with raw stored as bfloat16: materialises the bn_qkv backward
 // so the fp32 1x1 dgrad / wgrad kernels run without their (raw, coef) operands
 int bn_bwd_apply_raw_bf16(float* d, const float* raw_bf16, const float* coef, int N, int CH, int HW, int groups, hipStream_t s);
+int bn_bwd_fin_apply_bf16(const float* partials, int ppg, int groups, int CH, double count, float dscale, BnStats st,
+                          const float* weight, int training, float* coef, float* dweight, float* dbias, float* d,
+                          const float* raw_bf16, int N, int HW, hipStream_t s);
 // partials [n][ptile][OC][2] of [sum dstk, sum dstk*xhat] with dstk = dy (un-pooled, unscaled)
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st,
                         float* partials, hipStream_t s);

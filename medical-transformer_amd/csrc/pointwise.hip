@@ -662,6 +662,57 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_bwd_apply_raw_bf16_kernel(flo
     d[idx] = fmaf(cf[0], d[idx], fmaf(cf[1], bf16_bits_to_f32(raw[idx]), cf[2]));
 }
 
+// bf16 storage (BASELINE configs[1]), round 5: bn_bwd_finalize AND the application of bn_qkv's backward to dqkv in ONE launch (the
+// bn_fin_apply pattern of the forward): every workgroup re-derives the coefficients of ITS (BatchNorm group, channel) from the
+// partial rows (one wave, double accumulation, bn_bwd_coef as in the finalize kernel), applies them to its slice of the plane
+//     d <- coef0 * d + coef1 * raw(bf16) + coef2
+// and the first workgroup of every channel also does the finalize kernel's job (coefficients of all groups, parameter gradients).
+// Round 4 ran bn_bwd_finalize and bn_bwd_apply_raw_bf16 as two launches per attention layer: bf16 storage was 4-5 % SLOWER than
+// fp32 (one more dependent launch per layer on the chain); with this kernel both storage types have the same launch count.
+#define MEDT_BFA_PPT 4
+__global__ __launch_bounds__(MEDT_THREADS) void bn_bwd_fin_apply_bf16_kernel(
+    const float* __restrict__ partials, int ppg, int groups, int CH, double count, float dscale, BnStats st,
+    const float* __restrict__ weight, int training, float* __restrict__ coef, float* __restrict__ dweight,
+    float* __restrict__ dbias, float* __restrict__ d, const unsigned short* __restrict__ raw, int HW, int npg) {
+    MEDT_STATIC_SHARED float cf[4];
+    const int ch = blockIdx.y % CH, n = blockIdx.y / CH, grp = n / npg;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = lane; p < ppg; p += 64) {
+            const float* q = partials + ((size_t)(grp * ppg + p) * CH + ch) * 2;
+            s1 += (double)q[0];
+            s2 += (double)q[1];
+        }
+        s1 = wave_sum_d(s1) * dscale;
+        s2 = wave_sum_d(s2) * dscale;
+        if (lane == 0)
+            bn_bwd_coef(s1, s2, count, dscale, st.mean[grp * CH + ch], st.rstd[grp * CH + ch], weight[ch], training, cf);
+    }
+    __syncthreads();
+    const float c0 = cf[0], c1 = cf[1], c2 = cf[2];
+    const size_t base = (size_t)blockIdx.y * HW;
+#pragma unroll
+    for (int k = 0; k < MEDT_BFA_PPT; ++k) {
+        const int i = (blockIdx.x * MEDT_BFA_PPT + k) * MEDT_THREADS + threadIdx.x;
+        if (i < HW) d[base + i] = fmaf(c0, d[base + i], fmaf(c1, bf16_bits_to_f32(raw[base + i]), c2));
+    }
+    // the finalize kernel's own outputs, once per channel (the weight-gradient jobs of other storage modes read `coef`; the
+    // parameter gradients are this layer's bn_qkv.weight / .bias gradients)
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x < 64)
+        bn_bwd_finalize_body(ch, partials, ppg, groups, CH, count, dscale, st, weight, training, coef, dweight, dbias);
+}
+
+int bn_bwd_fin_apply_bf16(const float* partials, int ppg, int groups, int CH, double count, float dscale, BnStats st,
+                          const float* weight, int training, float* coef, float* dweight, float* dbias, float* d,
+                          const float* raw_bf16, int N, int HW, hipStream_t s) {
+    if ((long)N * CH > 65535) { set_error("bn_bwd_fin_apply_bf16: %d x %d planes exceed the grid", N, CH); return MEDT_EUNSUPPORTED; }
+    hipLaunchKernelGGL(bn_bwd_fin_apply_bf16_kernel, dim3(cdiv(HW, MEDT_THREADS * MEDT_BFA_PPT), N * CH), dim3(MEDT_THREADS), 0, s,
+                       partials, ppg, groups, CH, count, dscale, st, weight, training, coef, dweight, dbias, d,
+                       reinterpret_cast<const unsigned short*>(raw_bf16), HW, N / groups);
+    return launch_status("bn_bwd_fin_apply_bf16");
+}
+
 int bn_bwd_apply_raw_bf16(float* d, const float* raw_bf16, const float* coef, int N, int CH, int HW, int groups, hipStream_t s) {
     const size_t total = (size_t)N * CH * HW;
     hipLaunchKernelGGL(bn_bwd_apply_raw_bf16_kernel, dim3((unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS)),
