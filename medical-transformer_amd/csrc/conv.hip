@@ -704,6 +704,18 @@ static int wgrad_chunk_grouped(long NP) {
     return QS;
 }
 
+// chunks of the 16-byte body: 256 positions (two 128-position steps) while that gives at most MEDT_WG4_CHUNKS (16) chunks, up to
+// MEDT_WG4_QMAX (1024) positions; never fewer positions per chunk than the scalar policy (so never more slabs)
+static int wgrad_chunk_v4(long NP) {
+    static const int target = [] { const char* e = getenv("MEDT_WG4_CHUNKS"); return e ? atoi(e) : 16; }();
+    static const int qmax = [] { const char* e = getenv("MEDT_WG4_QMAX"); return e ? atoi(e) : 1024; }();
+    int QS = 256;
+    while (QS < qmax && (NP + QS - 1) / QS > target) QS <<= 1;
+    while ((NP + QS - 1) / QS > 64) QS <<= 1;
+    const int QG = wgrad_chunk_grouped(NP);
+    return QS > QG ? QS : QG;
+}
+
 int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo) {      // slabs of scratch: either mode
     const long NP = (long)N * Ho * Wo;
     const int QS = wgrad_chunk(Cout, Cin * K * K, NP), QG = wgrad_chunk_grouped(NP);
@@ -718,7 +730,11 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     const long NP = (long)N * Ho * Wo;
     const int Ktot = Cin * K * K;
     const bool mfma = conv_use_mfma(Cin, Cout, K, stride, NP) && Cout >= 64;
-    const int QS = (q && !mfma) ? wgrad_chunk_grouped(NP) : wgrad_chunk(Cout, Ktot, NP);
+    // recorded 1x1 stride-1 problems: the 16-byte position-axis body (conv_mfma.hip) with chunks of 256 ... 1024 positions --
+    // 4x fewer workgroups and partial slabs than the scalar-load body's 64 ... 256 (never more slabs than the workspace was
+    // sized for: conv2d_bwd_weight_splits takes the scalar policy's count, which is the larger)
+    const bool v4 = q && !mfma && conv_wgrad_v4_ok(dy, raw, x, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad);
+    const int QS = v4 ? wgrad_chunk_v4(NP) : ((q && !mfma) ? wgrad_chunk_grouped(NP) : wgrad_chunk(Cout, Ktot, NP));
     const int splits = (int)((NP + QS - 1) / QS);
     const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
     if (splits == 1) scratch = dw;                         // a single slab is the result: no reduction pass
@@ -739,7 +755,7 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     if (q) {                                               // deferred: grouped with the other layers' at the flush
         if (K != 1 && K != 3 && K != 7) { set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K); return MEDT_EUNSUPPORTED; }
         q->wgrad.push_back(WJob{dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, N / groups,
-                                cdiv(Cout, 64), cdiv(Ktot, 64), splits, K});
+                                cdiv(Cout, 64), cdiv(Ktot, 64), splits, K, v4 ? 1 : 0});
         if (splits > 1) q->reduce.push_back(RJob{scratch, dw, splits, Cout * Ktot});
         return MEDT_OK;
     }

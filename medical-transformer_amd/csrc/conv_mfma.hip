@@ -693,6 +693,128 @@ __device__ __forceinline__ void conv_wgrad_mfma_body32(
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------ //
+// Round 5: the recorded weight gradients of the 1x1 stride-1 layers (every qkv_transform, conv_down, conv_up: most of a flush)
+// with 16-BYTE loads along the position axis.  dW[o][c] = sum_q dY[o][q] X[c][q] is a plain A B^T with both operands contiguous
+// in q.  The scalar-load body above handles 64 positions per global round trip and spends ~1500 SALU instructions per wave on
+// per-row address arithmetic, bounds branches and coefficient loads (SQ counters, profiles/r04_step_pmc.json: SALU > VALU, 1.25
+// workgroups per CU in flight: the CU's one scalar unit is the bottleneck of a launch of ~4600 short workgroups).  Here:
+//   * a step is 128 positions: thread t moves float4 number (t & 31) of rows (t >> 5) + 8 i -- 4 + 4 (dY, raw) + 8 (X) loads of
+//     16 bytes per thread and step, unconditional (clamped row / position, zeroed by select), saddr + 32-bit voffset addressing;
+//   * the MFMA fragments are read as ds_read_b128: lane group g of MFMA j in a 16-position block takes position 4 g + j for BOTH
+//     operands (the contraction does not care about the order), so one 16-byte LDS read feeds four MFMAs;
+//   * chunks are 256 ... 1024 positions (2 ... 8 steps), 4x fewer workgroups and 4x fewer partial slabs for the row reduction.
+// ------------------------------------------------------------------------------------------------------------------------ //
+constexpr int V4_PS = 128, V4_LD = V4_PS + 4;
+__device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__ dy, const float* __restrict__ raw,
+                                                       const float* __restrict__ coef, const float* __restrict__ x,
+                                                       float* __restrict__ scratch, int N, int Cin, int HW, int Cout, int QS,
+                                                       int npg, int bx, int by, int bz, float* smem) {
+    float* A = smem;                              // [32][V4_LD]
+    float* B = smem + 32 * V4_LD;                 // [64][V4_LD]
+    const int o0 = bx * 32, c0 = by * 64;
+    const unsigned NP = (unsigned)N * HW;
+    const unsigned q_begin = (unsigned)bz * QS;
+    const unsigned q_end = q_begin + QS < NP ? q_begin + QS : NP;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = tid >> 5, col4 = tid & 31;
+    // element offsets of this thread's rows inside one image's (Cout | Cin, HW) block; rows past the end are clamped and zeroed
+    unsigned aoff[4], boff[8], acf[4];
+    bool aok[4], bok[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = o0 + lrow + 8 * i;
+        aok[i] = o < Cout;
+        const int oc = aok[i] ? o : Cout - 1;
+        aoff[i] = (unsigned)oc * HW;
+        acf[i] = (unsigned)oc * 3;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c0 + lrow + 8 * i;
+        bok[i] = c < Cin;
+        boff[i] = (unsigned)(bok[i] ? c : Cin - 1) * HW;
+    }
+    f32x4 acc[2];
+    acc[0] = (f32x4)(0.f);
+    acc[1] = (f32x4)(0.f);
+    f32x4 ra[4], rb[8];
+    const char* dyb = reinterpret_cast<const char*>(dy);
+    const char* rwb = reinterpret_cast<const char*>(raw);
+    const char* xb = reinterpret_cast<const char*>(x);
+    auto fetch = [&](unsigned q0) {
+        const unsigned q = q0 + 4u * col4;
+        const bool qok = q < q_end;                                  // (HW % 4 == 0: the four positions share the image)
+        const unsigned qc = qok ? q : q_begin;
+        const unsigned n = qc / (unsigned)HW, p = qc - n * HW;
+        const unsigned abase = n * (unsigned)Cout * HW + p, bbase = n * (unsigned)Cin * HW + p;
+        f32x4 rr[4];
+        float cf[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(dyb + (size_t)((abase + aoff[i]) * 4u));
+        if (coef) {
+            const float* cg = coef + (size_t)(n / (unsigned)npg) * Cout * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rr[i] = *reinterpret_cast<const f32x4*>(rwb + (size_t)((abase + aoff[i]) * 4u));
+                cf[i][0] = cg[acf[i]]; cf[i][1] = cg[acf[i] + 1]; cf[i][2] = cg[acf[i] + 2];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)((bbase + boff[i]) * 4u));
+        MEDT_SCHED_FENCE();                                          // every load of the step is in flight before the first use
+        if (coef) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = fmaf(cf[i][0], ra[i][e], fmaf(cf[i][1], rr[i][e], cf[i][2]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!(qok && aok[i])) ra[i] = (f32x4)(0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!(qok && bok[i])) rb[i] = (f32x4)(0.f);
+    };
+    const int rblk = wv & 1, t0 = 2 * (wv >> 1);
+    const bool wave_rows = o0 + 16 * rblk < Cout;
+    const int tcols = Cin - c0 >= 64 ? 4 : (Cin - c0 + 15) / 16;
+    const float* afrag = A + (16 * rblk + (lane & 15)) * V4_LD + 4 * (lane >> 4);
+    const float* bfrag = B + (t0 * 16 + (lane & 15)) * V4_LD + 4 * (lane >> 4);
+    if (q_begin < q_end) fetch(q_begin);
+    for (unsigned q0 = q_begin; q0 < q_end; q0 += V4_PS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(A + (lrow + 8 * i) * V4_LD + 4 * col4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(B + (lrow + 8 * i) * V4_LD + 4 * col4) = rb[i];
+        __syncthreads();
+        if (q0 + V4_PS < q_end) fetch(q0 + V4_PS);                   // flies during the MFMAs below
+        if (wave_rows && t0 < tcols) {
+#pragma unroll
+            for (int blk = 0; blk < V4_PS / 16; ++blk) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(afrag + 16 * blk);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bfrag + 16 * blk);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b0[jj], acc[0], 0, 0, 0);
+                if (t0 + 1 < tcols) {
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bfrag + 16 * V4_LD + 16 * blk);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b1[jj], acc[1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)bz * Cout * Cin;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * rblk + (lane >> 4) * 4 + r, k = c0 + (t0 + tt) * 16 + (lane & 15);
+            if (o < Cout && k < Cin) out[(size_t)o * Cin + k] = acc[tt][r];
+        }
+}
+
 template <int K>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ raw, const float* __restrict__ coef,
@@ -760,19 +882,27 @@ struct WJobP {                       // WJob packed for the kernel-argument bloc
     const float *dy, *raw, *coef, *x;
     float* scratch;
     int N, Cin, H, W, Cout, Ho, Wo, QS, npg, gz;
-    unsigned char stride, pad, K, unused;
+    unsigned char stride, pad, K, v4;           // v4: conv_wgrad_k1v4_body32 (1x1, stride 1, 16-byte aligned rows)
 };
 using WBatch = JobBatch<WJobP, 42>;
 static_assert(sizeof(WBatch) <= 4000, "job table must fit the kernel-argument block");
 template <int TO>
 __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(WBatch b) {
-    MEDT_STATIC_SHARED float A[TO][65];
-    MEDT_STATIC_SHARED float B[64][65];
+    // one LDS block for both tile movers: A[TO][65] | B[64][65] of the scalar-load bodies, A[32][132] | B[64][132] of the 16-byte one
+    MEDT_STATIC_SHARED __attribute__((aligned(16))) float smem[(TO == 32 ? 96 * V4_LD : (TO + 64) * 65)];
+    float (*A)[65] = reinterpret_cast<float (*)[65]>(smem);
+    float (*B)[65] = reinterpret_cast<float (*)[65]>(smem + TO * 65);
     const int j = find_job(b, blockIdx.x);
     const WJobP& w = b.job[j];
     const int local = blockIdx.x - b.start[j];
     const int gx = (w.Cout + TO - 1) / TO, gy = (w.Cin * w.K * w.K + 63) / 64;
     const int bx = local % gx, t = local / gx, by = t % gy, bz = t / gy;
+    if constexpr (TO == 32) {
+        if (w.v4) {
+            conv_wgrad_k1v4_body32(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H * w.W, w.Cout, w.QS, w.npg, bx, by, bz, smem);
+            return;
+        }
+    }
 #define MEDT_WG_BODY(KV)                                                                                                 \
     do {                                                                                                                 \
         if constexpr (TO == 64)                                                                                          \
@@ -786,6 +916,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(W
     else if (w.K == 3) MEDT_WG_BODY(3);
     else MEDT_WG_BODY(7);
 #undef MEDT_WG_BODY
+}
+
+// The 16-byte body's preconditions (the chunk policy of conv.hip asks before it sizes the job's chunks)
+bool conv_wgrad_v4_ok(const float* dy, const float* raw, const float* x, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+                      int K, int stride, int pad) {
+    static const bool off = [] { const char* e = getenv("MEDT_WG_V4"); return e && e[0] == '0'; }();
+    static const bool to64 = [] { const char* e = getenv("MEDT_WG_TILE"); return e && atoi(e) == 64; }();
+    static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
+    if (off || to64 || valu || K != 1 || stride != 1 || pad != 0 || Ho != H || Wo != W || (H * W) % 4) return false;
+    if ((((uintptr_t)dy | (uintptr_t)raw | (uintptr_t)x) & 15) != 0) return false;
+    const size_t HW = (size_t)H * W;
+    return (size_t)N * Cout * HW * 4 < 0xffffffffull && (size_t)N * Cin * HW * 4 < 0xffffffffull;      // 32-bit byte offsets
 }
 
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
@@ -817,13 +959,132 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
             fprintf(stderr, "  wjob K%d Cout %d Cin %d HoWo %dx%d N %d QS %d grid %dx%dx%d\n", w.K, w.Cout, w.Cin, w.Ho, w.Wo,
                     w.N, w.QS, w.gx, w.gy, w.gz);
         b.job[b.n] = WJobP{w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.QS, w.npg, w.gz,
-                           (unsigned char)w.stride, (unsigned char)w.pad, (unsigned char)w.K, 0};
+                           (unsigned char)w.stride, (unsigned char)w.pad, (unsigned char)w.K, (unsigned char)(to == 32 && w.v4)};
         b.start[b.n] = blocks;
         blocks += cdiv(w.Cout, to) * w.gy * w.gz;
         if (++b.n == 42) { int rc = launch(); if (rc) return rc; }
     }
     if (b.n) { int rc = launch(); if (rc) return rc; }
     return MEDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------ //
+// Round 5: the THREE kinds of recorded MFMA weight gradients of a flush in ONE launch.  The tail of the local branch's backward
+// ran conv_wgrad_mfma_grouped (63 us), conv3x3_rows16_wgrad (53 us) and conv_wgrad_mfma_batch (18 us) back to back on one
+// stream -- each of them latency-bound with 1-2 resident waves per SIMD (SQ counters: the grouped kernel keeps 1.25 workgroups per
+// CU in flight, the LDS-patch kernel waits on its next tile two thirds of the time), none depending on another.  Side by side in
+// one grid they fill each other's gaps: block -> job by prefix sums over a mixed job table (the long LDS-patch workgroups first,
+// then the few-tile problems, then the 32 x 64 tiles longest chunk first).  Same bodies, same arithmetic, same slabs.
+// ------------------------------------------------------------------------------------------------------------------------ //
+constexpr int TAIL_R16 = 2, TAIL_MW = 3, TAIL_W = 36, TAIL_MAXJ = TAIL_R16 + TAIL_MW + TAIL_W;
+struct TailBatch {
+    int n;
+    int start[TAIL_MAXJ + 1];
+    unsigned char kind[TAIL_MAXJ];           // 0: LDS-patch (rows16), 1: 64 x 64 tiles of a dedicated problem, 2: 32 x 64 grouped tile
+    unsigned char idx[TAIL_MAXJ];            // index in the kind's own table
+    R16WJob r16[TAIL_R16];
+    MWJob mw[TAIL_MW];
+    WJobP w[TAIL_W];
+};
+static_assert(sizeof(TailBatch) <= 4000, "job table must fit the kernel-argument block");
+__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_tail_kernel(TailBatch b) {
+    MEDT_STATIC_SHARED float smem[2 * 64 * 65];                        // the largest of the three bodies' LDS tiles
+    static_assert(2 * 64 * 65 >= 64 * R16_DST + 16 * R16_WCST, "LDS-patch tiles fit");
+    const int j = find_job(b, blockIdx.x);
+    const int r = blockIdx.x - b.start[j], k = b.kind[j], i = b.idx[j];
+    if (k == 0) {
+        const R16WJob& jb = b.r16[i];
+        conv3x3_rows16_wgrad_body(jb, r % jb.gx, (r / jb.gx) % jb.gy, r / (jb.gx * jb.gy), smem, smem + 64 * R16_DST);
+    } else if (k == 1) {
+        const MWJob& m = b.mw[i];
+        float (*A)[65] = reinterpret_cast<float (*)[65]>(smem);
+        float (*B)[65] = reinterpret_cast<float (*)[65]>(smem + 64 * 65);
+        const int bx = r % m.gx, by = (r / m.gx) % m.gy, bz = r / (m.gx * m.gy);
+        if (m.K == 1)
+            conv_wgrad_mfma_body<1>(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.stride, m.pad,
+                                    m.QS, m.npg, bx, by, bz, A, B);
+        else
+            conv_wgrad_mfma_body<3>(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.stride, m.pad,
+                                    m.QS, m.npg, bx, by, bz, A, B);
+    } else {
+        const WJobP& w = b.w[i];
+        float (*A)[65] = reinterpret_cast<float (*)[65]>(smem);
+        float (*B)[65] = reinterpret_cast<float (*)[65]>(smem + 32 * 65);
+        const int gx = (w.Cout + 31) / 32, gy = (w.Cin * w.K * w.K + 63) / 64;
+        const int bx = r % gx, t = r / gx, by = t % gy, bz = t / gy;
+        if (w.K == 1)
+            conv_wgrad_mfma_body32<1>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, w.pad,
+                                      w.QS, w.npg, bx, by, bz, A, B);
+        else if (w.K == 3)
+            conv_wgrad_mfma_body32<3>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, w.pad,
+                                      w.QS, w.npg, bx, by, bz, A, B);
+        else
+            conv_wgrad_mfma_body32<7>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, w.pad,
+                                      w.QS, w.npg, bx, by, bz, A, B);
+    }
+}
+
+// r16 / mw: the recorded dedicated problems (defer.h MJob) that take the LDS-patch kernel / the 64 x 64 tile kernel; w: the grouped
+// jobs.  Returns MEDT_EUNSUPPORTED (nothing launched) when the mix does not fit one job table -- the caller then issues the three
+// kinds separately as before.  Grouped jobs beyond the table's 36 go out in a second, grouped launch.
+int conv_wgrad_tail(const MJob* const* r16, int n_r16, const MJob* const* mw, int n_mw, const WJob* w, int n_w, hipStream_t s) {
+    // (to be measured: the LDS-patch body needs 213 + 40 registers, so the merged grid holds 2 workgroups per CU where the grouped
+    //  tiles alone hold 6 -- opt-in until the A/B is in)
+    static const bool off = [] { const char* e = getenv("MEDT_WGRAD_TAIL"); return !(e && e[0] == '1'); }();
+    static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
+    static const bool to64 = [] { const char* e = getenv("MEDT_WG_TILE"); return e && atoi(e) == 64; }();
+    if (off || valu || to64 || n_r16 > TAIL_R16 || n_mw > TAIL_MW || n_w <= 0 || n_r16 + n_mw == 0) return MEDT_EUNSUPPORTED;
+    for (int i = 0; i < n_w; ++i)
+        if (w[i].K != 1 && w[i].K != 3 && w[i].K != 7) return MEDT_EUNSUPPORTED;
+    for (int i = 0; i < n_mw; ++i)
+        if (mw[i]->K != 1 && mw[i]->K != 3) return MEDT_EUNSUPPORTED;
+    const bool skip_m = abl_skip((n_r16 ? r16[0] : mw[0])->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g");   // (timing experiments)
+    if (skip_m) return MEDT_EUNSUPPORTED;
+    std::vector<int> order(n_w);
+    for (int j = 0; j < n_w; ++j) order[j] = j;
+    auto cost = [&](int j) { return (long)((w[j].QS + 63) / 64) * (w[j].K == 1 ? 2 : 3); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cost(a) > cost(c); });
+    TailBatch b;
+    b.n = 0;
+    int blocks = 0;
+    auto add = [&](int kind, int idx, int nblocks) {
+        b.kind[b.n] = (unsigned char)kind;
+        b.idx[b.n] = (unsigned char)idx;
+        b.start[b.n++] = blocks;
+        blocks += nblocks;
+    };
+    for (int i = 0; i < n_r16; ++i) {
+        const MJob& m = *r16[i];
+        R16WJob& j = b.r16[i];
+        j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
+        j.Cin = m.Cin; j.H = m.H; j.Cout = m.Cout; j.tiles_per_split = m.QS / 64; j.ptiles = m.N * m.H / 4; j.npg = m.npg;
+        j.gx = cdiv(m.Cout, 64); j.gy = m.Cin / 16; j.gz = m.splits;
+        add(0, i, j.gx * j.gy * j.gz);
+    }
+    for (int i = 0; i < n_mw; ++i) {
+        const MJob& m = *mw[i];
+        MWJob& j = b.mw[i];
+        j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
+        j.N = m.N; j.Cin = m.Cin; j.H = m.H; j.W = m.W; j.Cout = m.Cout; j.Ho = m.Ho; j.Wo = m.Wo; j.stride = m.stride;
+        j.pad = m.pad; j.QS = m.QS; j.npg = m.npg; j.K = m.K;
+        j.gx = cdiv(m.Cout, 64); j.gy = cdiv(m.Cin * m.K * m.K, 64); j.gz = m.splits;
+        add(1, i, j.gx * j.gy * j.gz);
+    }
+    const int n_in = n_w < TAIL_W ? n_w : TAIL_W;
+    for (int i = 0; i < n_in; ++i) {
+        const WJob& q = w[order[i]];
+        b.w[i] = WJobP{q.dy, q.raw, q.coef, q.x, q.scratch, q.N, q.Cin, q.H, q.W, q.Cout, q.Ho, q.Wo, q.QS, q.npg, q.gz,
+                       (unsigned char)q.stride, (unsigned char)q.pad, (unsigned char)q.K, 0};
+        if (q.v4) return MEDT_EUNSUPPORTED;        // (the merged launch has the scalar-load tile movers only)
+        add(2, i, cdiv(q.Cout, 32) * q.gy * q.gz);
+    }
+    b.start[b.n] = blocks;
+    hipLaunchKernelGGL(conv_wgrad_tail_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+    int rc = launch_status("conv_wgrad_tail");
+    if (rc || n_in == n_w) return rc;
+    std::vector<WJob> rest;
+    for (int i = n_in; i < n_w; ++i) rest.push_back(w[order[i]]);
+    return conv_wgrad_grouped(rest.data(), (int)rest.size(), s);
 }
 
 bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stride, int pad, int QS) {

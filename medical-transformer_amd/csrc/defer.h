@@ -48,6 +48,7 @@ struct WJob {                        // conv_wgrad_body<K, 64, 64> over a (gx, g
     const float *dy, *raw, *coef, *x;
     float* scratch;
     int N, Cin, H, W, Cout, Ho, Wo, stride, pad, QS, npg, gx, gy, gz, K;
+    int v4;                          // 1: the 16-byte position-axis body (conv_wgrad_v4_ok; QS is a multiple of 128 then)
 };
 
 struct MJob {                        // conv_wgrad_mfma: the dedicated MFMA weight-gradient kernels (LDS-patch kernel of the 16-wide
@@ -93,10 +94,14 @@ int reduce_rows_grouped(const RJob* jobs, int n, hipStream_t s);
 int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s);
 int axial_attn_bwd_relfix_grouped(const RelfixJob* jobs, int n, hipStream_t s);
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);            // MFMA tiles (conv_mfma.hip)
+bool conv_wgrad_v4_ok(const float* dy, const float* raw, const float* x, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
+                      int K, int stride, int pad);
 int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s);       // VALU tiles (conv.hip), MEDT_WGRAD_VALU=1
 bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stride, int pad, int QS);
 int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s);   // LDS-patch kernel of the 16-wide maps, <= 4 problems per launch
 int conv_wgrad_mfma_batch(const MJob* const* jobs, int n, hipStream_t s);       // generic MFMA tile kernel (K = 1 | 3), <= 4 problems per launch
+// all three kinds in one launch (conv_mfma.hip); MEDT_EUNSUPPORTED = nothing launched, issue them separately
+int conv_wgrad_tail(const MJob* const* r16, int n_r16, const MJob* const* mw, int n_mw, const WJob* w, int n_w, hipStream_t s);
 
 // Job table passed by value in the kernel arguments (< 4 KB): block b belongs to job j with start[j] <= b < start[j+1].
 template <class J, int MAXJ>

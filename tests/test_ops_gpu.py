@@ -318,3 +318,71 @@ def test_gradient_fan_in_through_sink(k_final, device):
         return x.grad.clone()
 
     _cmp(run(True), run(False), 1e-6, "fan-in")
+
+
+# The recorded (grouped) weight gradients the way a training step takes them: parameter gradients in FlatAdam's slots, the
+# weight-gradient jobs recorded into a StepQueue and issued by its flush -- conv_wgrad_mfma_grouped_kernel.  Round 5: 1x1 stride-1
+# problems with 16-byte-aligned rows take the 16-byte position-axis body (conv_wgrad_k1v4_body32: 128-position steps, chunks of
+# 256 ... 1024 positions); everything else the scalar-load bodies.  Against fp64 torch.
+RECORDED_CASES = [
+    # Cin, Cout, K, stride, pad, bn, N, S, groups
+    (32, 16, 1, 1, 0, True, 2, 16, 1),        # conv_down: one chunk pair, BatchNorm backward applied on load
+    (16, 32, 1, 1, 0, True, 4, 8, 2),         # two BatchNorm groups inside one chunk (per-lane coefficient group)
+    (20, 24, 1, 1, 0, True, 3, 6, 3),         # ragged: 20 / 24 channels, 108 positions (a partial 128-position step), 3 groups
+    (72, 40, 1, 1, 0, False, 2, 10, 1),       # two k-tiles (72 input channels), 40 output channels (a partial row block), no BN
+    (128, 64, 1, 1, 0, True, 64, 4, 16),      # layer3_p.1-3 conv_down at BASELINE size: 1024 positions = 4 chunks of 256
+    (16, 32, 1, 1, 0, True, 16, 32, 1),       # 16384 positions: 16 chunks of 1024 (8 steps each)
+    (8, 8, 1, 1, 0, True, 2, 3, 1),           # 3x3 maps: 9 positions per image, not a multiple of 4 -> the scalar-load body
+    (32, 64, 1, 2, 0, True, 2, 16, 1),        # stride 2 -> the scalar-load body
+    (16, 16, 3, 1, 1, True, 2, 8, 1),         # 3x3 -> the scalar-load body
+]
+
+
+@pytest.mark.parametrize("case", RECORDED_CASES, ids=lambda c: "-".join(str(int(v)) for v in c))
+def test_recorded_weight_gradient(case, device):
+    from medt_amd import ops
+    from medt_amd.defer import StepQueue
+    from medt_amd.optim import FlatAdam
+    Cin, Cout, K, stride, pad, has_bn, N, S, groups = case
+    torch.manual_seed(Cin * 100 + Cout + K + S)
+    conv = nn.Conv2d(Cin, Cout, K, stride=stride, padding=pad, bias=False)
+    bn = nn.BatchNorm2d(Cout) if has_bn else None
+    if bn is not None:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+    x = torch.randn(N, Cin, S, S)
+    So = (S + 2 * pad - K) // stride + 1
+    dout = torch.randn(N, Cout, So, So)
+    conv64, bn64 = copy.deepcopy(conv).double(), (copy.deepcopy(bn).double() if bn is not None else None)
+    y64 = ref_conv_block(x.double(), conv64, bn64, None, True, True, groups)
+    (y64 * dout.double()).sum().backward()
+    convd, bnd = copy.deepcopy(conv).to(device), (copy.deepcopy(bn).to(device) if bn is not None else None)
+    params = [convd.weight] + ([bnd.weight, bnd.bias] if bnd is not None else [])
+    opt = FlatAdam(params, lr=0.0)
+    xd, dd = x.to(device), dout.to(device)
+    if device.type == "cpu":                              # the emulated device (pytest --emulate)
+        from emu_device import DeviceTensor
+        xd, dd = xd.as_subclass(DeviceTensor), dd.as_subclass(DeviceTensor)
+
+    def fwd_bwd(q=None):
+        opt.zero_grad()
+        y = ops.conv_block(xd, convd, bnd, None, True, True, groups)
+        if q is not None:
+            q.flush()                                     # the forward's recorded statistics: backward reads them (TrainStep does this)
+        (y * dd).sum().backward()
+    fwd_bwd()                                            # adoption step: gradients through autograd, immediate launches
+    opt.pack_gradients()
+    immediate = convd.weight.grad.detach().clone()
+    q = StepQueue()
+    with q.active():
+        fwd_bwd(q)
+        assert q.pending() > 0                            # the weight gradient (and its slab reduction) were recorded
+    opt.pack_gradients()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    _cmp(convd.weight.grad, conv64.weight.grad, what="recorded dw")
+    _cmp(convd.weight.grad, immediate, tol=2e-5, what="recorded vs immediate dw")
+    if bnd is not None:
+        gs = max(bn64.weight.grad.abs().max().item(), bn64.bias.grad.abs().max().item())
+        assert (bnd.weight.grad.double().cpu() - bn64.weight.grad).abs().max().item() < TOL * gs
