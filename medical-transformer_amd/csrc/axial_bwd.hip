@@ -890,6 +890,11 @@ static bool sweep_enabled() {
 
 }  // namespace
 
+// every (channels per head, length, lanes per sequence) the sweep is compiled for
+#define MEDT_SWEEP_INSTANCES(X)                                                                                          \
+    X(2, 32, 8) X(2, 64, 16) X(2, 128, 16) X(4, 32, 8) X(4, 64, 16) X(4, 128, 32) X(8, 32, 16) X(8, 16, 16) X(16, 16, 16)         \
+    X(2, 32, 16) X(2, 64, 32) X(2, 128, 32) X(4, 32, 16) X(4, 64, 32)
+
 // Plan: lanes per sequence, waves per workgroup, tiles, persistent workgroups.  Returns false when the generic two-pass
 // kernels of axial_core.hip have to run (other lengths, per-sequence gates, MEDT_BWD_SWEEP=0).
 bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
@@ -908,6 +913,13 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     if ((size_t)g.N * 2 * g.C * g.HW * 4 > 0xffffffffull) return false;
     static const int env_nw = [] { const char* e = getenv("MEDT_BWD_NW"); return e ? atoi(e) : 0; }();
     static const int env_cap = [] { const char* e = getenv("MEDT_BWD_CAP"); return e ? atoi(e) : 2048; }();
+    // Round 5: few sequences (the layers inside the networks: 128 - 256 sequences x 8 heads) leave half of the chip's 1024 SIMDs
+    // without a wave and every wave alone on its SIMD -- the launch is one wave's latency.  Twice the lanes per sequence then:
+    // half the key columns per lane (the row loop's body halves, its per-row bookkeeping does not) on twice the waves.
+    // MEDT_BWD_WIDE=0: the lane counts tuned on the bandwidth shape (rounds 3 / 4) everywhere.
+    static const int wide = [] { const char* e = getenv("MEDT_BWD_WIDE"); return e ? atoi(e) : 1; }();      // 2: wherever compiled
+    const bool has_wide = (g.gp == 2 || g.gp == 4) && ((g.L == 64 && ls == 16) || (g.L == 32 && ls == 8) || (g.gp == 2 && g.L == 128 && ls == 16));
+    if (wide && has_wide && (wide == 2 || (long)g.groups * g.G * cdiv(g.spg, 64 / ls) < 1024)) ls *= 2;
     const int spw = 64 / ls;
     int nw = g.axis == 0 ? 4 : 2;
     // small problems: as many workgroups as there are sequences to give them
@@ -923,10 +935,11 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS * FIX_PPT);
     const int hq = g.hq, np = hq * (hq + 1) / 2;
     p->npg_floats = 2 * (np + hq);
-    if (g.gp == 2) p->lds = g.L == 32 ? sweep_lds_bytes<2, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<2, 64, 16>(nw) : sweep_lds_bytes<2, 128, 16>(nw));
-    else if (g.gp == 4) p->lds = g.L == 32 ? sweep_lds_bytes<4, 32, 8>(nw) : (g.L == 64 ? sweep_lds_bytes<4, 64, 16>(nw) : sweep_lds_bytes<4, 128, 32>(nw));
-    else if (g.gp == 8) p->lds = g.L == 32 ? sweep_lds_bytes<8, 32, 16>(nw) : sweep_lds_bytes<8, 16, 16>(nw);
-    else p->lds = sweep_lds_bytes<16, 16, 16>(nw);
+    p->lds = 0;
+#define MEDT_SWEEP_LDS(GPv, Lv, LSv) if (g.gp == GPv && g.L == Lv && ls == LSv) p->lds = sweep_lds_bytes<GPv, Lv, LSv>(nw);
+    MEDT_SWEEP_INSTANCES(MEDT_SWEEP_LDS)
+#undef MEDT_SWEEP_LDS
+    if (!p->lds) return false;
     return p->lds <= 160 * 1024;
 }
 
@@ -955,16 +968,11 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
         if (gt) hipLaunchKernelGGL((attn_bwd_sweep_kernel<GPv, Lv, LSv, true>), grid, block, p.lds, s, a);            \
         else hipLaunchKernelGGL((attn_bwd_sweep_kernel<GPv, Lv, LSv, false>), grid, block, p.lds, s, a);              \
     } while (0)
-    if (g.gp == 2 && g.L == 32) MEDT_SWEEP(2, 32, 8);
-    else if (g.gp == 2 && g.L == 64) MEDT_SWEEP(2, 64, 16);
-    else if (g.gp == 2 && g.L == 128) MEDT_SWEEP(2, 128, 16);
-    else if (g.gp == 4 && g.L == 32) MEDT_SWEEP(4, 32, 8);
-    else if (g.gp == 4 && g.L == 64) MEDT_SWEEP(4, 64, 16);
-    else if (g.gp == 4 && g.L == 128) MEDT_SWEEP(4, 128, 32);
-    else if (g.gp == 8 && g.L == 32) MEDT_SWEEP(8, 32, 16);
-    else if (g.gp == 8 && g.L == 16) MEDT_SWEEP(8, 16, 16);
-    else if (g.gp == 16 && g.L == 16) MEDT_SWEEP(16, 16, 16);
-    else { set_error("attn_bwd_sweep: no instantiation for gp=%d L=%d", g.gp, g.L); return MEDT_EUNSUPPORTED; }
+    bool launched = false;
+#define MEDT_SWEEP_CASE(GPv, Lv, LSv) if (!launched && g.gp == GPv && g.L == Lv && p.LS == LSv) { MEDT_SWEEP(GPv, Lv, LSv); launched = true; }
+    MEDT_SWEEP_INSTANCES(MEDT_SWEEP_CASE)
+#undef MEDT_SWEEP_CASE
+    if (!launched) { set_error("attn_bwd_sweep: no instantiation for gp=%d L=%d LS=%d", g.gp, g.L, p.LS); return MEDT_EUNSUPPORTED; }
 #undef MEDT_SWEEP
     return launch_status("attn_bwd_sweep_kernel");
 }

@@ -777,8 +777,6 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
             if (!(qok && bok[i])) rb[i] = (f32x4)(0.f);
     };
     const int rblk = wv & 1, t0 = 2 * (wv >> 1);
-    const bool wave_rows = o0 + 16 * rblk < Cout;
-    const int tcols = Cin - c0 >= 64 ? 4 : (Cin - c0 + 15) / 16;
     const float* afrag = A + (16 * rblk + (lane & 15)) * V4_LD + 4 * (lane >> 4);
     const float* bfrag = B + (t0 * 16 + (lane & 15)) * V4_LD + 4 * (lane >> 4);
     if (q_begin < q_end) fetch(q_begin);
@@ -789,22 +787,32 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
         for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(B + (lrow + 8 * i) * V4_LD + 4 * col4) = rb[i];
         __syncthreads();
         if (q0 + V4_PS < q_end) fetch(q0 + V4_PS);                   // flies during the MFMAs below
-        if (wave_rows && t0 < tcols) {
+        // UNCONDITIONAL, straight-line MFMA section: rows past Cout / Cin are zero rows of the tiles, so the waves and column blocks
+        // that have nothing to add multiply zeros (the matrix pipe is < 5 % busy in this kernel).  With `if (t0 + 1 < tcols)` around
+        // the second tile's MFMAs hipcc (ROCm 7.2) carried acc[0] around the loop through a v_accvgpr_mov copy placed in the loop's
+        // back-edge block, two wait states behind the last v_mfma that writes it -- a gfx950 hazard it only accounts for inside a
+        // basic block: the copy read a stale fourth register and every output row 4 m + 3 of single-block tiles came out wrong ON
+        // THE MI355X (the CPU lane emulator knows nothing of ISA hazards and passed; tests/test_ops_gpu.py::
+        // test_recorded_weight_gradient caught it, scripts/r5_dbg_v4.py + profiles/r05_v4_hazard.txt pinned it down).
 #pragma unroll
-            for (int blk = 0; blk < V4_PS / 16; ++blk) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(afrag + 16 * blk);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bfrag + 16 * blk);
+        for (int blk = 0; blk < V4_PS / 16; ++blk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(afrag + 16 * blk);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bfrag + 16 * blk);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bfrag + 16 * V4_LD + 16 * blk);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b0[jj], acc[0], 0, 0, 0);
-                if (t0 + 1 < tcols) {
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bfrag + 16 * V4_LD + 16 * blk);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b1[jj], acc[1], 0, 0, 0);
-                }
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b0[jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b1[jj], acc[1], 0, 0, 0);
             }
         }
         __syncthreads();
     }
+    // (the accumulators are read in another basic block than the one that issues the last v_mfma: keep the matrix pipe's write-back
+    //  latency between them explicitly -- see the hazard note above)
+    MEDT_SCHED_FENCE();
+    __builtin_amdgcn_s_nop(15);
+    __builtin_amdgcn_s_nop(15);
+    MEDT_SCHED_FENCE();
     float* out = scratch + (size_t)bz * Cout * Cin;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)

@@ -131,7 +131,8 @@ class TrainStep:
         # the communicator exists, which the eager warm-up steps above guarantee) and the Adam launch behind it are captured
         # INTO the graph: one replay per step, no host round trip between backward, collective and update.
         # MEDT_GRAPH_COLLECTIVE=0, or a process group whose collectives cannot be captured (gloo), leaves them outside.
-        in_graph = single or (os.environ.get("MEDT_GRAPH_COLLECTIVE", "1") != "0" and self._collective_capturable())
+        in_graph = single or (os.environ.get("MEDT_GRAPH_COLLECTIVE", "1") != "0" and self._collective_capturable()
+                              and self._collective_capture_probe(static_x.device))
         from . import optim as OPT
         for attempt in (0, 1):
             graph = torch.cuda.CUDAGraph()
@@ -156,6 +157,22 @@ class TrainStep:
                 OPT.EARLY_ENABLED = True
         self.collective_in_graph = in_graph and not single
         return graph, static_x, static_y, loss.detach(), in_graph, getattr(loss, "_medt_ce_out", None)
+
+    @staticmethod
+    def _collective_capture_probe(device):
+        """Capture ONE tiny all-reduce in a throw-away graph: a process group whose collectives refuse stream capture raises here,
+        in the capturing thread, where the capture can be unwound cleanly.  (Since round 5 the step's first collective is issued
+        from inside the backward pass -- optim.branch_done, autograd's engine thread, other streams still forked: a refusal there
+        cannot be unwound, the capture stays active and the next capture_begin fails.)"""
+        t = torch.zeros(8, device=device)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        except RuntimeError:
+            torch.cuda.synchronize()
+            return False
+        return True
 
     @staticmethod
     def _collective_capturable():

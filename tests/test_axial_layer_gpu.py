@@ -359,6 +359,23 @@ def test_layer_by_layer_fallback_of_small_layers(device, emulating):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
+def test_narrow_sweep_instances_on_the_test_shapes(device, emulating):
+    """Round 5: launches of fewer than 1024 waves take the sweep with twice the lanes per sequence (<2,64,32>, <4,64,32>,
+    <2,32,16>, <4,32,16>, <2,128,32>) -- which is every test shape.  MEDT_BWD_WIDE=0 forces the lane counts of the bandwidth
+    shapes (<2,64,16>, <4,64,16>, <2,32,8>, <4,32,8>, <2,128,16>) onto the same parity and bit-reproducibility tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEDT_BWD_WIDE="0")
+    sel = "(test_layer_vs_oracle and (dynamic or plain) and train) or test_layer_backward_is_bit_reproducible"
+    if emulating:
+        sel = "test_layer_vs_oracle and train and (dynamic-16-32-True or dynamic-32-64-False or plain-16-64-False)"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_axial_layer_gpu.py"), "-k", sel] + (["--emulate"] if emulating else []),
+                       env=env, capture_output=True, text=True, timeout=7000 if emulating else 900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
 @pytest.mark.parametrize("case", [("dynamic", 16, 64, True, 1, 4, 64), ("dynamic", 32, 32, False, 2, 4, 32),
                                   ("dynamic", 64, 16, True, 1, 2, 16), ("dynamic", 64, 32, False, 2, 2, 32),
                                   ("dynamic", 128, 16, True, 1, 2, 16), ("dynamic", 32, 128, True, 2, 2, 128)],
