@@ -809,10 +809,11 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
     }
     // (the accumulators are read in another basic block than the one that issues the last v_mfma: keep the matrix pipe's write-back
     //  latency between them explicitly -- see the hazard note above)
+#ifndef MEDT_LANE_EMU
     MEDT_SCHED_FENCE();
-    __builtin_amdgcn_s_nop(15);
-    __builtin_amdgcn_s_nop(15);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     MEDT_SCHED_FENCE();
+#endif
     float* out = scratch + (size_t)bz * Cout * Cin;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)

@@ -112,7 +112,6 @@ static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.f / sqrtf(x); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
-static inline void __builtin_amdgcn_s_nop(int) {}
 
 // ---- synchronisation -------------------------------------------------------------------------------------------------------
 static inline void __syncthreads() { lane_emu::block_barrier(); }
