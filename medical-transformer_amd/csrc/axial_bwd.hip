@@ -917,9 +917,13 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     // without a wave and every wave alone on its SIMD -- the launch is one wave's latency.  Twice the lanes per sequence then:
     // half the key columns per lane (the row loop's body halves, its per-row bookkeeping does not) on twice the waves.
     // MEDT_BWD_WIDE=0: the lane counts tuned on the bandwidth shape (rounds 3 / 4) everywhere.
-    static const int wide = [] { const char* e = getenv("MEDT_BWD_WIDE"); return e ? atoi(e) : 1; }();      // 2: wherever compiled
+    // gp = 4: the wide instances everywhere -- <4,64,16> / <4,32,8> need more than the 256 registers two resident workgroups leave
+    // a lane (244 / 228 bytes of scratch), <4,64,32> / <4,32,16> take 164 (measured: gatedaxialunet bs 8 4.071 -> 4.022 ms/step, MedT-256
+    // 2.989 -> 2.980).  gp = 2 keeps the narrow lanes on big launches (the bandwidth shape: 0.61 vs 0.75 ms, round 3).
+    // MEDT_BWD_WIDE=0: the lane counts of rounds 3 / 4 everywhere; =2: wide wherever an instance exists.
+    static const int wide = [] { const char* e = getenv("MEDT_BWD_WIDE"); return e ? atoi(e) : 1; }();
     const bool has_wide = (g.gp == 2 || g.gp == 4) && ((g.L == 64 && ls == 16) || (g.L == 32 && ls == 8) || (g.gp == 2 && g.L == 128 && ls == 16));
-    if (wide && has_wide && (wide == 2 || (long)g.groups * g.G * cdiv(g.spg, 64 / ls) < 1024)) ls *= 2;
+    if (wide && has_wide && (wide == 2 || g.gp == 4 || (long)g.groups * g.G * cdiv(g.spg, 64 / ls) < 1024)) ls *= 2;
     const int spw = 64 / ls;
     int nw = g.axis == 0 ? 4 : 2;
     // small problems: as many workgroups as there are sequences to give them

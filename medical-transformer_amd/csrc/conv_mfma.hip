@@ -1037,12 +1037,16 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_tail_kernel(TailBatch
 // jobs.  Returns MEDT_EUNSUPPORTED (nothing launched) when the mix does not fit one job table -- the caller then issues the three
 // kinds separately as before.  Grouped jobs beyond the table's 36 go out in a second, grouped launch.
 int conv_wgrad_tail(const MJob* const* r16, int n_r16, const MJob* const* mw, int n_mw, const WJob* w, int n_w, hipStream_t s) {
-    // (to be measured: the LDS-patch body needs 213 + 40 registers, so the merged grid holds 2 workgroups per CU where the grouped
-    //  tiles alone hold 6 -- opt-in until the A/B is in)
-    static const bool off = [] { const char* e = getenv("MEDT_WGRAD_TAIL"); return !(e && e[0] == '1'); }();
+    // Measured (profiles/r05_step_ab.json): with the grouped tiles in the same grid the step is 32 us SLOWER (the LDS-patch body needs
+    // 213 + 40 registers: the merged grid holds 2 workgroups per CU where the grouped tiles alone hold 3 - 6).  The two DEDICATED kinds
+    // -- both low-occupancy by themselves -- share one launch by default (n_w == 0); MEDT_WGRAD_TAIL=0: three launches as before,
+    // =2: the grouped jobs too.
+    static const int mode = [] { const char* e = getenv("MEDT_WGRAD_TAIL"); return e ? atoi(e) : 1; }();
+    const bool off = mode == 0 || (n_w > 0 && mode != 2);
     static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
     static const bool to64 = [] { const char* e = getenv("MEDT_WG_TILE"); return e && atoi(e) == 64; }();
-    if (off || valu || to64 || n_r16 > TAIL_R16 || n_mw > TAIL_MW || n_w <= 0 || n_r16 + n_mw == 0) return MEDT_EUNSUPPORTED;
+    if (off || valu || to64 || n_r16 > TAIL_R16 || n_mw > TAIL_MW || n_w < 0 || n_r16 + n_mw == 0) return MEDT_EUNSUPPORTED;
+    if (n_w == 0 && (n_r16 == 0 || n_mw == 0)) return MEDT_EUNSUPPORTED;          // one kind alone: its own launcher
     for (int i = 0; i < n_w; ++i)
         if (w[i].K != 1 && w[i].K != 3 && w[i].K != 7) return MEDT_EUNSUPPORTED;
     for (int i = 0; i < n_mw; ++i)

@@ -67,6 +67,7 @@ int medt_queue_flush(void* qv, void* stream) {
             if (conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS)) r16.push_back(&m);
             else if (m.K == 1 || m.K == 3) rest.push_back(&m);
         }
+        // (the grouped tiles first: they are the longest launch and nothing of the flush waits for the other two)
         bool merged = false;
         if (!rc && !q.wgrad.empty() && (!r16.empty() || !rest.empty())) {
             const int t = conv_wgrad_tail(r16.data(), (int)r16.size(), rest.data(), (int)rest.size(), q.wgrad.data(),
@@ -75,8 +76,14 @@ int medt_queue_flush(void* qv, void* stream) {
         }
         if (!merged) {
             if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
-            if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), s);
-            if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
+            int t = MEDT_EUNSUPPORTED;
+            if (!rc && !r16.empty() && !rest.empty())        // the two dedicated kinds side by side in one launch
+                t = conv_wgrad_tail(r16.data(), (int)r16.size(), rest.data(), (int)rest.size(), nullptr, 0, s);
+            if (t != MEDT_EUNSUPPORTED) rc = t;
+            else {
+                if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), s);
+                if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
+            }
         }
     }
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
