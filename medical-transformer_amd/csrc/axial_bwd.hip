@@ -162,6 +162,7 @@ struct SweepArgs {
     GatePtrs gates;
     int pool;
     float *dqkv, *part_qb, *part_sb, *rel_part, *pg_part, *gram, *gate_raw;
+    float* raw32;                  // bf16 storage only: qkv_raw widened to float32 once, for the 1x1 dgrad / wgrad behind bn_qkv's backward
     int tiles, nparts;             // tiles of S_T sequences per BN group; workgroups per BN group
     int qb_rpg;                    // rows per BN group of part_qb (the sweep's nparts rows first, then the fix kernel's)
 };
@@ -329,6 +330,11 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
                 for (int k = 0; k < RREC; ++k) rbuf[k] = 0.f;
 #pragma unroll
                 for (int k = 0; k < CREC; ++k) cbuf[k] = 0.f;
+            }
+            if (a.raw32 && ok) {      // (bf16 storage: the layer's backward-data / weight-gradient kernels read fp32 -- see medt_api.hip)
+                float* r32 = a.raw32 + (size_t)hg * NCH * g.HW + ((size_t)n * 2 * g.C * g.HW + h * g.W + w);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) r32[(size_t)ch * g.HW] = r.raw[kk][ch];
             }
             f4* rr = reinterpret_cast<f4*>(rowrec + ls * RS + i * RREC);             // 16-byte records: vector stores
             f4* cr = reinterpret_cast<f4*>(colrec + (ls * L + i) * CREC);
@@ -956,7 +962,7 @@ int axial_bwd_tables(const AxialGeom& g, const float* relative, float* tables, h
 int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, BnStats sim,
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
-                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s) {
+                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32) {
     if (abl_skip("sweep")) return MEDT_OK;
     SweepArgs a;
     a.g = g;
@@ -964,6 +970,7 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
     a.qs = qkv; a.ss = sim; a.gates = gates; a.pool = stride;
     a.dqkv = dqkv; a.part_qb = part_qb; a.part_sb = part_sb; a.rel_part = rel_part; a.pg_part = pg_part; a.gram = gram;
     a.gate_raw = gate_raw;
+    a.raw32 = raw32;
     a.tiles = p.tiles; a.nparts = p.nparts; a.qb_rpg = qb_rpg;
     const dim3 grid(g.groups * p.nparts, g.G), block(64 * p.nw);
     const bool gt = gate_raw != nullptr;

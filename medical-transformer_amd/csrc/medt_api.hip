@@ -88,6 +88,7 @@ struct BwdWs {
     float *part_ob, *coef_out, *part_sb, *coef_sim, *dqkv, *part_qb, *coef_qkv, *rel_part, *gate_part, *dw_scratch,
         *dy_masked, *gate_eff, *gate_tmp;
     float *tables, *gram, *pg_part, *gate_raw, *gate_rows;     // single-sweep backward (axial_bwd.hip)
+    float* raw32;                // bf16 storage + sweep: qkv_raw as float32 (written by the sweep, read by the 1x1 dgrad / wgrad)
     size_t nblocks;
     bool sweep;                  // the single-sweep backward runs (else the two generic passes of axial_core.hip)
     SweepPlan plan;
@@ -121,6 +122,9 @@ struct BwdWs {
         pg_part = c.take<float>(sweep ? sweep_blocks * g.L * plan.npg_floats : 0);
         gate_raw = c.take<float>(sweep ? sweep_blocks * 4 : 0);
         gate_rows = c.take<float>(sweep ? (size_t)g.groups * g.G * 4 : 0);
+        static const bool raw32_on = [] { const char* e = getenv("MEDT_BF16_RAW32"); return !(e && e[0] == '0'); }();
+        raw32 = c.take<float>(sweep && g.bf16 && raw32_on ? (size_t)g.N * 2 * g.C * g.HW : 0);
+        if (!(sweep && g.bf16 && raw32_on)) raw32 = nullptr;
     }
 };
 
@@ -135,7 +139,7 @@ static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, cons
     if (w.sweep) {
         if ((rc = axial_attn_bwd_sweep(g, w.plan, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out,
                                        d->stride, w.dqkv, w.part_qb, w.qb_rpg, w.part_sb, w.rel_part, w.pg_part, w.gram,
-                                       want_gates ? w.gate_raw : nullptr, s))) return rc;
+                                       want_gates ? w.gate_raw : nullptr, s, w.raw32))) return rc;
         AxialGeom gs = g;
         gs.tpg = w.plan.nparts;                               // part_sb rows per group
         // (+ the sliding-window table sums of the fix kernel as extra blocks of this launch)
@@ -379,7 +383,14 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // bn_qkv backward, qkv_transform backward
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
     static const bool bf16_fused = [] { const char* e = getenv("MEDT_BF16_FIN_APPLY"); return !(e && e[0] == '0'); }();
-    if (g.bf16 && bf16_fused && (long)g.N * 2 * g.C <= 65535) {
+    if (g.bf16 && w.raw32) {
+        // bf16 storage, round 5: the sweep has left qkv_raw widened to float32 in the workspace (one extra store per element of a
+        // VALU-bound kernel): bn_qkv's backward is then applied on load by the 1x1 dgrad / wgrad exactly as with fp32 storage --
+        // no extra launch, no extra pass over dqkv (gatedaxialunet bs 8: bf16 was 4-6 % slower than fp32 with the separate pass)
+        if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
+                                  w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
+        bq_raw = w.raw32;
+    } else if (g.bf16 && bf16_fused && (long)g.N * 2 * g.C <= 65535) {
         // bf16 storage: the finalisation and the bn_qkv backward materialised in fp32 in ONE launch, then the plain 1x1 dgrad / wgrad
         if ((rc = bn_bwd_fin_apply_bf16(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
                                         w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, w.dqkv, qkv_raw, g.N, g.HW, s))) return rc;

@@ -242,7 +242,7 @@ int axial_bwd_tables(const AxialGeom& g, const float* relative, float* tables, h
 int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, BnStats sim,
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
-                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s);
+                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32 = nullptr);
 // u / w terms of dq | dk (apply != 0: training mode) and the bn_qkv partial rows [nparts, nparts + fparts) (q | k channels)
 int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
                        const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,
