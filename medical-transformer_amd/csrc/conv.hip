@@ -699,7 +699,9 @@ static int wgrad_chunk_grouped(long NP) {
     int QS = 64;
     while (QS < qmax && (NP + QS - 1) / QS > target) QS <<= 1;
     static const int smax = [] { const char* e = getenv("MEDT_WG_SLABS"); return e ? atoi(e) : 64; }();
-    static const int smax_big = [] { const char* e = getenv("MEDT_WG_SLABS_BIG"); return e ? atoi(e) : 64; }();
+    // (>= 65536 positions -- the 128 x 128 maps of decoderf / adjust: 16-step chunks were the long pole of the global branch's flush;
+    //  their weight matrices are tiny, so 256 slabs cost the row reduction nothing: 2.080 -> 2.067 ms/step, profiles/r05_step_ab.json)
+    static const int smax_big = [] { const char* e = getenv("MEDT_WG_SLABS_BIG"); return e ? atoi(e) : 256; }();
     while ((NP + QS - 1) / QS > (NP >= 65536 ? smax_big : smax)) QS <<= 1;
     return QS;
 }

@@ -977,129 +977,11 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     return MEDT_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------------------------ //
-// Round 5: the THREE kinds of recorded MFMA weight gradients of a flush in ONE launch.  The tail of the local branch's backward
-// ran conv_wgrad_mfma_grouped (63 us), conv3x3_rows16_wgrad (53 us) and conv_wgrad_mfma_batch (18 us) back to back on one
-// stream -- each of them latency-bound with 1-2 resident waves per SIMD (SQ counters: the grouped kernel keeps 1.25 workgroups per
-// CU in flight, the LDS-patch kernel waits on its next tile two thirds of the time), none depending on another.  Side by side in
-// one grid they fill each other's gaps: block -> job by prefix sums over a mixed job table (the long LDS-patch workgroups first,
-// then the few-tile problems, then the 32 x 64 tiles longest chunk first).  Same bodies, same arithmetic, same slabs.
-// ------------------------------------------------------------------------------------------------------------------------ //
-constexpr int TAIL_R16 = 2, TAIL_MW = 3, TAIL_W = 36, TAIL_MAXJ = TAIL_R16 + TAIL_MW + TAIL_W;
-struct TailBatch {
-    int n;
-    int start[TAIL_MAXJ + 1];
-    unsigned char kind[TAIL_MAXJ];           // 0: LDS-patch (rows16), 1: 64 x 64 tiles of a dedicated problem, 2: 32 x 64 grouped tile
-    unsigned char idx[TAIL_MAXJ];            // index in the kind's own table
-    R16WJob r16[TAIL_R16];
-    MWJob mw[TAIL_MW];
-    WJobP w[TAIL_W];
-};
-static_assert(sizeof(TailBatch) <= 4000, "job table must fit the kernel-argument block");
-__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_tail_kernel(TailBatch b) {
-    MEDT_STATIC_SHARED float smem[2 * 64 * 65];                        // the largest of the three bodies' LDS tiles
-    static_assert(2 * 64 * 65 >= 64 * R16_DST + 16 * R16_WCST, "LDS-patch tiles fit");
-    const int j = find_job(b, blockIdx.x);
-    const int r = blockIdx.x - b.start[j], k = b.kind[j], i = b.idx[j];
-    if (k == 0) {
-        const R16WJob& jb = b.r16[i];
-        conv3x3_rows16_wgrad_body(jb, r % jb.gx, (r / jb.gx) % jb.gy, r / (jb.gx * jb.gy), smem, smem + 64 * R16_DST);
-    } else if (k == 1) {
-        const MWJob& m = b.mw[i];
-        float (*A)[65] = reinterpret_cast<float (*)[65]>(smem);
-        float (*B)[65] = reinterpret_cast<float (*)[65]>(smem + 64 * 65);
-        const int bx = r % m.gx, by = (r / m.gx) % m.gy, bz = r / (m.gx * m.gy);
-        if (m.K == 1)
-            conv_wgrad_mfma_body<1>(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.stride, m.pad,
-                                    m.QS, m.npg, bx, by, bz, A, B);
-        else
-            conv_wgrad_mfma_body<3>(m.dy, m.raw, m.coef, m.x, m.scratch, m.N, m.Cin, m.H, m.W, m.Cout, m.Ho, m.Wo, m.stride, m.pad,
-                                    m.QS, m.npg, bx, by, bz, A, B);
-    } else {
-        const WJobP& w = b.w[i];
-        float (*A)[65] = reinterpret_cast<float (*)[65]>(smem);
-        float (*B)[65] = reinterpret_cast<float (*)[65]>(smem + 32 * 65);
-        const int gx = (w.Cout + 31) / 32, gy = (w.Cin * w.K * w.K + 63) / 64;
-        const int bx = r % gx, t = r / gx, by = t % gy, bz = t / gy;
-        if (w.K == 1)
-            conv_wgrad_mfma_body32<1>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, w.pad,
-                                      w.QS, w.npg, bx, by, bz, A, B);
-        else if (w.K == 3)
-            conv_wgrad_mfma_body32<3>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, w.pad,
-                                      w.QS, w.npg, bx, by, bz, A, B);
-        else
-            conv_wgrad_mfma_body32<7>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride, w.pad,
-                                      w.QS, w.npg, bx, by, bz, A, B);
-    }
-}
-
-// r16 / mw: the recorded dedicated problems (defer.h MJob) that take the LDS-patch kernel / the 64 x 64 tile kernel; w: the grouped
-// jobs.  Returns MEDT_EUNSUPPORTED (nothing launched) when the mix does not fit one job table -- the caller then issues the three
-// kinds separately as before.  Grouped jobs beyond the table's 36 go out in a second, grouped launch.
-int conv_wgrad_tail(const MJob* const* r16, int n_r16, const MJob* const* mw, int n_mw, const WJob* w, int n_w, hipStream_t s) {
-    // Measured (profiles/r05_step_ab.json): with the grouped tiles in the same grid the step is 32 us SLOWER (the LDS-patch body needs
-    // 213 + 40 registers: the merged grid holds 2 workgroups per CU where the grouped tiles alone hold 3 - 6).  The two DEDICATED kinds
-    // -- both low-occupancy by themselves -- share one launch by default (n_w == 0); MEDT_WGRAD_TAIL=0: three launches as before,
-    // =2: the grouped jobs too.
-    static const int mode = [] { const char* e = getenv("MEDT_WGRAD_TAIL"); return e ? atoi(e) : 1; }();
-    const bool off = mode == 0 || (n_w > 0 && mode != 2);
-    static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
-    static const bool to64 = [] { const char* e = getenv("MEDT_WG_TILE"); return e && atoi(e) == 64; }();
-    if (off || valu || to64 || n_r16 > TAIL_R16 || n_mw > TAIL_MW || n_w < 0 || n_r16 + n_mw == 0) return MEDT_EUNSUPPORTED;
-    if (n_w == 0 && (n_r16 == 0 || n_mw == 0)) return MEDT_EUNSUPPORTED;          // one kind alone: its own launcher
-    for (int i = 0; i < n_w; ++i)
-        if (w[i].K != 1 && w[i].K != 3 && w[i].K != 7) return MEDT_EUNSUPPORTED;
-    for (int i = 0; i < n_mw; ++i)
-        if (mw[i]->K != 1 && mw[i]->K != 3) return MEDT_EUNSUPPORTED;
-    const bool skip_m = abl_skip((n_r16 ? r16[0] : mw[0])->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g");   // (timing experiments)
-    if (skip_m) return MEDT_EUNSUPPORTED;
-    std::vector<int> order(n_w);
-    for (int j = 0; j < n_w; ++j) order[j] = j;
-    auto cost = [&](int j) { return (long)((w[j].QS + 63) / 64) * (w[j].K == 1 ? 2 : 3); };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cost(a) > cost(c); });
-    TailBatch b;
-    b.n = 0;
-    int blocks = 0;
-    auto add = [&](int kind, int idx, int nblocks) {
-        b.kind[b.n] = (unsigned char)kind;
-        b.idx[b.n] = (unsigned char)idx;
-        b.start[b.n++] = blocks;
-        blocks += nblocks;
-    };
-    for (int i = 0; i < n_r16; ++i) {
-        const MJob& m = *r16[i];
-        R16WJob& j = b.r16[i];
-        j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
-        j.Cin = m.Cin; j.H = m.H; j.Cout = m.Cout; j.tiles_per_split = m.QS / 64; j.ptiles = m.N * m.H / 4; j.npg = m.npg;
-        j.gx = cdiv(m.Cout, 64); j.gy = m.Cin / 16; j.gz = m.splits;
-        add(0, i, j.gx * j.gy * j.gz);
-    }
-    for (int i = 0; i < n_mw; ++i) {
-        const MJob& m = *mw[i];
-        MWJob& j = b.mw[i];
-        j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
-        j.N = m.N; j.Cin = m.Cin; j.H = m.H; j.W = m.W; j.Cout = m.Cout; j.Ho = m.Ho; j.Wo = m.Wo; j.stride = m.stride;
-        j.pad = m.pad; j.QS = m.QS; j.npg = m.npg; j.K = m.K;
-        j.gx = cdiv(m.Cout, 64); j.gy = cdiv(m.Cin * m.K * m.K, 64); j.gz = m.splits;
-        add(1, i, j.gx * j.gy * j.gz);
-    }
-    const int n_in = n_w < TAIL_W ? n_w : TAIL_W;
-    for (int i = 0; i < n_in; ++i) {
-        const WJob& q = w[order[i]];
-        b.w[i] = WJobP{q.dy, q.raw, q.coef, q.x, q.scratch, q.N, q.Cin, q.H, q.W, q.Cout, q.Ho, q.Wo, q.QS, q.npg, q.gz,
-                       (unsigned char)q.stride, (unsigned char)q.pad, (unsigned char)q.K, 0};
-        if (q.v4) return MEDT_EUNSUPPORTED;        // (the merged launch has the scalar-load tile movers only)
-        add(2, i, cdiv(q.Cout, 32) * q.gy * q.gz);
-    }
-    b.start[b.n] = blocks;
-    hipLaunchKernelGGL(conv_wgrad_tail_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-    int rc = launch_status("conv_wgrad_tail");
-    if (rc || n_in == n_w) return rc;
-    std::vector<WJob> rest;
-    for (int i = n_in; i < n_w; ++i) rest.push_back(w[order[i]]);
-    return conv_wgrad_grouped(rest.data(), (int)rest.size(), s);
-}
-
+// (Round 5, measured and removed: the three kinds of recorded MFMA weight gradients of a flush -- grouped tiles, LDS-patch problems,
+//  few-tile problems -- as ONE launch with a mixed job table.  The LDS-patch body needs 213 + 40 registers, so the merged grid holds 2
+//  workgroups per CU: with the grouped tiles inside the step was 32 us slower (2.201 vs 2.168 ms), with only the two dedicated kinds
+//  merged it was neutral (2.078 vs 2.082 ms: the merged kernel took 71 us = 53 + 18, the LDS-patch workgroups fill every slot first).
+//  profiles/r05_step_ab.json.)
 bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stride, int pad, int QS) {
     return QS % 64 == 0 && Ho == H && Wo == W && conv_rows16_ok(Cin, H, W, K, stride, pad);
 }

@@ -100,8 +100,6 @@ int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s);       // VA
 bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stride, int pad, int QS);
 int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s);   // LDS-patch kernel of the 16-wide maps, <= 4 problems per launch
 int conv_wgrad_mfma_batch(const MJob* const* jobs, int n, hipStream_t s);       // generic MFMA tile kernel (K = 1 | 3), <= 4 problems per launch
-// all three kinds in one launch (conv_mfma.hip); MEDT_EUNSUPPORTED = nothing launched, issue them separately
-int conv_wgrad_tail(const MJob* const* r16, int n_r16, const MJob* const* mw, int n_mw, const WJob* w, int n_w, hipStream_t s);
 
 // Job table passed by value in the kernel arguments (< 4 KB): block b belongs to job j with start[j] <= b < start[j+1].
 template <class J, int MAXJ>

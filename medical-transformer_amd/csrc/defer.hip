@@ -59,32 +59,16 @@ int medt_queue_flush(void* qv, void* stream) {
     if (!rc && !q.bfin.empty()) rc = bn_bwd_finalize_grouped(q.bfin.data(), (int)q.bfin.size(), s);
     if (!rc && !q.sfin.empty()) rc = wopos_small_bwd_finalize_grouped(q.sfin.data(), (int)q.sfin.size(), s);
     if (!rc && !q.csum.empty()) rc = channel_sum_grouped(q.csum.data(), (int)q.csum.size(), s);
+    if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
     {
-        // the LDS-patch problems of the 16-wide maps, the other dedicated MFMA problems and the grouped tiles: ONE launch when
-        // they fit one job table (conv_wgrad_tail), else side by side per kind as before
+        // the LDS-patch problems of the 16-wide maps side by side in one launch (they fill each other's load gaps); so the others
         std::vector<const MJob*> r16, rest;
         for (const MJob& m : q.mwgrad) {
             if (conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS)) r16.push_back(&m);
             else if (m.K == 1 || m.K == 3) rest.push_back(&m);
         }
-        // (the grouped tiles first: they are the longest launch and nothing of the flush waits for the other two)
-        bool merged = false;
-        if (!rc && !q.wgrad.empty() && (!r16.empty() || !rest.empty())) {
-            const int t = conv_wgrad_tail(r16.data(), (int)r16.size(), rest.data(), (int)rest.size(), q.wgrad.data(),
-                                          (int)q.wgrad.size(), s);
-            if (t != MEDT_EUNSUPPORTED) { rc = t; merged = true; }
-        }
-        if (!merged) {
-            if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
-            int t = MEDT_EUNSUPPORTED;
-            if (!rc && !r16.empty() && !rest.empty())        // the two dedicated kinds side by side in one launch
-                t = conv_wgrad_tail(r16.data(), (int)r16.size(), rest.data(), (int)rest.size(), nullptr, 0, s);
-            if (t != MEDT_EUNSUPPORTED) rc = t;
-            else {
-                if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), s);
-                if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
-            }
-        }
+        if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), s);
+        if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
     }
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
     q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();

@@ -335,6 +335,8 @@ RECORDED_CASES = [
     (8, 8, 1, 1, 0, True, 2, 3, 1),           # 3x3 maps: 9 positions per image, not a multiple of 4 -> the scalar-load body
     (32, 64, 1, 2, 0, True, 2, 16, 1),        # stride 2 -> the scalar-load body
     (16, 16, 3, 1, 1, True, 2, 8, 1),         # 3x3 -> the scalar-load body
+    (16, 16, 3, 1, 1, False, 4, 128, 1),      # decoderf at BASELINE size: 65536 positions = 256 chunks / slabs of the scalar-load body
+    (16, 2, 1, 1, 0, False, 4, 128, 1),       # adjust: 65536 positions = 64 chunks of 1024 (16-byte body)
 ]
 
 
