@@ -711,9 +711,10 @@ static int wgrad_chunk_grouped(long NP) {
 static int wgrad_chunk_v4(long NP) {
     static const int target = [] { const char* e = getenv("MEDT_WG4_CHUNKS"); return e ? atoi(e) : 16; }();
     static const int qmax = [] { const char* e = getenv("MEDT_WG4_QMAX"); return e ? atoi(e) : 1024; }();
+    static const int smax_big = [] { const char* e = getenv("MEDT_WG_SLABS_BIG"); return e ? atoi(e) : 256; }();
     int QS = 256;
-    while (QS < qmax && (NP + QS - 1) / QS > target) QS <<= 1;
-    while ((NP + QS - 1) / QS > 64) QS <<= 1;
+    while (QS < qmax && (NP + QS - 1) / QS > (NP >= 65536 ? smax_big : target)) QS <<= 1;
+    while ((NP + QS - 1) / QS > (NP >= 65536 ? smax_big : 64)) QS <<= 1;
     const int QG = wgrad_chunk_grouped(NP);
     return QS > QG ? QS : QG;
 }

@@ -703,16 +703,23 @@ __device__ __forceinline__ void conv_wgrad_mfma_body32(
 //     16 bytes per thread and step, unconditional (clamped row / position, zeroed by select), saddr + 32-bit voffset addressing;
 //   * the MFMA fragments are read as ds_read_b128: lane group g of MFMA j in a 16-position block takes position 4 g + j for BOTH
 //     operands (the contraction does not care about the order), so one 16-byte LDS read feeds four MFMAs;
-//   * chunks are 256 ... 1024 positions (2 ... 8 steps), 4x fewer workgroups and 4x fewer partial slabs for the row reduction.
+//   * chunks are 256 ... 1024 positions (2 ... 8 steps), 4x fewer workgroups and 4x fewer partial slabs for the row reduction;
+//   * K = 3 (stride 1, pad 1: the decoders, conv2 / conv3 of the global stem -- the other half of a flush's workgroups): row k =
+//     (c, dh, dw) of the tile reads the ALIGNED float4 of input row h + dh - 1 plus ONE neighbour element (left for dw = 0, right
+//     for dw = 2) and shifts in registers -- no unaligned or out-of-tensor address, image borders zeroed by select.
 // ------------------------------------------------------------------------------------------------------------------------ //
 constexpr int V4_PS = 128, V4_LD = V4_PS + 4;
-__device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__ dy, const float* __restrict__ raw,
-                                                       const float* __restrict__ coef, const float* __restrict__ x,
-                                                       float* __restrict__ scratch, int N, int Cin, int HW, int Cout, int QS,
-                                                       int npg, int bx, int by, int bz, float* smem) {
+template <int K>
+__device__ __forceinline__ void conv_wgrad_v4_body32(const float* __restrict__ dy, const float* __restrict__ raw,
+                                                     const float* __restrict__ coef, const float* __restrict__ x,
+                                                     float* __restrict__ scratch, int N, int Cin, int HW, int Wd, int Cout, int QS,
+                                                     int npg, int bx, int by, int bz, float* smem) {
+    static_assert(K == 1 || K == 3, "1x1 or 3x3 (stride 1, pad K / 2)");
+    constexpr int KK = K * K;
+    const int Ktot = Cin * KK;
     float* A = smem;                              // [32][V4_LD]
     float* B = smem + 32 * V4_LD;                 // [64][V4_LD]
-    const int o0 = bx * 32, c0 = by * 64;
+    const int o0 = bx * 32, c0 = by * 64;         // (c0: first k = (c, tap) row of the tile)
     const unsigned NP = (unsigned)N * HW;
     const unsigned q_begin = (unsigned)bz * QS;
     const unsigned q_end = q_begin + QS < NP ? q_begin + QS : NP;
@@ -720,6 +727,7 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
     const int lrow = tid >> 5, col4 = tid & 31;
     // element offsets of this thread's rows inside one image's (Cout | Cin, HW) block; rows past the end are clamped and zeroed
     unsigned aoff[4], boff[8], acf[4];
+    int btap[8];                                  // K = 3: the tap t = 3 dh + dw of row i (row shift (dh - 1) W, column shift dw - 1)
     bool aok[4], bok[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -731,9 +739,12 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int c = c0 + lrow + 8 * i;
-        bok[i] = c < Cin;
-        boff[i] = (unsigned)(bok[i] ? c : Cin - 1) * HW;
+        const int k = c0 + lrow + 8 * i;
+        bok[i] = k < Ktot;
+        const int kc = bok[i] ? k : Ktot - 1;
+        const int c = kc / KK, t = kc - c * KK;
+        boff[i] = (unsigned)c * HW;
+        btap[i] = K == 3 ? t : 4;
     }
     f32x4 acc[2];
     acc[0] = (f32x4)(0.f);
@@ -760,9 +771,37 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
                 cf[i][0] = cg[acf[i]]; cf[i][1] = cg[acf[i] + 1]; cf[i][2] = cg[acf[i] + 2];
             }
         }
+        float nb[8];                                                 // K = 3: the neighbour element of the shifted taps
+        bool hok[8], nok[8];
+        if (K == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)((bbase + boff[i]) * 4u));
+            for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)((bbase + boff[i]) * 4u));
+        } else {
+            const int h = (int)(p / (unsigned)Wd), w0 = (int)p - h * Wd, Hd = HW / Wd;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int dh1 = btap[i] / 3 - 1, dw = btap[i] - 3 * (dh1 + 1);
+                hok[i] = (unsigned)(h + dh1) < (unsigned)Hd;         // input row of the tap
+                const unsigned e0 = bbase + boff[i] + (hok[i] ? dh1 * Wd : 0);      // aligned float4 of that row (this row if outside)
+                rb[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(e0 * 4u));
+                // left neighbour x[w0 - 1] for dw = 0, right neighbour x[w0 + 4] for dw = 2 (inside the row, else zero)
+                const int wn = dw == 0 ? w0 - 1 : w0 + 4;
+                nok[i] = hok[i] && dw != 1 && (unsigned)wn < (unsigned)Wd;
+                nb[i] = *reinterpret_cast<const float*>(xb + (size_t)((e0 + (nok[i] ? wn - w0 : 0)) * 4u));
+            }
+        }
         MEDT_SCHED_FENCE();                                          // every load of the step is in flight before the first use
+        if (K == 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float nv = nok[i] ? nb[i] : 0.f;
+                const f32x4 v = hok[i] ? rb[i] : (f32x4)(0.f);
+                const int dw = btap[i] % 3;
+                if (dw == 0) rb[i] = f32x4{nv, v[0], v[1], v[2]};
+                else if (dw == 2) rb[i] = f32x4{v[1], v[2], v[3], nv};
+                else rb[i] = v;
+            }
+        }
         if (coef) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -814,13 +853,13 @@ __device__ __forceinline__ void conv_wgrad_k1v4_body32(const float* __restrict__
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     MEDT_SCHED_FENCE();
 #endif
-    float* out = scratch + (size_t)bz * Cout * Cin;
+    float* out = scratch + (size_t)bz * Cout * Ktot;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = o0 + 16 * rblk + (lane >> 4) * 4 + r, k = c0 + (t0 + tt) * 16 + (lane & 15);
-            if (o < Cout && k < Cin) out[(size_t)o * Cin + k] = acc[tt][r];
+            if (o < Cout && k < Ktot) out[(size_t)o * Ktot + k] = acc[tt][r];
         }
 }
 
@@ -891,12 +930,12 @@ struct WJobP {                       // WJob packed for the kernel-argument bloc
     const float *dy, *raw, *coef, *x;
     float* scratch;
     int N, Cin, H, W, Cout, Ho, Wo, QS, npg, gz;
-    unsigned char stride, pad, K, v4;           // v4: conv_wgrad_k1v4_body32 (1x1, stride 1, 16-byte aligned rows)
+    unsigned char stride, pad, K, v4;           // v4: conv_wgrad_v4_body32<K> (1x1 / 3x3, stride 1, 16-byte aligned rows)
 };
 using WBatch = JobBatch<WJobP, 42>;
 static_assert(sizeof(WBatch) <= 4000, "job table must fit the kernel-argument block");
 template <int TO>
-__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(WBatch b) {
+__global__ __launch_bounds__(MEDT_THREADS, 3) void conv_wgrad_mfma_grouped_kernel(WBatch b) {      // (3 workgroups per CU: the LDS limit)
     // one LDS block for both tile movers: A[TO][65] | B[64][65] of the scalar-load bodies, A[32][132] | B[64][132] of the 16-byte one
     MEDT_STATIC_SHARED __attribute__((aligned(16))) float smem[(TO == 32 ? 96 * V4_LD : (TO + 64) * 65)];
     float (*A)[65] = reinterpret_cast<float (*)[65]>(smem);
@@ -908,7 +947,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_mfma_grouped_kernel(W
     const int bx = local % gx, t = local / gx, by = t % gy, bz = t / gy;
     if constexpr (TO == 32) {
         if (w.v4) {
-            conv_wgrad_k1v4_body32(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H * w.W, w.Cout, w.QS, w.npg, bx, by, bz, smem);
+            if (w.K == 1) conv_wgrad_v4_body32<1>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H * w.W, w.W, w.Cout, w.QS, w.npg, bx, by, bz, smem);
+            else conv_wgrad_v4_body32<3>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H * w.W, w.W, w.Cout, w.QS, w.npg, bx, by, bz, smem);
             return;
         }
     }
@@ -933,7 +973,9 @@ bool conv_wgrad_v4_ok(const float* dy, const float* raw, const float* x, int N, 
     static const bool off = [] { const char* e = getenv("MEDT_WG_V4"); return e && e[0] == '0'; }();
     static const bool to64 = [] { const char* e = getenv("MEDT_WG_TILE"); return e && atoi(e) == 64; }();
     static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
-    if (off || to64 || valu || K != 1 || stride != 1 || pad != 0 || Ho != H || Wo != W || (H * W) % 4) return false;
+    static const bool k3 = [] { const char* e = getenv("MEDT_WG_V4_K3"); return !(e && e[0] == '0'); }();
+    if (off || to64 || valu || stride != 1 || Ho != H || Wo != W) return false;
+    if (!((K == 1 && pad == 0 && (H * W) % 4 == 0) || (K == 3 && pad == 1 && W % 4 == 0 && k3))) return false;
     if ((((uintptr_t)dy | (uintptr_t)raw | (uintptr_t)x) & 15) != 0) return false;
     const size_t HW = (size_t)H * W;
     return (size_t)N * Cout * HW * 4 < 0xffffffffull && (size_t)N * Cin * HW * 4 < 0xffffffffull;      // 32-bit byte offsets

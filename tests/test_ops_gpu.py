@@ -322,7 +322,7 @@ def test_gradient_fan_in_through_sink(k_final, device):
 
 # The recorded (grouped) weight gradients the way a training step takes them: parameter gradients in FlatAdam's slots, the
 # weight-gradient jobs recorded into a StepQueue and issued by its flush -- conv_wgrad_mfma_grouped_kernel.  Round 5: 1x1 stride-1
-# problems with 16-byte-aligned rows take the 16-byte position-axis body (conv_wgrad_k1v4_body32: 128-position steps, chunks of
+# problems with 16-byte-aligned rows take the 16-byte position-axis body (conv_wgrad_v4_body32<K>: 128-position steps; K = 3 with stride 1 / pad 1 on maps whose width is a multiple of 4 likewise, chunks of
 # 256 ... 1024 positions); everything else the scalar-load bodies.  Against fp64 torch.
 RECORDED_CASES = [
     # Cin, Cout, K, stride, pad, bn, N, S, groups
@@ -334,9 +334,14 @@ RECORDED_CASES = [
     (16, 32, 1, 1, 0, True, 16, 32, 1),       # 16384 positions: 16 chunks of 1024 (8 steps each)
     (8, 8, 1, 1, 0, True, 2, 3, 1),           # 3x3 maps: 9 positions per image, not a multiple of 4 -> the scalar-load body
     (32, 64, 1, 2, 0, True, 2, 16, 1),        # stride 2 -> the scalar-load body
-    (16, 16, 3, 1, 1, True, 2, 8, 1),         # 3x3 -> the scalar-load body
-    (16, 16, 3, 1, 1, False, 4, 128, 1),      # decoderf at BASELINE size: 65536 positions = 256 chunks / slabs of the scalar-load body
-    (16, 2, 1, 1, 0, False, 4, 128, 1),       # adjust: 65536 positions = 64 chunks of 1024 (16-byte body)
+    (16, 16, 3, 1, 1, True, 2, 8, 1),         # 3x3 stride 1 pad 1 on 8-wide maps: the 16-byte body's K = 3 instance (one float4 per row)
+    (16, 16, 3, 1, 1, False, 4, 128, 1),      # decoderf at BASELINE size: 65536 positions = 256 chunks / slabs
+    (16, 2, 1, 1, 0, False, 4, 128, 1),       # adjust: 65536 positions = 256 chunks
+    (32, 16, 3, 1, 1, True, 3, 12, 3),        # 3x3, 12-wide maps (three float4 per row: left / interior / right borders), 3 BatchNorm groups
+    (128, 8, 3, 1, 1, True, 2, 16, 1),        # conv3's shape: 1152 = 18 k-tiles of (channel, tap) rows, 8 output channels
+    (8, 40, 3, 1, 1, False, 2, 20, 1),        # 72 (channel, tap) rows = a full and a partial k-tile, 40 output channels
+    (16, 16, 3, 1, 1, True, 2, 6, 1),         # 6-wide maps: not a multiple of 4 -> the scalar-load body
+    (16, 16, 3, 2, 1, True, 2, 8, 1),         # stride 2 -> the scalar-load body
 ]
 
 
