@@ -276,6 +276,8 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
                int y_bf16) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     if (abl_skip(N >= 16 ? (K == 3 ? "conv3_fwd_l" : (K == 1 ? "conv1_fwd_l" : "conv7_fwd_l")) : (K == 3 ? "conv3_fwd_g" : (K == 1 ? "conv1_fwd_g" : "conv7_fwd_g")))) return MEDT_OK;
+    if (!y_bf16 && conv_stem7_ok(Cin, H, W, Cout, K, stride, pad))        // (medt_api.hip sizes the partial sums for it: conv_geom)
+        return conv_stem7_fwd(x, w, bias, y, partials, N, H, W, Cout, relu, s);
     if (!y_bf16 && conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
         (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
         return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);

@@ -280,6 +280,115 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
     }
 }
 
+// --------------------------------------------------------------------------- //
+// 7x7 / stride 2 / pad 3 with 3 input channels: the stems (conv1_p 3 -> 64 on the 64 patch-images of MedT's local branch: 308 MFLOP
+// that took 29 us on the VALU kernel -- every lane walked 8 x 147 taps with scalar-loaded weights -- on the CRITICAL forward chain).
+// Round 5, the LDS-patch scheme of the 3x3 kernel above: a workgroup owns 8 MFMA tiles = 128 output positions of one image (8 output
+// rows of a 16-wide map, or 2 rows of a 64-wide one) x 64 output channels; the zero-padded input patch (3 x (2 R + 5) x (W + 6)) and the
+// 64 x 147 weight slab are staged in LDS ONCE and all 37 k-steps run from them -- 296 MFMAs per wave, one global round trip.
+//   k = (c, kh, kw) = 4 ks + (lane >> 4);  B fragment of tile (row tr, columns 16 tc ..): Ps[c][2 tr + kh][2 (16 tc + (lane & 15)) + kw]
+// --------------------------------------------------------------------------- //
+constexpr int S7_LDW = 149;                    // weight-slab row stride (147 taps + the zero 148th, odd: conflict-free fragment reads)
+bool conv_stem7_ok(int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    static const bool off = [] { const char* e = getenv("MEDT_CONV_STEM7"); return e && e[0] == '0'; }();
+    if (off || K != 7 || stride != 2 || pad != 3 || Cin != 3 || Cout < 32 || (H & 1) || (W & 1)) return false;
+    const int Ho = H / 2, Wo = W / 2;
+    if (Wo % 16 || (Ho * Wo) % 128 || Wo > 128) return false;
+    const int R = 128 / Wo;                    // output rows per workgroup
+    return (size_t)(3 * (2 * R + 5) * (W + 6) + 64 * S7_LDW) * sizeof(float) <= 64 * 1024;
+}
+int conv_stem7_parts_per_group(int N, int groups, int HoWo) { return (N / groups) * HoWo / 128; }
+
+__global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ partials, int H, int W, int Cout, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ho = H >> 1, Wo = W >> 1, HoWo = Ho * Wo, R = 128 / Wo, TC = Wo >> 4;      // rows per workgroup, tiles per row
+    const int PH = 2 * R + 5, PW = W + 6;
+    float* As = smem;                          // [64][S7_LDW]
+    float* Ps = smem + 64 * S7_LDW;            // [3][PH][PW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ppi = HoWo / 128;                // workgroups per image
+    const int n = blockIdx.x / ppi, ho0 = (blockIdx.x - n * ppi) * R, o0 = blockIdx.y * 64;
+    // ---- stage the weight slab (rows past Cout and column 147 are zero) and the zero-padded patch: one batch of loads each
+    for (int e = tid; e < 64 * 148; e += MEDT_THREADS) {
+        const int o = e / 148, k = e - o * 148;
+        As[o * S7_LDW + k] = (o0 + o < Cout && k < 147) ? w[(size_t)(o0 + o) * 147 + k] : 0.f;
+    }
+    const float* xn = x + (size_t)n * 3 * H * W;
+    for (int e = tid; e < 3 * PH * PW; e += MEDT_THREADS) {
+        const int c = e / (PH * PW), rem = e - c * PH * PW, r = rem / PW, col = rem - r * PW;
+        const int gh = 2 * ho0 - 3 + r, gw = col - 3;
+        Ps[e] = ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) ? xn[((size_t)c * H + gh) * W + gw] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = (f32x4)(0.f);
+    const float* arow = As + (16 * wv + (lane & 15)) * S7_LDW + (lane >> 4);
+    // tile t of the workgroup: output row ho0 + t / TC, columns 16 (t % TC) ...; this lane's column inside the patch
+    int toff[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) toff[t] = 2 * (t / TC) * PW + 2 * (16 * (t % TC) + (lane & 15));
+#pragma unroll 1
+    for (int ks = 0; ks < 37; ++ks) {
+        const int k = min(4 * ks + (lane >> 4), 146);             // (k = 147: the slab's zero column multiplies a valid address)
+        const int c = k / 49, r49 = k - c * 49, kh = r49 / 7, kw = r49 - kh * 7;
+        const float a = arow[4 * ks];
+        const float* pk = Ps + (c * PH + kh) * PW + kw;
+        float b[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[t] = pk[toff[t]];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+    }
+#ifndef MEDT_LANE_EMU        // (accumulators are read in another basic block than the last v_mfma: explicit wait states, see conv_wgrad_v4_body32)
+    MEDT_SCHED_FENCE();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    MEDT_SCHED_FENCE();
+#endif
+    // D[(lane>>4)*4 + r][lane&15] of tile t -> o = o0 + 16 wv + (lane>>4)*4 + r, position (ho0 + t / TC, 16 (t % TC) + (lane&15))
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+        if (o < Cout) {
+            const float bo = bias ? bias[o] : 0.f;
+            float* yo = y + ((size_t)n * Cout + o) * HoWo + ho0 * Wo + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float v = acc[t][r] + bo;
+                s1[r] += v;
+                s2[r] = fmaf(v, v, s2[r]);
+                yo[(t / TC) * Wo + 16 * (t % TC)] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+    if (partials) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double a = s1[r], b = s2[r];                       // (double from the cross-lane tree on: block_sum_d, medt_common.h)
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
+            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+            if ((lane & 15) == 0 && o < Cout) {
+                double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
+                dst[0] = a;
+                dst[1] = b;
+            }
+        }
+    }
+}
+
+int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W, int Cout,
+                   int relu, hipStream_t s) {
+    const int Ho = H / 2, Wo = W / 2, R = 128 / Wo;
+    const size_t lds = (size_t)(64 * S7_LDW + 3 * (2 * R + 5) * (W + 6)) * sizeof(float);
+    hipLaunchKernelGGL(conv_stem7_fwd_kernel, dim3(N * (Ho * Wo / 128), cdiv(Cout, 64)), dim3(MEDT_THREADS), lds, s, x, w, bias, y,
+                       partials, H, W, Cout, relu);
+    return launch_status("conv_stem7_fwd");
+}
+
 // Weight gradient of the same layers: dW[o][c][t] = sum_q dY[o][q] * X[c][q + t].  A workgroup owns 64 output channels x
 // one 16-channel chunk x all 9 taps (9 accumulator tiles per wave) over a chunk of 64-position tiles: the dY tile and the
 // halo patch are staged once per position tile and the 9 taps read shifted windows of the patch -- 144 MFMAs per wave per

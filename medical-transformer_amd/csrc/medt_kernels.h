@@ -51,6 +51,11 @@ int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
 // partials (optional): [group][part][Cout][2], part = 256-position chunk of the group's npg*Ho*Wo positions
 int conv2d_parts_per_group(int N, int groups, int HoWo);       // VALU kernel (256 positions per part)
 int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride);   // whichever kernel runs
+// the LDS-patch MFMA kernel of the 7x7 stride-2 stems (conv_mfma.hip): 128 positions per part
+bool conv_stem7_ok(int Cin, int H, int W, int Cout, int K, int stride, int pad);
+int conv_stem7_parts_per_group(int N, int groups, int HoWo);
+int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W, int Cout,
+                   int relu, hipStream_t s);
 // y_bf16: store y as bfloat16 (VALU path only: the 1x1 qkv_transform of a bf16-storage attention layer)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,

@@ -36,7 +36,9 @@ def ref_conv_block(x, conv, bn, res, relu, training, groups):
 CONV_CASES = [
     # Cin, Cout, K, stride, pad, bias, bn, res, relu, N, H, groups
     (3, 8, 7, 2, 3, False, True, False, True, 2, 32, 1),        # stem conv1
-    (3, 64, 7, 2, 3, False, True, False, True, 4, 32, 4),       # conv1_p, grouped BN
+    (3, 64, 7, 2, 3, False, True, False, True, 4, 32, 4),       # conv1_p, grouped BN (round 5: the LDS-patch MFMA stem kernel)
+    (3, 40, 7, 2, 3, True, False, False, True, 3, 64, 1),       # stem kernel on 32-wide output maps (two tiles per row), partial channel tile, bias
+    (3, 96, 7, 2, 3, False, True, False, False, 2, 32, 2),      # stem kernel, two channel tiles (64 + 32), no ReLU
     (8, 128, 3, 1, 1, False, True, False, True, 2, 16, 1),      # conv2
     (128, 8, 3, 1, 1, False, True, False, True, 2, 16, 2),      # conv3
     (32, 16, 1, 1, 0, False, True, False, True, 2, 16, 1),      # conv_down
