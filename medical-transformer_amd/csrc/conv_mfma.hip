@@ -301,7 +301,7 @@ int conv_stem7_parts_per_group(int N, int groups, int HoWo) { return (N / groups
 
 __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    float* __restrict__ partials, int H, int W, int Cout, int relu) {
+    float* __restrict__ partials, int H, int W, int Cout, int relu, unsigned inv_pw, unsigned inv_phpw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Ho = H >> 1, Wo = W >> 1, HoWo = Ho * Wo, R = 128 / Wo, TC = Wo >> 4;      // rows per workgroup, tiles per row
     const int PH = 2 * R + 5, PW = W + 6;
@@ -310,16 +310,52 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ppi = HoWo / 128;                // workgroups per image
     const int n = blockIdx.x / ppi, ho0 = (blockIdx.x - n * ppi) * R, o0 = blockIdx.y * 64;
-    // ---- stage the weight slab (rows past Cout and column 147 are zero) and the zero-padded patch: one batch of loads each
-    for (int e = tid; e < 64 * 148; e += MEDT_THREADS) {
-        const int o = e / 148, k = e - o * 148;
-        As[o * S7_LDW + k] = (o0 + o < Cout && k < 147) ? w[(size_t)(o0 + o) * 147 + k] : 0.f;
-    }
+    // ---- stage the weight slab (rows past Cout and column 147 are zero) and the zero-padded patch.  Every global load of the stage is
+    // issued BEFORE the first LDS store (unconditional clamped addresses + select): a rolled `for (e ...) lds[e] = cond ? g[..] : 0` loop
+    // is one global round trip per element (measured: the first version of this kernel took 28 us, 20 of them in these two loops)
     const float* xn = x + (size_t)n * 3 * H * W;
-    for (int e = tid; e < 3 * PH * PW; e += MEDT_THREADS) {
-        const int c = e / (PH * PW), rem = e - c * PH * PW, r = rem / PW, col = rem - r * PW;
-        const int gh = 2 * ho0 - 3 + r, gw = col - 3;
-        Ps[e] = ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) ? xn[((size_t)c * H + gh) * W + gw] : 0.f;
+    const int PE = 3 * PH * PW;
+    constexpr int WPT = (64 * 147 + MEDT_THREADS - 1) / MEDT_THREADS;      // 37 slab elements per thread
+    constexpr int PPT = 12;                                                 // patch elements per thread and batch
+    float wreg[WPT], preg[PPT];
+    // the slab's 64 rows are one contiguous block of w: element g of the block, no index arithmetic in front of the loads
+    const char* wblk = reinterpret_cast<const char*>(w + (size_t)o0 * 147);
+    const unsigned wvalid = (unsigned)min(64, Cout - o0) * 147u;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const unsigned g = (unsigned)(tid + MEDT_THREADS * i);
+        const float v = *reinterpret_cast<const float*>(wblk + (size_t)((g < wvalid ? g : 0u) * 4u));
+        wreg[i] = g < wvalid ? v : 0.f;
+    }
+    auto patch_load = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int e = base + tid + MEDT_THREADS * i;
+            const int ec = e < PE ? e : 0;
+            // (e < 2^16: floor(e / d) == mulhi(e, floor(2^32 / d) + 1) -- no runtime integer division per element)
+            const int c = (int)__umulhi((unsigned)ec, inv_phpw), rem = ec - c * PH * PW;
+            const int r = (int)__umulhi((unsigned)rem, inv_pw), col = rem - r * PW;
+            const int gh = 2 * ho0 - 3 + r, gw = col - 3;
+            const bool ok = e < PE && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xn) + (size_t)((ok ? (unsigned)((c * H + gh) * W + gw) : 0u) * 4u));
+            preg[i] = ok ? v : 0.f;
+        }
+    };
+    patch_load(0);
+    MEDT_SCHED_FENCE();
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int g = tid + MEDT_THREADS * i, o = g / 147, k = g - o * 147;
+        if (g < 64 * 147) As[o * S7_LDW + k] = wreg[i];
+    }
+    if (tid < 64) As[tid * S7_LDW + 147] = 0.f;                             // the zero 148th column (k-step 36's fourth lane group)
+    for (int base = 0; base < PE; base += PPT * MEDT_THREADS) {
+        if (base) { patch_load(base); MEDT_SCHED_FENCE(); }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int e = base + tid + MEDT_THREADS * i;
+            if (e < PE) Ps[e] = preg[i];
+        }
     }
     __syncthreads();
     f32x4 acc[8];
@@ -384,8 +420,9 @@ int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, 
                    int relu, hipStream_t s) {
     const int Ho = H / 2, Wo = W / 2, R = 128 / Wo;
     const size_t lds = (size_t)(64 * S7_LDW + 3 * (2 * R + 5) * (W + 6)) * sizeof(float);
+    const unsigned PW = (unsigned)(W + 6), PHPW = (unsigned)(2 * R + 5) * PW;
     hipLaunchKernelGGL(conv_stem7_fwd_kernel, dim3(N * (Ho * Wo / 128), cdiv(Cout, 64)), dim3(MEDT_THREADS), lds, s, x, w, bias, y,
-                       partials, H, W, Cout, relu);
+                       partials, H, W, Cout, relu, (unsigned)(0x100000000ull / PW) + 1u, (unsigned)(0x100000000ull / PHPW) + 1u);
     return launch_status("conv_stem7_fwd");
 }
 

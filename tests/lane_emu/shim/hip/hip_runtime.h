@@ -112,6 +112,7 @@ static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.f / sqrtf(x); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 
 // ---- synchronisation -------------------------------------------------------------------------------------------------------
 static inline void __syncthreads() { lane_emu::block_barrier(); }
