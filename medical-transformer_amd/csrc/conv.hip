@@ -533,14 +533,19 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
     return launch_status("conv2d_bwd_data");
 }
 
+// the backward-data of this layer runs as a forward MFMA convolution with flipped weights (conv_mfma_bwd_data_s1)
+bool conv2d_bwd_data_flips(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    return stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W);
+}
+
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
-                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add) {
+                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add, bool wt_ready) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     if (abl_skip(N >= 16 ? (K == 3 ? "conv3_dgrad_l" : "conv1_dgrad_l") : (K == 3 ? "conv3_dgrad_g" : "conv1_dgrad_g"))) return MEDT_OK;
     // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K   (the `add` epilogue is VALU-path only)
-    if (!add && wt_scratch && stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) &&
+    if (!add && wt_scratch && conv2d_bwd_data_flips(N, Cin, H, W, Cout, K, stride, pad) &&
         (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K) == 0))
-        return conv_mfma_bwd_data_s1(dy, w, wt_scratch, ksplit_scratch, dx, N, Cin, H, W, Cout, K, pad, s);
+        return conv_mfma_bwd_data_s1(dy, w, wt_scratch, ksplit_scratch, dx, N, Cin, H, W, Cout, K, pad, s, wt_ready);
     switch (K) {
         case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s, add);
         case 3: return conv2d_bwd_data_k<3>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s, add);

@@ -366,18 +366,28 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
     int toff[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) toff[t] = 2 * (t / TC) * PW + 2 * (16 * (t % TC) + (lane & 15));
-#pragma unroll 1
-    for (int ks = 0; ks < 37; ++ks) {
+    // k-step ks + 1's fragments are read from LDS while step ks multiplies (one wave per SIMD here: nothing else hides the LDS latency)
+    auto frags = [&](int ks, float& a, float (&b)[8]) {
         const int k = min(4 * ks + (lane >> 4), 146);             // (k = 147: the slab's zero column multiplies a valid address)
         const int c = k / 49, r49 = k - c * 49, kh = r49 / 7, kw = r49 - kh * 7;
-        const float a = arow[4 * ks];
+        a = arow[4 * ks];
         const float* pk = Ps + (c * PH + kh) * PW + kw;
-        float b[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = pk[toff[t]];
+    };
+    float a0, b0[8], a1, b1[8];
+    frags(0, a0, b0);
+#pragma unroll 1
+    for (int ks = 0; ks < 36; ks += 2) {
+        frags(ks + 1, a1, b1);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc[t], 0, 0, 0);
+        frags(ks + 2, a0, b0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc[t], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc[t], 0, 0, 0);      // k-step 36
 #ifndef MEDT_LANE_EMU        // (accumulators are read in another basic block than the last v_mfma: explicit wait states, see conv_wgrad_v4_body32)
     MEDT_SCHED_FENCE();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -626,13 +636,20 @@ __global__ __launch_bounds__(MEDT_THREADS) void flip_weights_kernel(const float*
     wt[((size_t)c * Cout + o) * KK + (KK - 1 - t)] = w[idx];
 }
 
-int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,
-                          int Cin, int H, int W, int Cout, int K, int pad, hipStream_t s) {
+int conv_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, hipStream_t s) {
     const int total = Cout * Cin * K * K;
-    hipLaunchKernelGGL(flip_weights_kernel, dim3(cdiv(total, MEDT_THREADS)), dim3(MEDT_THREADS), 0, s, w, wt_scratch,
-                       Cout, Cin, K * K);
-    int rc = launch_status("flip_weights");
-    if (rc) return rc;
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(cdiv(total, MEDT_THREADS)), dim3(MEDT_THREADS), 0, s, w, wt, Cout, Cin, K * K);
+    return launch_status("flip_weights");
+}
+
+// wt_ready: the flipped weights already sit in wt_scratch (round 5: the TRAINING forward pass leaves them behind the layer's saved
+// statistics -- recorded for the forward's grouped flush, off the backward chain; medt_api.hip)
+int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,
+                          int Cin, int H, int W, int Cout, int K, int pad, hipStream_t s, bool wt_ready) {
+    if (!wt_ready) {
+        int rc = conv_flip_weights(w, wt_scratch, Cout, Cin, K, s);
+        if (rc) return rc;
+    }
     // dy (N,Cout,Ho,Wo) with Ho = H + 2*pad - K + 1  ->  dx (N,Cin,H,W): forward conv, pad' = K-1-pad
     const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
     return conv_mfma_fwd(dy, wt_scratch, nullptr, dx, nullptr, ksplit_scratch, N, Cout, Ho, Wo, Cin, K, 1, K - 1 - pad, 0,

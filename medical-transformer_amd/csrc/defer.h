@@ -43,6 +43,7 @@ struct SmallFinArgs {                // wopos_small_bwd_finalize: BatchNorm para
     float dscale_out;
 };
 struct RJob { const float* src; float* dst; int P, K; };                         // reduce_rows
+struct FlipJob { const float* w; float* wt; int Cout, Cin, K; };                  // conv_flip_weights (forward pass, for the MFMA backward-data)
 struct CJob { const float* x; float* part; int N, C, HW; };                      // channel_sum, first stage
 struct WJob {                        // conv_wgrad_body<K, 64, 64> over a (gx, gy, gz) grid of (o-tile, k-tile, position chunk)
     const float *dy, *raw, *coef, *x;
@@ -77,8 +78,9 @@ struct Queue {
     std::vector<WJob> wgrad;
     std::vector<MJob> mwgrad;
     std::vector<RJob> reduce;
+    std::vector<FlipJob> flip;
     size_t pending() const {
-        return relfix.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + mwgrad.size() + reduce.size();
+        return flip.size() + relfix.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + mwgrad.size() + reduce.size();
     }
 };
 

@@ -488,8 +488,24 @@ struct ConvWs {
 
 extern "C" {
 
+// Round 5: a TRAINING-mode forward leaves the flipped / transposed weights the MFMA backward-data kernel reads behind the
+// layer's saved BatchNorm statistics (`stats` is the one buffer both passes get): the flip leaves the backward chain (four
+// launches of MedT's local branch) for the forward pass's grouped flush.  Both sides derive the layout from the descriptor.
+static bool conv_preflip(const medt_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("MEDT_PREFLIP"); return !(e && e[0] == '0'); }();
+    // (3x3 only: the layers that take the MFMA backward-data in practice; the 1x1 blocks that adopt a one-launch block kernel's outputs
+    //  -- medt_amd/block.py -- never call the forward entry and bring their own, smaller statistics block)
+    return on && d->training && d->K == 3 && conv2d_bwd_data_flips(d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad);
+}
+static size_t conv_bn_stats_floats(const medt_conv_desc* d) { return d->has_bn ? (size_t)4 * d->bn_groups * d->Cout : 0; }
+static float* conv_preflip_ptr(const medt_conv_desc* d, float* stats) { return stats + align_up(conv_bn_stats_floats(d), 64); }
+
 size_t medt_conv_stats_floats(const medt_conv_desc* d) {
-    return (d && d->has_bn) ? (size_t)4 * d->bn_groups * d->Cout : 0;
+    if (!d) return 0;
+    const size_t bn = (d->has_bn && d->bn_groups > 0 && d->Cout > 0) ? (size_t)4 * d->bn_groups * d->Cout : 0;
+    ConvGeom g;
+    if (conv_geom(d, &g)) return bn;           // (invalid descriptors: the entry points refuse them)
+    return conv_preflip(d) ? align_up(bn, 64) + (size_t)d->Cout * d->Cin * d->K * d->K : bn;
 }
 
 size_t medt_conv_workspace_bytes(const medt_conv_desc* d) {
@@ -513,6 +529,11 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
     Carver c(ws, ws_bytes);
     ConvWs cw(c, d, g);
     if (!ws || !c.ok()) { set_error("conv workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    if (stats && conv_preflip(d)) {            // (see medt_conv_stats_floats; nothing in the forward chain reads it)
+        float* wt = conv_preflip_ptr(d, stats);
+        if (Queue* q = queue_for(s)) q->flip.push_back(FlipJob{w, wt, d->Cout, d->Cin, d->K});
+        else if ((rc = conv_flip_weights(w, wt, d->Cout, d->Cin, d->K, s))) return rc;
+    }
     if (!d->has_bn)
         return conv2d_fwd(x, w, d->has_bias ? bias : nullptr, y, nullptr, cw.ksplit_fwd, d->N, d->Cin, d->H, d->W, d->Cout,
                           d->K, d->stride, d->pad, d->relu, 1, s);
@@ -610,8 +631,10 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     } else {
         grad_out = dy;
     }
-    if (dx && !dx_done && (rc = conv2d_bwd_data(grad_out, w, dx, cw.wt, cw.ksplit_bwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s,
-                                    dx_add))) return rc;
+    // (training mode: the forward pass left the flipped weights behind the saved statistics)
+    const bool preflipped = stats && conv_preflip(d);
+    if (dx && !dx_done && (rc = conv2d_bwd_data(grad_out, w, dx, preflipped ? conv_preflip_ptr(d, const_cast<float*>(stats)) : cw.wt, cw.ksplit_bwd,
+                                                d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad, s, dx_add, preflipped))) return rc;
     Queue* q = queue_for(s);          // parameter gradients: recorded for the grouped flush when a queue is bound
     if (d->has_bias) {
         if (q) {

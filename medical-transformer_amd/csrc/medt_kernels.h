@@ -64,7 +64,9 @@ size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int C
 // wt_scratch: Cout*Cin*K*K floats (used by the MFMA path for the flipped weights; may be NULL -> VALU path)
 // add (optional): dx = dgrad + add -- the other gradient contributions of a fanned-out input, summed in the epilogue
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
-                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add = nullptr);
+                    int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add = nullptr, bool wt_ready = false);
+bool conv2d_bwd_data_flips(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad);
+int conv_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, hipStream_t s);
 size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // dw[o,c,kh,kw] = sum_{n,ho,wo} val * x[...], val = coef ? c0*dy + c1*raw + c2 : dy (coef [group][Cout][3]);
 // scratch: conv2d_bwd_weight_splits() * Cout*Cin*K*K floats
@@ -84,7 +86,7 @@ size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, 
 int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                   int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
 int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,
-                          int Cin, int H, int W, int Cout, int K, int pad, hipStream_t s);
+                          int Cin, int H, int W, int Cout, int K, int pad, hipStream_t s, bool wt_ready = false);
 int conv_wgrad_mfma(const float* dy, const float* raw, const float* coef, const float* x, float* scratch, int N, int Cin,
                     int H, int W, int Cout, int Ho, int Wo, int K, int stride, int pad, int QS, int splits, int npg,
                     hipStream_t s);

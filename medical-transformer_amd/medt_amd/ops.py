@@ -118,8 +118,10 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.cfg, ctx.training, ctx.has_bias, ctx.has_res = cfg, training, bias is not None, res is not None
         # gradient slots of (w, bias, bn.weight, bn.bias) in FlatAdam's flat bucket: backward writes them directly
         ctx.slots = tuple(OPT.grad_slot(t) if t is not None else None for t in (w, bias, bn_w, bn_b))
+        # (stats: the BatchNorm statistics and, behind them, the flipped weights a training-mode forward leaves for the MFMA
+        #  backward-data kernel -- medt_conv_stats_floats says how much; layers without either bring a one-float dummy)
         ctx.save_for_backward(x, w, z if has_bn else None, y if (cfg.relu or has_bn) else None,
-                              stats if has_bn else None)
+                              stats if (has_bn or stats.numel() > 1) else None)
         return y
 
     @staticmethod
