@@ -190,6 +190,10 @@ def conv_block(x, conv, bn=None, res=None, relu=False, training=False, bn_groups
     pre: (z, y, stats) computed by the one-launch block forward (medt_amd.block) -- nothing is launched then."""
     cfg = ConvBlockCfg(conv.stride[0], conv.padding[0], bn, relu, bn_groups if bn is not None else 1, x_sink, x_role,
                        res_sink, last_of_branch, pre)
+    if bn is None:
+        # without BatchNorm the descriptor's `training` flag only says "a backward pass follows": the forward then leaves the
+        # flipped weights of the MFMA backward-data kernel behind (medt_conv_stats_floats), off the backward chain
+        training = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                              bn.bias if bn is not None else None, res, cfg, training)
 
