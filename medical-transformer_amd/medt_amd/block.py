@@ -35,7 +35,7 @@ def fused_forward(blk, x, bn_groups: int):
     """None when the block / shape is not one the fused kernel is built for; else the precomputed stage outputs
     {"down": (z1, y1, stats1), "h": (qkv_raw, stacked, lse, stats, y_h), "w": (...), "up": (z2, y, stats2)}."""
     from . import ops
-    if not ENABLED or ops.LEAN or not x.is_cuda or x.dtype != torch.float32 or blk.downsample is not None:
+    if not ENABLED or ops.lean() or not x.is_cuda or x.dtype != torch.float32 or blk.downsample is not None:
         return None
     h, w = blk.hight_block, blk.width_block
     if h._has_pos or w._has_pos or h._gate_mode or w._gate_mode or h.stride != 1 or w.stride != 1:

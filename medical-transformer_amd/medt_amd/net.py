@@ -146,8 +146,8 @@ def medt_forward(net, x):
     # take the fused small-layer kernels (2 launches per layer instead of 6)
     groups = GRID * GRID
     # beyond 128 px the global branch dominates the step and runs CU-filling persistent attention kernels (L = 128): the
-    # local branch then keeps to kernels whose workgroups co-reside with them (ops.LEAN -> medt_conv_desc.lean)
-    ops.LEAN = side is not None and xin.shape[2] * xin.shape[3] > 128 * 128
+    # local branch then keeps to kernels whose workgroups co-reside with them (ops.set_lean -> medt_conv_desc.lean; a per-thread hint)
+    ops.set_lean(side is not None and xin.shape[2] * xin.shape[3] > 128 * 128)
     try:
         if side is not None:
             with torch.cuda.stream(side):
@@ -170,7 +170,7 @@ def medt_forward(net, x):
             xp = ops.patch_gather(xin, PATCH, GRID)
             yp = _unet_body(net, _stem(net, xp, "_p", groups), "_p", groups)
     finally:
-        ops.LEAN = False               # (the hint is read when a block's configuration is built: forward time)
+        ops.set_lean(False)            # (the hint is read when a block's configuration is built: forward time)
     y = ops.logo_merge(y, yp, PATCH, GRID)
     y = ops.conv_block(y, net.decoderf, relu=True)
     return ops.conv_block(y, net.adjust)

@@ -60,7 +60,19 @@ def sink_of(x):
 
 # Scheduling hint (net.medt_forward sets it per call): True when the OTHER branch's stream runs CU-filling persistent kernels
 # (MedT's global branch beyond 128 px): the local branch then keeps to kernels with small LDS footprints (medt_conv_desc.lean)
-LEAN = False
+# Per THREAD (nn.DataParallel's thread-per-replica model, a validation thread next to a training thread): a forward of one thread
+# must not change the kernels another thread's forward picks.
+import threading
+_hint = threading.local()
+
+
+def set_lean(v: bool):
+    _hint.lean = bool(v)
+
+
+def lean() -> bool:
+    return getattr(_hint, "lean", False)
+
 
 
 class ConvBlockCfg:
@@ -72,7 +84,7 @@ class ConvBlockCfg:
         self.x_sink, self.x_role, self.res_sink = x_sink, x_role, res_sink
         self.last_of_branch = last_of_branch       # this block's backward is the last work of its stream's backward pass
         self.pre = pre                             # (z, y, stats) already computed by the one-launch block forward (block.py)
-        self.lean = LEAN
+        self.lean = lean()
 
 
 def _conv_desc(x, w, cfg: ConvBlockCfg, has_bias, has_res, training) -> L.ConvDesc:
