@@ -173,14 +173,23 @@ bool conv_rows16_ok(int Cin, int H, int W, int K, int stride, int pad) {
     return !off && K == 3 && stride == 1 && pad == 1 && W == 16 && H % 4 == 0 && Cin % 16 == 0;
 }
 
+// OT = 64: a wave owns a 16-channel row block and all four position tiles of the workgroup's 4 rows (round 2).
+// OT = 32 (round 5): half the output channels per workgroup -- wave w owns row block (w & 1) and the two position tiles 2 (w >> 1),
+// + 1 -- so conv3_p (64 output channels: 256 workgroups = ONE per CU, one wave per SIMD, the matrix pipe idle through every staging
+// phase) becomes 512 workgroups of 26 KB LDS, conv2_p 1024: several waves per SIMD take turns on the matrix pipe.
+template <int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ partials, int Cin, int H, int Cout, int relu) {
-    MEDT_STATIC_SHARED float As[64 * R16_AST];
+    constexpr int RB = OT / 16;                                    // 16-channel row blocks per workgroup
+    constexpr int NTQ = OT == 64 ? 4 : 2;                          // position tiles (image rows) per wave
+    MEDT_STATIC_SHARED float As[OT * R16_AST];
     MEDT_STATIC_SHARED float Ps[16 * R16_CST];
+    MEDT_STATIC_SHARED double Rd[2][2][16][2];                     // OT = 32: BatchNorm partials of the upper tile pair, per row block
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rb = OT == 64 ? wv : (wv & 1), t0 = OT == 64 ? 0 : 2 * (wv >> 1);
     const int tpi = H >> 2;                                        // 4-row tiles per image
-    const int n = blockIdx.x / tpi, r0 = (blockIdx.x - n * tpi) * 4, o0 = blockIdx.y * 64;
+    const int n = blockIdx.x / tpi, r0 = (blockIdx.x - n * tpi) * 4, o0 = blockIdx.y * OT;
     const int Ktot = Cin * 9, HW = H * 16;
     if (tid < 192) {                                               // the padding columns (-1 and 16) stay zero
         const int c = tid / 12, rem = tid - c * 12;
@@ -196,10 +205,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
         poff[i] = c * R16_CST + row * R16_RST + 1 + col;
         goff[i] = (gr >= 0 && gr < H) ? c * HW + gr * 16 + col : -1;       // rows above / below the image stay zero
     }
-    float ra[36], rp[6];
+    float ra[RB * 9], rp[6];
     auto fetch = [&](int c0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RB; ++j) {
             const int o = min(o0 + ar + 16 * j, Cout - 1);          // rows past Cout: their accumulators are never stored
             const float* wr = w + (size_t)o * Ktot + c0 * 9 + ae;
 #pragma unroll
@@ -212,29 +221,29 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
             rp[i] = goff[i] >= 0 ? v : 0.f;
         }
     };
-    f32x4 acc[4];
+    f32x4 acc[NTQ];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
-    const float* arow = As + (16 * wv + (lane & 15)) * R16_AST + (lane >> 4) * 9;
-    const float* prow = Ps + (lane >> 4) * R16_CST + (lane & 15);
+    for (int t = 0; t < NTQ; ++t) acc[t] = (f32x4)(0.f);
+    const float* arow = As + (16 * rb + (lane & 15)) * R16_AST + (lane >> 4) * 9;
+    const float* prow = Ps + (lane >> 4) * R16_CST + (lane & 15) + t0 * R16_RST;
     const int nch = Cin >> 4;
     fetch(0);
     for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < RB; ++j)
 #pragma unroll
             for (int m = 0; m < 9; ++m) As[(ar + 16 * j) * R16_AST + ae + 16 * m] = ra[j * 9 + m];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Ps[poff[i]] = rp[i];
         __syncthreads();
-        if (ch + 1 < nch) fetch((ch + 1) * 16);                    // flies during the 144 MFMAs below
+        if (ch + 1 < nch) fetch((ch + 1) * 16);                    // flies during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float a[9], b[6][3];
+            float a[9], b[NTQ + 2][3];
 #pragma unroll
             for (int t = 0; t < 9; ++t) a[t] = arow[ks * 36 + t];
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < NTQ + 2; ++r)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) b[r][kw] = prow[ks * 4 * R16_CST + r * R16_RST + kw];
 #pragma unroll
@@ -242,21 +251,21 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                    for (int tq = 0; tq < 4; ++tq)
+                    for (int tq = 0; tq < NTQ; ++tq)
                         acc[tq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kh * 3 + kw], b[tq + kh][kw], acc[tq], 0, 0, 0);
         }
         __syncthreads();
     }
-    // D[(lane>>4)*4 + r][lane&15] of tile tq  ->  o = o0 + 16 wv + (lane>>4)*4 + r,  position (r0 + tq, lane&15)
+    // D[(lane>>4)*4 + r][lane&15] of tile tq  ->  o = o0 + 16 rb + (lane>>4)*4 + r,  position (r0 + t0 + tq, lane&15)
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+        const int o = o0 + 16 * rb + (lane >> 4) * 4 + r;
         if (o < Cout) {
             const float bo = bias ? bias[o] : 0.f;
-            float* yo = y + ((size_t)n * Cout + o) * HW + r0 * 16 + (lane & 15);
+            float* yo = y + ((size_t)n * Cout + o) * HW + (r0 + t0) * 16 + (lane & 15);
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) {
+            for (int tq = 0; tq < NTQ; ++tq) {
                 const float v = acc[tq][r] + bo;
                 s1[r] += v;
                 s2[r] = fmaf(v, v, s2[r]);
@@ -265,16 +274,33 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
         }
     }
     if (partials) {
+        double pa[4], pb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double a = s1[r], b = s2[r];                       // (double from the cross-lane tree on: block_sum_d, medt_common.h)
 #pragma unroll
             for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
-            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
-            if ((lane & 15) == 0 && o < Cout) {
-                double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
-                dst[0] = a;
-                dst[1] = b;
+            pa[r] = a;
+            pb[r] = b;
+        }
+        if (OT == 32) {                                        // the two waves of a row block each hold half of the 64 positions
+            if (wv >= 2 && (lane & 15) == 0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { Rd[rb][0][(lane >> 4) * 4 + r][0] = pa[r]; Rd[rb][0][(lane >> 4) * 4 + r][1] = pb[r]; }
+            __syncthreads();
+            if (wv < 2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pa[r] += Rd[rb][0][(lane >> 4) * 4 + r][0]; pb[r] += Rd[rb][0][(lane >> 4) * 4 + r][1]; }
+        }
+        if (OT == 64 || wv < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + 16 * rb + (lane >> 4) * 4 + r;
+                if ((lane & 15) == 0 && o < Cout) {
+                    double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
+                    dst[0] = pa[r];
+                    dst[1] = pb[r];
+                }
             }
         }
     }
@@ -607,8 +633,15 @@ int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, f
     const dim3 grid((unsigned)qt, cdiv(Cout, 64), ks), block(MEDT_THREADS);
     if (ks == 1 && (N / groups) * Ho * Wo % 64 == 0 && conv_rows16_ok(Cin, H, W, K, stride, pad)) {
         if (abl_skip("rows16")) return MEDT_OK;
-        hipLaunchKernelGGL(conv3x3_rows16_fwd_kernel, dim3((unsigned)qt, cdiv(Cout, 64)), block, 0, s, x, w, bias, y,
-                           partials, Cin, H, Cout, relu);
+        // fewer than three 64-channel workgroups per CU: half-width workgroups instead (MEDT_R16_OT=64 / 32 forces one)
+        static const int force_ot = [] { const char* e = getenv("MEDT_R16_OT"); return e ? atoi(e) : 0; }();
+        const bool half = force_ot == 32 || (force_ot != 64 && qt * cdiv(Cout, 64) < 768);
+        if (half)
+            hipLaunchKernelGGL(conv3x3_rows16_fwd_kernel<32>, dim3((unsigned)qt, cdiv(Cout, 32)), block, 0, s, x, w, bias, y,
+                               partials, Cin, H, Cout, relu);
+        else
+            hipLaunchKernelGGL(conv3x3_rows16_fwd_kernel<64>, dim3((unsigned)qt, cdiv(Cout, 64)), block, 0, s, x, w, bias, y,
+                               partials, Cin, H, Cout, relu);
         return launch_status("conv3x3_rows16_fwd");
     }
     float* kout = ks > 1 ? scratch : nullptr;

@@ -395,3 +395,18 @@ def test_recorded_weight_gradient(case, device):
     if bnd is not None:
         gs = max(bn64.weight.grad.abs().max().item(), bn64.bias.grad.abs().max().item())
         assert (bnd.weight.grad.double().cpu() - bn64.weight.grad).abs().max().item() < TOL * gs
+
+
+def test_rows16_full_width_workgroups(device, emulating):
+    """conv3x3_rows16_fwd_kernel<64> (a workgroup = 64 output channels) runs from three workgroups per CU on; the test shapes and
+    MedT's own (bs 4) take the half-width <32> instance.  MEDT_R16_OT=64 forces the full-width one onto the same parity cases."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEDT_R16_OT="64")
+    sel = "test_conv_block and (64-128-3-1-1 or 128-64-3-1-1-1-0 or 48-80)" if not emulating else "test_conv_block and train and 48-80"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_ops_gpu.py"), "-k", sel] + (["--emulate"] if emulating else []),
+                       env=env, capture_output=True, text=True, timeout=7000 if emulating else 900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
