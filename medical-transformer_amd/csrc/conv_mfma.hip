@@ -315,38 +315,44 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_fwd_kernel(
 //   k = (c, kh, kw) = 4 ks + (lane >> 4);  B fragment of tile (row tr, columns 16 tc ..): Ps[c][2 tr + kh][2 (16 tc + (lane & 15)) + kw]
 // --------------------------------------------------------------------------- //
 constexpr int S7_LDW = 149;                    // weight-slab row stride (147 taps + the zero 148th, odd: conflict-free fragment reads)
+constexpr int S7_OT = 32;                      // output channels per workgroup: 2 row blocks x 2 tile halves over the four waves
 bool conv_stem7_ok(int Cin, int H, int W, int Cout, int K, int stride, int pad) {
     static const bool off = [] { const char* e = getenv("MEDT_CONV_STEM7"); return e && e[0] == '0'; }();
     if (off || K != 7 || stride != 2 || pad != 3 || Cin != 3 || Cout < 32 || (H & 1) || (W & 1)) return false;
     const int Ho = H / 2, Wo = W / 2;
     if (Wo % 16 || (Ho * Wo) % 128 || Wo > 128) return false;
     const int R = 128 / Wo;                    // output rows per workgroup
-    return (size_t)(3 * (2 * R + 5) * (W + 6) + 64 * S7_LDW) * sizeof(float) <= 64 * 1024;
+    return (size_t)(3 * (2 * R + 5) * (W + 6) + S7_OT * S7_LDW) * sizeof(float) <= 64 * 1024;
 }
 int conv_stem7_parts_per_group(int N, int groups, int HoWo) { return (N / groups) * HoWo / 128; }
 
+// A workgroup = 128 output positions of one image x 32 output channels: wave w owns the 16-channel row block (w & 1) and the
+// four MFMA tiles 4 (w >> 1) .. + 3 (the first version -- 64 channels, a wave = a row block x all eight tiles -- put 128 workgroups
+// on 256 CUs and staged twice the weight slab per workgroup).
 __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ partials, int H, int W, int Cout, int relu, unsigned inv_pw, unsigned inv_phpw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    MEDT_STATIC_SHARED double Rd7[2][16][2];                             // BatchNorm partials of the upper tile half, per row block
     const int Ho = H >> 1, Wo = W >> 1, HoWo = Ho * Wo, R = 128 / Wo, TC = Wo >> 4;      // rows per workgroup, tiles per row
     const int PH = 2 * R + 5, PW = W + 6;
-    float* As = smem;                          // [64][S7_LDW]
-    float* Ps = smem + 64 * S7_LDW;            // [3][PH][PW]
+    float* As = smem;                          // [S7_OT][S7_LDW]
+    float* Ps = smem + S7_OT * S7_LDW;         // [3][PH][PW]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rb = wv & 1, t0 = 4 * (wv >> 1);
     const int ppi = HoWo / 128;                // workgroups per image
-    const int n = blockIdx.x / ppi, ho0 = (blockIdx.x - n * ppi) * R, o0 = blockIdx.y * 64;
+    const int n = blockIdx.x / ppi, ho0 = (blockIdx.x - n * ppi) * R, o0 = blockIdx.y * S7_OT;
     // ---- stage the weight slab (rows past Cout and column 147 are zero) and the zero-padded patch.  Every global load of the stage is
     // issued BEFORE the first LDS store (unconditional clamped addresses + select): a rolled `for (e ...) lds[e] = cond ? g[..] : 0` loop
     // is one global round trip per element (measured: the first version of this kernel took 28 us, 20 of them in these two loops)
     const float* xn = x + (size_t)n * 3 * H * W;
     const int PE = 3 * PH * PW;
-    constexpr int WPT = (64 * 147 + MEDT_THREADS - 1) / MEDT_THREADS;      // 37 slab elements per thread
+    constexpr int WPT = (S7_OT * 147 + MEDT_THREADS - 1) / MEDT_THREADS;   // 19 slab elements per thread
     constexpr int PPT = 12;                                                 // patch elements per thread and batch
     float wreg[WPT], preg[PPT];
-    // the slab's 64 rows are one contiguous block of w: element g of the block, no index arithmetic in front of the loads
+    // the slab's rows are one contiguous block of w: element g of the block, no index arithmetic in front of the loads
     const char* wblk = reinterpret_cast<const char*>(w + (size_t)o0 * 147);
-    const unsigned wvalid = (unsigned)min(64, Cout - o0) * 147u;
+    const unsigned wvalid = (unsigned)min(S7_OT, Cout - o0) * 147u;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const unsigned g = (unsigned)(tid + MEDT_THREADS * i);
@@ -372,9 +378,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int g = tid + MEDT_THREADS * i, o = g / 147, k = g - o * 147;
-        if (g < 64 * 147) As[o * S7_LDW + k] = wreg[i];
+        if (g < S7_OT * 147) As[o * S7_LDW + k] = wreg[i];
     }
-    if (tid < 64) As[tid * S7_LDW + 147] = 0.f;                             // the zero 148th column (k-step 36's fourth lane group)
+    if (tid < S7_OT) As[tid * S7_LDW + 147] = 0.f;                          // the zero 148th column (k-step 36's fourth lane group)
     for (int base = 0; base < PE; base += PPT * MEDT_THREADS) {
         if (base) { patch_load(base); MEDT_SCHED_FENCE(); }
 #pragma unroll
@@ -384,69 +390,81 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
         }
     }
     __syncthreads();
-    f32x4 acc[8];
+    f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = (f32x4)(0.f);
-    const float* arow = As + (16 * wv + (lane & 15)) * S7_LDW + (lane >> 4);
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4)(0.f);
+    const float* arow = As + (16 * rb + (lane & 15)) * S7_LDW + (lane >> 4);
     // tile t of the workgroup: output row ho0 + t / TC, columns 16 (t % TC) ...; this lane's column inside the patch
-    int toff[8];
+    int toff[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) toff[t] = 2 * (t / TC) * PW + 2 * (16 * (t % TC) + (lane & 15));
-    // k-step ks + 1's fragments are read from LDS while step ks multiplies (one wave per SIMD here: nothing else hides the LDS latency)
-    auto frags = [&](int ks, float& a, float (&b)[8]) {
+    for (int t = 0; t < 4; ++t) toff[t] = 2 * ((t0 + t) / TC) * PW + 2 * (16 * ((t0 + t) % TC) + (lane & 15));
+    // k-step ks + 1's fragments are read from LDS while step ks multiplies
+    auto frags = [&](int ks, float& a, float (&b)[4]) {
         const int k = min(4 * ks + (lane >> 4), 146);             // (k = 147: the slab's zero column multiplies a valid address)
         const int c = k / 49, r49 = k - c * 49, kh = r49 / 7, kw = r49 - kh * 7;
         a = arow[4 * ks];
         const float* pk = Ps + (c * PH + kh) * PW + kw;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) b[t] = pk[toff[t]];
+        for (int t = 0; t < 4; ++t) b[t] = pk[toff[t]];
     };
-    float a0, b0[8], a1, b1[8];
+    float a0, b0[4], a1, b1[4];
     frags(0, a0, b0);
 #pragma unroll 1
     for (int ks = 0; ks < 36; ks += 2) {
         frags(ks + 1, a1, b1);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc[t], 0, 0, 0);
         frags(ks + 2, a0, b0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc[t], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc[t], 0, 0, 0);      // k-step 36
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc[t], 0, 0, 0);      // k-step 36
 #ifndef MEDT_LANE_EMU        // (accumulators are read in another basic block than the last v_mfma: explicit wait states, see conv_wgrad_v4_body32)
     MEDT_SCHED_FENCE();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     MEDT_SCHED_FENCE();
 #endif
-    // D[(lane>>4)*4 + r][lane&15] of tile t -> o = o0 + 16 wv + (lane>>4)*4 + r, position (ho0 + t / TC, 16 (t % TC) + (lane&15))
+    // D[(lane>>4)*4 + r][lane&15] of tile t -> o = o0 + 16 rb + (lane>>4)*4 + r, position (ho0 + (t0 + t) / TC, 16 ((t0 + t) % TC) + (lane&15))
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+        const int o = o0 + 16 * rb + (lane >> 4) * 4 + r;
         if (o < Cout) {
             const float bo = bias ? bias[o] : 0.f;
             float* yo = y + ((size_t)n * Cout + o) * HoWo + ho0 * Wo + (lane & 15);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 4; ++t) {
                 const float v = acc[t][r] + bo;
                 s1[r] += v;
                 s2[r] = fmaf(v, v, s2[r]);
-                yo[(t / TC) * Wo + 16 * (t % TC)] = relu ? fmaxf(v, 0.f) : v;
+                yo[((t0 + t) / TC) * Wo + 16 * ((t0 + t) % TC)] = relu ? fmaxf(v, 0.f) : v;
             }
         }
     }
     if (partials) {
+        double pa[4], pb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double a = s1[r], b = s2[r];                       // (double from the cross-lane tree on: block_sum_d, medt_common.h)
 #pragma unroll
             for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }   // over lane&15
-            const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
-            if ((lane & 15) == 0 && o < Cout) {
-                double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
-                dst[0] = a;
-                dst[1] = b;
+            pa[r] = a;
+            pb[r] = b;
+        }
+        if (wv >= 2 && (lane & 15) == 0)                       // the two waves of a row block each hold half of the 128 positions
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Rd7[rb][(lane >> 4) * 4 + r][0] = pa[r]; Rd7[rb][(lane >> 4) * 4 + r][1] = pb[r]; }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + 16 * rb + (lane >> 4) * 4 + r;
+                if ((lane & 15) == 0 && o < Cout) {
+                    double* dst = reinterpret_cast<double*>(partials) + ((size_t)blockIdx.x * Cout + o) * 2;
+                    dst[0] = pa[r] + Rd7[rb][(lane >> 4) * 4 + r][0];
+                    dst[1] = pb[r] + Rd7[rb][(lane >> 4) * 4 + r][1];
+                }
             }
         }
     }
@@ -455,9 +473,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_stem7_fwd_kernel(
 int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W, int Cout,
                    int relu, hipStream_t s) {
     const int Ho = H / 2, Wo = W / 2, R = 128 / Wo;
-    const size_t lds = (size_t)(64 * S7_LDW + 3 * (2 * R + 5) * (W + 6)) * sizeof(float);
+    const size_t lds = (size_t)(S7_OT * S7_LDW + 3 * (2 * R + 5) * (W + 6)) * sizeof(float);
     const unsigned PW = (unsigned)(W + 6), PHPW = (unsigned)(2 * R + 5) * PW;
-    hipLaunchKernelGGL(conv_stem7_fwd_kernel, dim3(N * (Ho * Wo / 128), cdiv(Cout, 64)), dim3(MEDT_THREADS), lds, s, x, w, bias, y,
+    hipLaunchKernelGGL(conv_stem7_fwd_kernel, dim3(N * (Ho * Wo / 128), cdiv(Cout, S7_OT)), dim3(MEDT_THREADS), lds, s, x, w, bias, y,
                        partials, H, W, Cout, relu, (unsigned)(0x100000000ull / PW) + 1u, (unsigned)(0x100000000ull / PHPW) + 1u);
     return launch_status("conv_stem7_fwd");
 }
