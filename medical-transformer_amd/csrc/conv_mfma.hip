@@ -492,15 +492,22 @@ struct R16WJob {                         // one weight-gradient problem of the k
     int Cin, H, Cout, tiles_per_split, ptiles, npg, gx, gy, gz;
 };
 
+// OT = 64: a wave owns a 16-channel row block and all nine taps (round 2).  OT = 32 (round 5): wave w owns row block (w & 1) and the
+// taps 0..4 / 5..8 ((w >> 1); the unused tenth slot multiplies a zero operand -- no branch around an MFMA, see conv_wgrad_v4_body32):
+// half the accumulators (the full kernel needs 189 + 40 registers: two waves per SIMD), twice the workgroups.
+template <int OT>
 __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int bx, int by, int bz, float* Ds, float* Ps) {
+    constexpr int NR = OT / 4;                                   // dY rows per thread and tile
+    constexpr int NA = OT == 64 ? 9 : 5;                         // accumulator tiles (taps) per wave
     const float* __restrict__ dy = jb.dy;
     const float* __restrict__ raw = jb.raw;
     const float* __restrict__ coef = jb.coef;
     const float* __restrict__ x = jb.x;
     float* __restrict__ scratch = jb.scratch;
     const int Cin = jb.Cin, H = jb.H, Cout = jb.Cout, tiles_per_split = jb.tiles_per_split, ptiles = jb.ptiles, npg = jb.npg;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int o0 = bx * 64, c0 = by * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = OT == 64 ? wv : (wv & 1), tlo = OT == 64 ? 0 : 5 * (wv >> 1);
+    const int o0 = bx * OT, c0 = by * 16;
     const int Ktot = Cin * 9, HW = H * 16, tpi = H >> 2;
     const int pt_begin = bz * tiles_per_split;
     const int pt_end = min(ptiles, pt_begin + tiles_per_split);
@@ -516,17 +523,17 @@ __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int
         pc[i] = (c0 + c) * HW + col;
         prw[i] = row - 1;
     }
-    float rd[16], rp[6];
+    float rd[NR], rp[6];
     auto fetch = [&](int pt) {
         const int n = pt / tpi, r0 = (pt - n * tpi) * 4;
         const size_t base = (size_t)n * Cout * HW + r0 * 16 + lane;
         const float* cf = coef ? coef + (size_t)(n / npg) * Cout * 3 : nullptr;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)                                // rows past Cout: their accumulators are never stored
+        for (int j = 0; j < NR; ++j)                                // rows past Cout: their accumulators are never stored
             rd[j] = dy[base + (size_t)min(o0 + wv + 4 * j, Cout - 1) * HW];
         if (cf) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NR; ++j) {
                 const int o = min(o0 + wv + 4 * j, Cout - 1);
                 rd[j] = fmaf(cf[o * 3], rd[j], fmaf(cf[o * 3 + 1], raw[base + (size_t)o * HW], cf[o * 3 + 2]));
             }
@@ -539,15 +546,24 @@ __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int
             rp[i] = (unsigned)gr < (unsigned)H ? v : 0.f;
         }
     };
-    f32x4 acc[9];
+    f32x4 acc[NA];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = (f32x4)(0.f);
-    const float* drow = Ds + (16 * wv + (lane & 15)) * R16_DST + (lane >> 4);
+    for (int t = 0; t < NA; ++t) acc[t] = (f32x4)(0.f);
+    // this wave's taps: LDS offset of tap slot tt inside the patch window, and whether the slot exists (the tenth does not)
+    int tapoff[NA];
+    float tapon[NA];
+#pragma unroll
+    for (int tt = 0; tt < NA; ++tt) {
+        const int t = min(tlo + tt, 8);
+        tapoff[tt] = (t / 3) * R16_RST + t % 3;
+        tapon[tt] = tlo + tt <= 8 ? 1.f : 0.f;
+    }
+    const float* drow = Ds + (16 * rb + (lane & 15)) * R16_DST + (lane >> 4);
     const float* prow = Ps + (lane & 15) * R16_WCST + (lane >> 4);
     if (pt_begin < pt_end) fetch(pt_begin);
     for (int pt = pt_begin; pt < pt_end; ++pt) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Ds[(wv + 4 * j) * R16_DST + lane] = rd[j];
+        for (int j = 0; j < NR; ++j) Ds[(wv + 4 * j) * R16_DST + lane] = rd[j];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Ps[poff[i]] = rp[i];
         __syncthreads();
@@ -557,21 +573,20 @@ __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int
             const float a = drow[ks * 4];
             const float* pk = prow + (ks >> 2) * R16_RST + (ks & 3) * 4;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pk[kh * R16_RST + kw], acc[kh * 3 + kw], 0, 0, 0);
+            for (int tt = 0; tt < NA; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(OT == 64 ? a : a * tapon[tt], pk[tapoff[tt]], acc[tt], 0, 0, 0);
         }
         __syncthreads();
     }
     float* out = scratch + (size_t)bz * Cout * Ktot;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = o0 + 16 * wv + (lane >> 4) * 4 + r;
+        const int o = o0 + 16 * rb + (lane >> 4) * 4 + r;
         if (o < Cout) {
             float* dst = out + (size_t)o * Ktot + (c0 + (lane & 15)) * 9;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
+            for (int tt = 0; tt < NA; ++tt)
+                if (tlo + tt <= 8) dst[tlo + tt] = acc[tt][r];
         }
     }
 }
@@ -580,13 +595,14 @@ __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int
 // branch's backward): each alone puts one workgroup of one wave per SIMD on every CU and spends two thirds of its time
 // waiting for the next tile; side by side they fill each other's gaps (46 + 46 us back to back before).
 using R16WBatch = JobBatch<R16WJob, 4>;
+template <int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv3x3_rows16_wgrad_kernel(R16WBatch b) {
-    MEDT_STATIC_SHARED float Ds[64 * R16_DST];
+    MEDT_STATIC_SHARED float Ds[OT * R16_DST];
     MEDT_STATIC_SHARED float Ps[16 * R16_WCST];
     const int j = find_job(b, blockIdx.x);
     const R16WJob& jb = b.job[j];
     const int r = blockIdx.x - b.start[j], bx = r % jb.gx, by = (r / jb.gx) % jb.gy, bz = r / (jb.gx * jb.gy);
-    conv3x3_rows16_wgrad_body(jb, bx, by, bz, Ds, Ps);
+    conv3x3_rows16_wgrad_body<OT>(jb, bx, by, bz, Ds, Ps);
 }
 
 // y[n,o,p] = bias[o] + sum over K slices; optional ReLU and BatchNorm partials ([group][256-position part][Cout][2]).
@@ -1245,6 +1261,7 @@ bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stri
 // the LDS-patch weight-gradient kernel for up to four recorded problems at once
 int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s) {
     if (abl_skip(jobs[0]->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
+    static const int ot = [] { const char* e = getenv("MEDT_R16W_OT"); return (e && atoi(e) == 64) ? 64 : 32; }();      // output channels per workgroup
     for (int i0 = 0; i0 < n; i0 += 4) {
         R16WBatch b;
         b.n = n - i0 < 4 ? n - i0 : 4;
@@ -1254,12 +1271,13 @@ int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s) {
             R16WJob& j = b.job[i];
             j.dy = m.dy; j.raw = m.raw; j.coef = m.coef; j.x = m.x; j.scratch = m.scratch;
             j.Cin = m.Cin; j.H = m.H; j.Cout = m.Cout; j.tiles_per_split = m.QS / 64; j.ptiles = m.N * m.H / 4; j.npg = m.npg;
-            j.gx = cdiv(m.Cout, 64); j.gy = m.Cin / 16; j.gz = m.splits;
+            j.gx = cdiv(m.Cout, ot); j.gy = m.Cin / 16; j.gz = m.splits;
             b.start[i] = blocks;
             blocks += j.gx * j.gy * j.gz;
         }
         b.start[b.n] = blocks;
-        hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        if (ot == 32) hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel<32>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        else hipLaunchKernelGGL(conv3x3_rows16_wgrad_kernel<64>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
         int rc = launch_status("conv3x3_rows16_wgrad");
         if (rc) return rc;
     }
