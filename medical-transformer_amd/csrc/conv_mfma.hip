@@ -494,7 +494,8 @@ struct R16WJob {                         // one weight-gradient problem of the k
 
 // OT = 64: a wave owns a 16-channel row block and all nine taps (round 2).  OT = 32 (round 5): wave w owns row block (w & 1) and the
 // taps 0..4 / 5..8 ((w >> 1); the unused tenth slot multiplies a zero operand -- no branch around an MFMA, see conv_wgrad_v4_body32):
-// half the accumulators (the full kernel needs 189 + 40 registers: two waves per SIMD), twice the workgroups.
+// half the accumulators, twice the workgroups -- measured slower for the weight-gradient pair (see conv_wgrad_rows16_grouped), kept
+// behind MEDT_R16W_OT=32; the explicit tap-offset table of this round took the full kernel from 189 + 40 to 123 + 40 registers.
 template <int OT>
 __device__ __forceinline__ void conv3x3_rows16_wgrad_body(const R16WJob& jb, int bx, int by, int bz, float* Ds, float* Ps) {
     constexpr int NR = OT / 4;                                   // dY rows per thread and tile
@@ -1261,7 +1262,9 @@ bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stri
 // the LDS-patch weight-gradient kernel for up to four recorded problems at once
 int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s) {
     if (abl_skip(jobs[0]->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
-    static const int ot = [] { const char* e = getenv("MEDT_R16W_OT"); return (e && atoi(e) == 64) ? 64 : 32; }();      // output channels per workgroup
+    // output channels per workgroup.  Measured (profiles/r05_step_ab.json): the half-width instance is 12 us SLOWER here (56.8 us per
+    // launch: twice the workgroups restage the patch, and the pair is matrix-pipe-bound already) -- MEDT_R16W_OT=32 selects it
+    static const int ot = [] { const char* e = getenv("MEDT_R16W_OT"); return (e && atoi(e) == 32) ? 32 : 64; }();
     for (int i0 = 0; i0 < n; i0 += 4) {
         R16WBatch b;
         b.n = n - i0 < 4 ? n - i0 : 4;
