@@ -212,9 +212,9 @@ int medt_wopos_block_fwd(const medt_block_desc*, const medt_block_params*, const
  * gradients and the BatchNorm parameter reductions are recorded for the grouped flush exactly like the per-stage entry
  * points record theirs.  `saved` is what medt_wopos_block_fwd (or the four per-stage forwards) filled, `y` the block output.
  * medt_wopos_block_bwd_workspace_bytes() returns 0 when this path is not available for the shape or not enabled
- * (MEDT_BLOCK_BWD=1; the caller then runs medt_conv_block_bwd / medt_axial_layer_bwd for the four stages).
- * State: verified against the reference fixture on the CPU lane emulator (tests/test_lane_emu.py); off by default until
- * it has been run and timed on the GPU. */
+ * (on by default, MEDT_BLOCK_BWD=0 disables; the caller then runs medt_conv_block_bwd / medt_axial_layer_bwd for the four stages).
+ * State: verified against the reference fixture on the CPU lane emulator (tests/test_lane_emu.py) and on the MI355X
+ * (tests/test_block_gpu.py); default since round 5 (profiles/r05_never_run_kernels.txt, profiles/r05_step_ab.json). */
 typedef struct medt_block_grads {
     float *w_down, *bn1_weight, *bn1_bias;
     medt_axial_grads height, width;          /* relative / gates: NULL (position-free layers)                 */

@@ -95,7 +95,7 @@ __device__ __forceinline__ void blk_scale_shift(float s, float m2, float n, cons
     shift = fmaf(-mean, scale, b);
 }
 
-// K wave sums at once by TRANSPOSITION (the second-generation instantiations, MEDT_BLOCK_PK=1): a lane swap exchanges halves
+// K wave sums at once by TRANSPOSITION (the second-generation instantiations, the default; MEDT_BLOCK_PK=0 = the first): a lane swap exchanges halves
 // between two registers, so one swap + one add folds TWO values over the wave halves (value a ends up in lanes 0-31, b in 32-63),
 // the next does the same over the row pairs -- after two levels one register holds FOUR channels, one per 16-lane row, and only
 // the in-row part (four DPP adds) is paid per register instead of per channel: K = 8 costs 20 VALU instructions instead of 80.
@@ -199,7 +199,7 @@ __device__ __forceinline__ void wave_bn(const float (&v)[K], const float* prm, d
 
 // Two FMAs per lane and instruction (v_pk_fma_f32 with the weights as an SGPR pair: the kernels are VALU-issue-bound on the one CU a
 // patch group gets, and two thirds of their instructions are these FMAs).  The second-generation instantiations (template
-// parameter PK: these FMAs + the transposed wave reductions above): MEDT_BLOCK_PK=1, off until measured.
+// parameter PK: these FMAs + the transposed wave reductions above): the default since round 5 (measured: profiles/r05_step_ab.json); MEDT_BLOCK_PK=0 disables.
 typedef medt_f2 blk_v2f;
 #ifdef MEDT_LANE_EMU
 __device__ __forceinline__ blk_v2f blk_pk_fma(blk_v2f a, blk_v2f b, blk_v2f c) { return blk_v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
@@ -439,7 +439,7 @@ int& block_pk_mode() {
 
 // ------------------------------------------------------------------------------------------------------------------------ //
 // The same block on 8x8 MAPS (layer2_p.1 of MedT at 128 px: 64 -> 32 -> 64 channels, 4 images per patch group = 256 positions),
-// end of round 4: compiled, verified on the CPU lane emulator, NOT yet run on the GPU -- opt-in, MEDT_BLOCK8=1.
+// verified on the CPU lane emulator (round 4) and on the MI355X (round 5, profiles/r05_never_run_kernels.txt); default, MEDT_BLOCK8=0 disables.
 // A wave = ONE IMAGE's 64 positions (lane = position) x a quarter of the output channels, so a 1x1 contraction only ever reads
 // its own image's columns of the tile and a wave's attention needs nothing but the q | k | v rows it has just produced (two heads
 // per wave).  What crosses waves is (a) each BatchNorm's statistics -- every wave reduces its image in registers (transposed
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(1024) void wopos_block_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ //
-// BACKWARD of the 8x8-map block in one workgroup per patch group (MEDT_BLOCK8=1 + MEDT_BLOCK_BWD=1; emulator-verified, unmeasured).
+// BACKWARD of the 8x8-map block in one workgroup per patch group (default since round 5; MEDT_BLOCK8=0 or MEDT_BLOCK_BWD=0 disables).
 // The forward's mapping -- a wave = one image x a quarter of the channels -- keeps the whole attention backward of a wave's two
 // heads inside the wave (its own q | k | v rows, its own d(sv) rows, strips of its own for the transposed accesses); what crosses
 // waves is each BatchNorm backward's two sums (four per-image records per channel, merged behind one barrier) and the gradient

@@ -6,7 +6,7 @@ the whole block as one launch that writes exactly the tensors the four stages sa
 autograd Functions are then applied in "adopt" mode (`pre=`): they wrap the precomputed outputs, save what they always
 save, and launch nothing -- the autograd graph, and with it the whole backward, is the one of the per-stage path.
 
-`block_forward` (MEDT_BLOCK_BWD=1 only) wraps the same forward launch into ONE autograd Function whose backward is the
+`block_forward` (default; MEDT_BLOCK_BWD=0 disables) wraps the same forward launch into ONE autograd Function whose backward is the
 one-launch block backward (medt_wopos_block_bwd): six dependent launches -> one.  That kernel is verified against the
 reference fixture on the CPU lane emulator (tests/test_lane_emu.py) and is OFF by default until it has been run and timed
 on the GPU.

@@ -60,7 +60,7 @@ def axial_block_forward(blk, x, bn_groups: int = 1):
     sink = ops.sink_of(x) if (SINKS and x.requires_grad) else None
     # the deep position-free blocks of the local branch: the whole block forward is ONE launch (block.py); the four stages
     # below then adopt its outputs (`pre`) instead of launching -- same autograd graph, same backward
-    if BLOCK.BWD_ENABLED:                  # ... and (MEDT_BLOCK_BWD=1) its backward too: the block is one autograd node
+    if BLOCK.BWD_ENABLED:                  # ... and (default; MEDT_BLOCK_BWD=0 disables) its backward too: the block is one autograd node
         y = BLOCK.block_forward(blk, x, bn_groups, sink)
         if y is not None:
             return y

@@ -101,7 +101,7 @@ def run(n, seed):
         bp, bs = L.BlockParams(), L.BlockSaved()
         assert lib.medt_wopos_block_fwd(C.byref(bd), C.byref(bp), null, null, C.byref(bs), null, bws, null) < 0
         assert lib.medt_wopos_block_fwd(None, None, None, None, None, None, 0, None) < 0
-        bbw = lib.medt_wopos_block_bwd_workspace_bytes(C.byref(bd))       # 0 unless MEDT_BLOCK_BWD=1 and the fused shape
+        bbw = lib.medt_wopos_block_bwd_workspace_bytes(C.byref(bd))       # 0 when MEDT_BLOCK_BWD=0 or not the fused shape
         assert bbw < (1 << 30)
         bg = L.BlockGrads()
         assert lib.medt_wopos_block_bwd(C.byref(bd), C.byref(bp), null, null, null, C.byref(bs), null, null, C.byref(bg), null,

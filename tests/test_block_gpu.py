@@ -243,7 +243,7 @@ def test_block8_fused_equals_stagewise(training, device):
 @bwd_opt_in
 @pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
 def test_block8_backward_one_launch_equals_stagewise(training, device):
-    """wopos_block8_bwd_kernel (MEDT_BLOCK8=1 + MEDT_BLOCK_BWD=1) against the six per-stage backward launches on layer2_p.1's shape;
+    """wopos_block8_bwd_kernel (default since round 5) against the six per-stage backward launches on layer2_p.1's shape;
     verified on the CPU lane emulator against the oracle (tests/test_lane_emu.py::test_block8_backward_kernel_on_the_emulator)."""
     import lib as droplib
     from medt_amd import block
