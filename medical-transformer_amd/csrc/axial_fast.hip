@@ -649,6 +649,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 // copy 1 (U[x]), lanes with even i0 copy 0 (U[x-3]), which makes the window base a multiple of 4 floats for
 // both and -- with the copy stride a multiple of 64 floats -- puts the two copies' windows on disjoint banks.
 // --------------------------------------------------------------------------- //
+#ifndef MEDT_F4R_CARRY
+#define MEDT_F4R_CARRY 2
+#endif
 template <int L>
 struct Fast4 {
     static constexpr int GP = 2, HQ = 1, NCH = 4, OCG = 4, LEN = L;
@@ -718,6 +721,11 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
         __syncthreads();
         tqmax = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
         tkmax = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+#if MEDT_F4R_CARRY
+        // wave-uniform: scalar registers (the sweep runs at the edge of the three-waves-per-SIMD register budget)
+        tqmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tqmax)));
+        tkmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tkmax)));
+#endif
     }
     const float* sc = red + 128;
     const float* sh = red + 160;
@@ -783,25 +791,26 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                 for (int r = 0; r < 4; ++r) { l2[r] = av0[r] = av1[r] = ae0[r] = ae1[r] = (f2)(0.f); }
                 const float* kp = sq + L;
                 const float* vp = sq + 2 * L;
+#if MEDT_F4R_CARRY
+                // The windows of consecutive chunks overlap in two of their three 16-byte pieces: piece t of chunk c is
+                // piece t - 1 of chunk c + 1.  The loop is fully unrolled, so carrying the two pieces is a renaming, and a
+                // chunk fetches ONE new piece per table (7 ds_read_b128 per chunk instead of 11 + 2 ds_read2st64_b64).
+                f4 cq[2], ck[2], c0[2], c1[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    cq[t] = *reinterpret_cast<const f4*>(tabl + 0 * CS + 4 * t);
+                    ck[t] = *reinterpret_cast<const f4*>(tabl + 2 * CS + 4 * t);
+                    c0[t] = *reinterpret_cast<const f4*>(tabl + 4 * CS + 4 * t);
+                    c1[t] = *reinterpret_cast<const f4*>(tabl + 6 * CS + 4 * t);
+                }
+#endif
 #pragma unroll
                 for (int j0 = 0; j0 < L; j0 += 4) {
                     const f4 k4 = *reinterpret_cast<const f4*>(kp + j0);
                     const f4 v0 = *reinterpret_cast<const f4*>(vp + j0);
                     const f4 v1 = *reinterpret_cast<const f4*>(vp + L + j0);
                     f2 wq[6], wk[6], w0[6], w1[6];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const f4 xq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 4 * t);
-                        const f4 xk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 4 * t);
-                        const f4 x0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 4 * t);
-                        const f4 x1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 4 * t);
-                        wq[2 * t] = xq.lo; wq[2 * t + 1] = xq.hi;
-                        wk[2 * t] = xk.lo; wk[2 * t + 1] = xk.hi;
-                        w0[2 * t] = x0.lo; w0[2 * t + 1] = x0.hi;
-                        w1[2 * t] = x1.lo; w1[2 * t + 1] = x1.hi;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    auto row = [&](const int r) {
                         const f2 fqa = (f2)(qa[r]), fqb = (f2)(qb[r]);
                         if constexpr (EXACT) {
                             f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + k4.lo * wk[3 - r]);
@@ -832,7 +841,45 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                             ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r]);
                             ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r]);
                         }
+                    };
+#if MEDT_F4R_CARRY
+                    wq[0] = cq[0].lo; wq[1] = cq[0].hi; wq[2] = cq[1].lo; wq[3] = cq[1].hi;
+                    wk[0] = ck[0].lo; wk[1] = ck[0].hi; wk[2] = ck[1].lo; wk[3] = ck[1].hi;
+                    w0[0] = c0[0].lo; w0[1] = c0[0].hi; w0[2] = c0[1].lo; w0[3] = c0[1].hi;
+                    w1[0] = c1[0].lo; w1[1] = c1[0].hi; w1[2] = c1[1].lo; w1[3] = c1[1].hi;
+#if MEDT_F4R_CARRY == 2
+                    row(3);                                      // needs carried pieces only; its first pair dies here,
+                    __builtin_amdgcn_sched_barrier(0);           // before the new piece is fetched (same register peak as without carry)
+#endif
+                    {
+                        const f4 nq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 8);
+                        const f4 nk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 8);
+                        const f4 n0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 8);
+                        const f4 n1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 8);
+                        wq[4] = nq.lo; wk[4] = nk.lo; w0[4] = n0.lo; w1[4] = n1.lo;
+                        cq[0] = cq[1]; cq[1] = nq;
+                        ck[0] = ck[1]; ck[1] = nk;
+                        c0[0] = c0[1]; c0[1] = n0;
+                        c1[0] = c1[1]; c1[1] = n1;
                     }
+#if MEDT_F4R_CARRY != 2
+                    row(3);
+#endif
+                    row(2); row(1); row(0);                      // the row that needs the new piece goes last
+#else
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const f4 xq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 4 * t);
+                        const f4 xk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 4 * t);
+                        const f4 x0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 4 * t);
+                        const f4 x1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 4 * t);
+                        wq[2 * t] = xq.lo; wq[2 * t + 1] = xq.hi;
+                        wk[2 * t] = xk.lo; wk[2 * t + 1] = xk.hi;
+                        w0[2 * t] = x0.lo; w0[2 * t + 1] = x0.hi;
+                        w1[2 * t] = x1.lo; w1[2 * t + 1] = x1.hi;
+                    }
+                    row(0); row(1); row(2); row(3);
+#endif
                     __builtin_amdgcn_sched_barrier(0);           // keep the unrolled chunks in order (register pressure)
                 }
                 // results replace this sequence's q|k|v rows in LDS: its lanes all sit in this wave and have issued
