@@ -650,7 +650,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 // both and -- with the copy stride a multiple of 64 floats -- puts the two copies' windows on disjoint banks.
 // --------------------------------------------------------------------------- //
 #ifndef MEDT_F4R_CARRY
-#define MEDT_F4R_CARRY 2
+#define MEDT_F4R_CARRY 3
 #endif
 template <int L>
 struct Fast4 {
@@ -850,6 +850,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
 #if MEDT_F4R_CARRY == 2
                     row(3);                                      // needs carried pieces only; its first pair dies here,
                     __builtin_amdgcn_sched_barrier(0);           // before the new piece is fetched (same register peak as without carry)
+#elif MEDT_F4R_CARRY >= 3
+                    row(3); row(2);                              // the oldest piece dies here, before the new one is fetched
+                    __builtin_amdgcn_sched_barrier(0);
 #endif
                     {
                         const f4 nq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 8);
@@ -862,10 +865,13 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                         c0[0] = c0[1]; c0[1] = n0;
                         c1[0] = c1[1]; c1[1] = n1;
                     }
-#if MEDT_F4R_CARRY != 2
+#if MEDT_F4R_CARRY == 1
                     row(3);
 #endif
-                    row(2); row(1); row(0);                      // the row that needs the new piece goes last
+#if MEDT_F4R_CARRY < 3
+                    row(2);
+#endif
+                    row(1); row(0);                              // the row that needs the new piece goes last
 #else
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
