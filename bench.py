@@ -54,6 +54,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     from medt_amd.axial import AxialConfig, _desc, _params
     import lib as droplib
     lib = ML.lib()
+    iters = int(os.environ.get("MEDT_ROOF_ITERS", iters))     # tuning aid: more launches per timing (kernel A/B runs)
     width = os.environ.get("MEDT_ROOF_AXIS", "w") != "h"      # tuning aid: the height-axis variant of the same shape
     layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=width).to(device)
     layer.train()

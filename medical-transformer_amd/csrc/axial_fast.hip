@@ -260,6 +260,30 @@ __device__ __forceinline__ void sta_u(float* __restrict__ ubase, unsigned byteof
     else *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
 }
 
+// Four consecutive elements at once (16 bytes of float32, 8 of bfloat16): byte offset a multiple of the access size
+template <bool BF>
+__device__ __forceinline__ f4 lda4_u(const float* __restrict__ ubase, unsigned byteoff) {
+    if (BF) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ubase) + byteoff);
+        f4 r;
+        r.x = __uint_as_float(w.x << 16); r.y = __uint_as_float(w.x & 0xffff0000u);
+        r.z = __uint_as_float(w.y << 16); r.w = __uint_as_float(w.y & 0xffff0000u);
+        return r;
+    }
+    return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(ubase) + byteoff);
+}
+template <bool BF>
+__device__ __forceinline__ void sta4_u(float* __restrict__ ubase, unsigned byteoff, f4 v) {
+    if (BF) {
+        uint2 w;
+        w.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
+        w.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ubase) + byteoff) = w;
+    } else {
+        *reinterpret_cast<f4*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
+    }
+}
+
 // Where the elements of one super-tile live.  (n0, s0, nseq) are wave-uniform (first image, first sequence inside
 // it, sequences in the tile); element t of a thread is e = threadIdx.x + 256 t, laid out with lanes along the
 // contiguous NCHW direction (width axis: along the sequence; height axis: across the sequences of the tile).
@@ -650,7 +674,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 // both and -- with the copy stride a multiple of 64 floats -- puts the two copies' windows on disjoint banks.
 // --------------------------------------------------------------------------- //
 #ifndef MEDT_F4R_CARRY
-#define MEDT_F4R_CARRY 3
+#define MEDT_F4R_CARRY 5
 #endif
 template <int L>
 struct Fast4 {
@@ -672,7 +696,12 @@ int fast4_max_subtiles(int axis) { return axis == 1 ? 1 : 2; }
 #endif
 namespace MEDT_FAST_NS {
 
-template <int AXIS, int L, bool EXACT>
+// VEC (width axis only): the lanes that move a sequence between global memory and LDS are the lanes that sweep it -- lane a of a
+// sequence owns elements 4a .. 4a+3 of each channel row, one 16-byte access per channel and phase instead of four 4-byte ones
+// with their address arithmetic -- so a wave only ever touches the LDS rows of its own sequences and the tile loop needs no
+// workgroup barrier (the in-order LDS pipe orders a wave's own accesses).  Needs 16-byte aligned tensors (the launcher checks).
+#define MEDT_F4R_WAVE_SYNC() do { MEDT_WAVE_LOCKSTEP(); __builtin_amdgcn_wave_barrier(); } while (0)
+template <int AXIS, int L, bool EXACT, bool VEC>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
                                                                   BnStats qs, BnStats ss,
                                                                   const float* __restrict__ relative, GatePtrs gates,
@@ -747,23 +776,55 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
         const int dn = q0 / (unsigned)g.Bo;
         nxt.set(g, grp * g.npg + dn, q0 - dn * g.Bo, min(SSr, g.spg - (int)q0));
     }
+    constexpr bool ROWMOVE = VEC && AXIS == 1;                 // (one sub-tile per tile on the width axis: F::nta(1) == 1)
+    constexpr unsigned ES = kBF ? 2u : 4u;
     PF pf;
-    if (part < nsup) pf.issue(qkv_raw, g, hg, nxt);
+    f4 pv[NCH];                                                // ROWMOVE: the next tile's raw q | k | v0 | v1 pieces of this lane
+    auto row_issue = [&](const Map& m) {
+        if (lsub < m.nseq) {
+            int dn, sq;
+            m.image_of(g, lsub, dn, sq);
+            const float* base = act_base<kBF>(qkv_raw, ((size_t)m.n0 * 2 * g.C + hg * NCH) * g.HW);      // uniform
+            const unsigned off = (unsigned)(dn * (2 * g.C * g.HW) + sq * g.W + 4 * a) * ES;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) pv[ch] = lda4_u<kBF>(base, off + (unsigned)(ch * g.HW) * ES);
+        }
+    };
+    if (part < nsup) {
+        if constexpr (ROWMOVE) row_issue(nxt);
+        else pf.issue(qkv_raw, g, hg, nxt);
+    }
     for (int u = part; u < nsup; u += g.oparts) {
         cur = nxt;
         const int nseq = cur.nseq;
-        __syncthreads();                                       // previous super-tile fully stored / tables staged
-        pf.commit(reg, g, cur, sc, sh);
+        if constexpr (ROWMOVE) {
+            MEDT_F4R_WAVE_SYNC();                              // this wave's stores of the previous tile have read the rows
+            if (lsub < nseq) {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const float c1 = sc[ch], c0 = sh[ch];
+                    f4 t;
+                    t.x = fmaf(pv[ch].x, c1, c0); t.y = fmaf(pv[ch].y, c1, c0);
+                    t.z = fmaf(pv[ch].z, c1, c0); t.w = fmaf(pv[ch].w, c1, c0);
+                    *reinterpret_cast<f4*>(reg + lsub * RS + ch * L + 4 * a) = t;
+                }
+            }
+        } else {
+            __syncthreads();                                   // previous super-tile fully stored / tables staged
+            pf.commit(reg, g, cur, sc, sh);
+        }
         {
             const int un = u + g.oparts;
             int s0 = cur.s0 + ds_step, n0 = cur.n0 + dn_step;
             if (s0 >= g.Bo) { s0 -= g.Bo; ++n0; }
             if (un < nsup) {
                 nxt.set(g, n0, s0, min(SSr, g.spg - un * SSr));
-                pf.issue(qkv_raw, g, hg, nxt);
+                if constexpr (ROWMOVE) row_issue(nxt);
+                else pf.issue(qkv_raw, g, hg, nxt);
             }
         }
-        __syncthreads();
+        if constexpr (ROWMOVE) MEDT_F4R_WAVE_SYNC();
+        else __syncthreads();
 #pragma unroll 1
         for (int sub = 0; sub < g.nt4; ++sub) {
             const int ls = sub * S_T + lsub;
@@ -804,9 +865,16 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                     c1[t] = *reinterpret_cast<const f4*>(tabl + 6 * CS + 4 * t);
                 }
 #endif
+#if MEDT_F4R_CARRY == 5
+                f4 kc = *reinterpret_cast<const f4*>(kp);
+#endif
 #pragma unroll
                 for (int j0 = 0; j0 < L; j0 += 4) {
+#if MEDT_F4R_CARRY == 5
+                    const f4 k4 = kc;
+#else
                     const f4 k4 = *reinterpret_cast<const f4*>(kp + j0);
+#endif
                     const f4 v0 = *reinterpret_cast<const f4*>(vp + j0);
                     const f4 v1 = *reinterpret_cast<const f4*>(vp + L + j0);
                     f2 wq[6], wk[6], w0[6], w1[6];
@@ -855,6 +923,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                     __builtin_amdgcn_sched_barrier(0);
 #endif
                     {
+#if MEDT_F4R_CARRY == 5
+                        kc = *reinterpret_cast<const f4*>(kp + (j0 + 4 < L ? j0 + 4 : j0));
+#endif
                         const f4 nq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 8);
                         const f4 nk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 8);
                         const f4 n0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 8);
@@ -908,9 +979,26 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                 }
             }
         }
-        __syncthreads();
-        store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, 1);
-        if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
+        if constexpr (ROWMOVE) {
+            MEDT_F4R_WAVE_SYNC();
+            if (lsub < nseq) {
+                int dn, sq;
+                cur.image_of(g, lsub, dn, sq);
+                const unsigned pix = (unsigned)(sq * g.W + 4 * a);
+                float* bo = act_base<kBF>(stacked, ((size_t)cur.n0 * g.OC + hg * OCG) * g.HW);         // uniform
+                const unsigned off = ((unsigned)(dn * g.OC * g.HW) + pix) * ES;
+#pragma unroll
+                for (int k = 0; k < OCG; ++k)
+                    sta4_u<kBF>(bo, off + (unsigned)(k * g.HW) * ES, *reinterpret_cast<const f4*>(reg + lsub * RS + k * L + 4 * a));
+                if (lse_out)
+                    sta4_u<false>(lse_out + ((size_t)cur.n0 * g.G + hg) * g.HW, ((unsigned)(dn * g.G * g.HW) + pix) * 4u,
+                                  *reinterpret_cast<const f4*>(reg + lsub * RS + NCH * L + 4 * a));
+            }
+        } else {
+            __syncthreads();
+            store_super<F, AXIS>(reg, 0, stacked, g.OC, hg * OCG, OCG, g, cur, 1);
+            if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
+        }
     }
     if (!EXACT && bad) atomicOr(flag, 1u);
     if (out_partials) {
@@ -969,16 +1057,34 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
 }  // namespace MEDT_FAST_NS
 using namespace MEDT_FAST_NS;
 
+template <bool EX, int AX, int Lv>
+static void r4_launch(bool vec, const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
+                      GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
+    const dim3 grid(g.groups * g.oparts, g.G), block(MEDT_THREADS);
+    const size_t lds = Fast4<Lv>::lds_floats(g.nt4) * sizeof(float);
+    if constexpr (AX == 1) {
+        if (vec) {
+            hipLaunchKernelGGL((attn_fwd4r_kernel<AX, Lv, EX, true>), grid, block, lds, s, g, qkv_raw, qkv, sim, relative, gates,
+                               stacked, lse, out_partials, flag);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((attn_fwd4r_kernel<AX, Lv, EX, false>), grid, block, lds, s, g, qkv_raw, qkv, sim, relative, gates, stacked,
+                       lse, out_partials, flag);
+}
+
 int MEDT_FAST_FN(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
 #define MEDT_K_EXACT(a, b, c) attn_fwd3_kernel<a, b, c, true>
 #define MEDT_K_BOUND(a, b, c) attn_fwd3_kernel<a, b, c, false>
     if (g.rows4 && flag) {
         // gp = 2, large problem: four rows per lane (VALU bound instead of LDS bound), same repair protocol
+        // width axis: 16-byte movers when the tensors allow it (MEDT_F4R_VEC=0: the 4-byte movers, for A/B)
+        static const bool vec_on = [] { const char* e = getenv("MEDT_F4R_VEC"); return !(e && atoi(e) == 0); }();
+        const bool vec = vec_on && g.axis == 1 && g.nt4 == 1 && (g.W & 3) == 0 && (g.HW & 3) == 0 &&
+                         (((uintptr_t)qkv_raw | (uintptr_t)stacked | (uintptr_t)lse) & 15) == 0;
 #define MEDT_R4_LAUNCH(EX, AX, Lv)                                                                                   \
-    hipLaunchKernelGGL((attn_fwd4r_kernel<AX, Lv, EX>), dim3(g.groups * g.oparts, g.G), dim3(MEDT_THREADS),            \
-                       Fast4<Lv>::lds_floats(g.nt4) * sizeof(float), s, g, qkv_raw, qkv, sim, relative, gates, stacked, \
-                       lse, out_partials, flag)
+    r4_launch<EX, AX, Lv>(vec, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s)
 #define MEDT_R4_CASES(EX)                                                                                            \
     switch (g.L * 2 + g.axis) {                                                                                      \
         case 16 * 2 + 0: MEDT_R4_LAUNCH(EX, 0, 16); break;   case 16 * 2 + 1: MEDT_R4_LAUNCH(EX, 1, 16); break;        \

@@ -303,6 +303,11 @@ if os.environ.get("MEDT_TEST_EMULATE") == "1":          # pytest --emulate: the 
     _emulated = emulated_device(emu)                      # (kept alive: leaving the context restores the product's device checks)
     _emulated.__enter__()
     dev = torch.device("cpu")
+tol = 1e-3
+if os.environ.get("MEDT_TEST_BF16") == "1":              # bfloat16 storage of qkv_raw / stacked (BF16_TOL of this file)
+    import medt_amd
+    medt_amd.set_activation_dtype(torch.bfloat16)
+    tol = 3e-2
 for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, False), (16, 64, False), (16, 32, True),
                     (16, 128, False), (16, 128, True), (16, 16, True), (16, 32, False)):
     layer = droplib.models.axialnet.AxialAttention_dynamic(C, C, groups=8, kernel_size=L, stride=1, width=width).to(dev)
@@ -315,7 +320,7 @@ for C, L, width in ((16, 64, True), (32, 32, False), (32, 128, True), (16, 16, F
     ost = O.clone_state({("m." + k): v for k, v in st.items()}, torch.float64)
     yo = O.axial_attention(x.double(), ost, "m", width, 1, True)
     err = (y.double().cpu() - yo).abs().max().item() / yo.abs().max().item()
-    assert err < 1e-3, (C, L, err)
+    assert err < tol, (C, L, err)
 print("layers ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -342,6 +347,15 @@ def test_four_rows_per_lane_kernel(bound, shift, device, emulating):
     """gp = 2 layers of large problems run the four-rows-per-lane forward kernel (MEDT_ROWS4=1 forces it on the
     small test shapes, ragged tiles included): exact, bound-referenced and repaired variants, both axes, L = 16..128."""
     _run_layer_subprocess({"MEDT_ROWS4": "1", "MEDT_BOUND_PATH": bound, "MEDT_DEBUG_BOUND_SHIFT": shift}, emulating)
+
+
+@pytest.mark.parametrize("env", [{"MEDT_TEST_BF16": "1"}, {"MEDT_F4R_VEC": "0"}, {"MEDT_F4R_VEC": "0", "MEDT_TEST_BF16": "1"}],
+                         ids=["bf16", "scalar-movers", "scalar-movers-bf16"])
+def test_four_rows_per_lane_kernel_movers(env, device, emulating):
+    """Round 5: on the width axis the four-rows-per-lane kernel moves a sequence with the lanes that sweep it, 16 bytes of
+    float32 / 8 of bfloat16 per access and no workgroup barrier in the tile loop.  bfloat16 storage through those movers, and
+    the 4-byte movers (MEDT_F4R_VEC=0: what misaligned tensors get) with both storage types."""
+    _run_layer_subprocess({"MEDT_ROWS4": "1", "MEDT_BOUND_PATH": "1", "MEDT_DEBUG_BOUND_SHIFT": "0", **env}, emulating)
 
 
 def test_layer_by_layer_fallback_of_small_layers(device, emulating):
