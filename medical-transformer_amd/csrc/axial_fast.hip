@@ -674,7 +674,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 // both and -- with the copy stride a multiple of 64 floats -- puts the two copies' windows on disjoint banks.
 // --------------------------------------------------------------------------- //
 #ifndef MEDT_F4R_CARRY
-#define MEDT_F4R_CARRY 5
+#define MEDT_F4R_CARRY 1
 #endif
 template <int L>
 struct Fast4 {
@@ -856,6 +856,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                 // The windows of consecutive chunks overlap in two of their three 16-byte pieces: piece t of chunk c is
                 // piece t - 1 of chunk c + 1.  The loop is fully unrolled, so carrying the two pieces is a renaming, and a
                 // chunk fetches ONE new piece per table (7 ds_read_b128 per chunk instead of 11 + 2 ds_read2st64_b64).
+                // Measured on the roofline shape (profiles/r05_fwd_variants_*.json): 185 -> 169 us with the 4-byte movers.
+                // (-DMEDT_F4R_CARRY=0 builds the round-4 body for A/B runs.)
                 f4 cq[2], ck[2], c0[2], c1[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -864,13 +866,11 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                     c0[t] = *reinterpret_cast<const f4*>(tabl + 4 * CS + 4 * t);
                     c1[t] = *reinterpret_cast<const f4*>(tabl + 6 * CS + 4 * t);
                 }
-#endif
-#if MEDT_F4R_CARRY == 5
                 f4 kc = *reinterpret_cast<const f4*>(kp);
 #endif
 #pragma unroll
                 for (int j0 = 0; j0 < L; j0 += 4) {
-#if MEDT_F4R_CARRY == 5
+#if MEDT_F4R_CARRY
                     const f4 k4 = kc;
 #else
                     const f4 k4 = *reinterpret_cast<const f4*>(kp + j0);
@@ -915,33 +915,20 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
                     wk[0] = ck[0].lo; wk[1] = ck[0].hi; wk[2] = ck[1].lo; wk[3] = ck[1].hi;
                     w0[0] = c0[0].lo; w0[1] = c0[0].hi; w0[2] = c0[1].lo; w0[3] = c0[1].hi;
                     w1[0] = c1[0].lo; w1[1] = c1[0].hi; w1[2] = c1[1].lo; w1[3] = c1[1].hi;
-#if MEDT_F4R_CARRY == 2
-                    row(3);                                      // needs carried pieces only; its first pair dies here,
-                    __builtin_amdgcn_sched_barrier(0);           // before the new piece is fetched (same register peak as without carry)
-#elif MEDT_F4R_CARRY >= 3
                     row(3); row(2);                              // the oldest piece dies here, before the new one is fetched
                     __builtin_amdgcn_sched_barrier(0);
-#endif
                     {
-#if MEDT_F4R_CARRY == 5
-                        kc = *reinterpret_cast<const f4*>(kp + (j0 + 4 < L ? j0 + 4 : j0));
-#endif
                         const f4 nq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 8);
                         const f4 nk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 8);
                         const f4 n0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 8);
                         const f4 n1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 8);
+                        kc = *reinterpret_cast<const f4*>(kp + (j0 + 4 < L ? j0 + 4 : j0));   // next chunk's keys, half a chunk ahead
                         wq[4] = nq.lo; wk[4] = nk.lo; w0[4] = n0.lo; w1[4] = n1.lo;
                         cq[0] = cq[1]; cq[1] = nq;
                         ck[0] = ck[1]; ck[1] = nk;
                         c0[0] = c0[1]; c0[1] = n0;
                         c1[0] = c1[1]; c1[1] = n1;
                     }
-#if MEDT_F4R_CARRY == 1
-                    row(3);
-#endif
-#if MEDT_F4R_CARRY < 3
-                    row(2);
-#endif
                     row(1); row(0);                              // the row that needs the new piece goes last
 #else
 #pragma unroll
