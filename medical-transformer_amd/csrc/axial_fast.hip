@@ -16,6 +16,7 @@
 // (axial_attn_fwd_fast), MEDT_FAST_BF16=1 -> bfloat16 storage (axial_attn_fwd_fast_bf16).  The storage type is a
 // compile-time constant of the hot loops (kBF); the two sets of kernels live in distinct namespaces.
 #include "axial_tiles.h"
+#include <type_traits>
 
 #ifndef MEDT_FAST_BF16
 #define MEDT_FAST_BF16 0
@@ -676,6 +677,16 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 #ifndef MEDT_F4R_CARRY
 #define MEDT_F4R_CARRY 1
 #endif
+// true on every lane when the predicate holds on any lane of the wavefront (call it with the whole wave converged)
+__device__ __forceinline__ bool wave_any(bool p) {
+#ifdef MEDT_LANE_EMU
+    int v = p ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v != 0;
+#else
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#endif
+}
 template <int L>
 struct Fast4 {
     static constexpr int GP = 2, HQ = 1, NCH = 4, OCG = 4, LEN = L;
@@ -763,7 +774,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
     float st_sum[OCG], st_sq[OCG];
 #pragma unroll
     for (int k = 0; k < OCG; ++k) { st_sum[k] = 0.f; st_sq[k] = 0.f; }
-    int bad = 0;
     const int SSr = S_T * g.nt4;
     const int nsup = (g.spg + SSr - 1) / SSr;
     using Map = SuperMap<F, AXIS>;
@@ -837,122 +847,145 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
             }
 #pragma unroll
             for (int o = LPS / 2; o > 0; o >>= 1) kmx = fmaxf(kmx, __shfl_xor(kmx, o, 64));
+            float qa[4], qb[4], m[4];
+            f2 l2[4], av0[4], av1[4], ae0[4], ae1[4];
+            const float* kp = sq + L;
+            const float* vp = sq + 2 * L;
+            // One pass over the L keys for this lane's four query rows.  EX = false: softmax referenced to the per-row upper
+            // bound of the logits; EX = true: online softmax (running maximum, one rescale per chunk).  Active lanes only.
+            auto sweep_rows = [&](auto exact_tag) {
+                constexpr bool EX = decltype(exact_tag)::value;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[r] = EX ? -INFINITY : g.bound_shift + fabsf(qa[r]) * kmx + fabsf(qb[r]) * tqmax + kmx * tkmax;
+                    l2[r] = av0[r] = av1[r] = ae0[r] = ae1[r] = (f2)(0.f);
+                }
+#if MEDT_F4R_CARRY
+                    // The windows of consecutive chunks overlap in two of their three 16-byte pieces: piece t of chunk c is
+                    // piece t - 1 of chunk c + 1.  The loop is fully unrolled, so carrying the two pieces is a renaming, and a
+                    // chunk fetches ONE new piece per table (7 ds_read_b128 per chunk instead of 11 + 2 ds_read2st64_b64).
+                    // Measured on the roofline shape (profiles/r05_fwd_variants_*.json): 185 -> 169 us with the 4-byte movers.
+                    // (-DMEDT_F4R_CARRY=0 builds the round-4 body for A/B runs.)
+                    f4 cq[2], ck[2], c0[2], c1[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        cq[t] = *reinterpret_cast<const f4*>(tabl + 0 * CS + 4 * t);
+                        ck[t] = *reinterpret_cast<const f4*>(tabl + 2 * CS + 4 * t);
+                        c0[t] = *reinterpret_cast<const f4*>(tabl + 4 * CS + 4 * t);
+                        c1[t] = *reinterpret_cast<const f4*>(tabl + 6 * CS + 4 * t);
+                    }
+                    f4 kc = *reinterpret_cast<const f4*>(kp);
+#endif
+#pragma unroll
+                    for (int j0 = 0; j0 < L; j0 += 4) {
+#if MEDT_F4R_CARRY
+                        const f4 k4 = kc;
+#else
+                        const f4 k4 = *reinterpret_cast<const f4*>(kp + j0);
+#endif
+                        const f4 v0 = *reinterpret_cast<const f4*>(vp + j0);
+                        const f4 v1 = *reinterpret_cast<const f4*>(vp + L + j0);
+                        f2 wq[6], wk[6], w0[6], w1[6];
+                        auto row = [&](const int r) {
+                            const f2 fqa = (f2)(qa[r]), fqb = (f2)(qb[r]);
+                            if constexpr (EX) {
+                                f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + k4.lo * wk[3 - r]);
+                                f2 zhi = fqa * k4.hi + (fqb * wq[4 - r] + k4.hi * wk[4 - r]);
+                                const float mn = fmaxf(m[r], fmaxf(fmaxf(zlo.x, zlo.y), fmaxf(zhi.x, zhi.y)));
+                                const f2 alpha = (f2)(__builtin_amdgcn_exp2f(m[r] - mn));
+                                m[r] = mn;
+                                zlo -= (f2)(mn);
+                                zhi -= (f2)(mn);
+                                f2 plo, phi;
+                                plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
+                                phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
+                                l2[r] = l2[r] * alpha + (plo + phi);
+                                av0[r] = plo * v0.lo + (phi * v0.hi + av0[r] * alpha);
+                                av1[r] = plo * v1.lo + (phi * v1.hi + av1[r] * alpha);
+                                ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r] * alpha);
+                                ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r] * alpha);
+                            } else {
+                                const f2 zi = (f2)(-m[r]);
+                                const f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + (k4.lo * wk[3 - r] + zi));
+                                const f2 zhi = fqa * k4.hi + (fqb * wq[4 - r] + (k4.hi * wk[4 - r] + zi));
+                                f2 plo, phi;
+                                plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
+                                phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
+                                l2[r] += plo + phi;
+                                av0[r] = plo * v0.lo + (phi * v0.hi + av0[r]);
+                                av1[r] = plo * v1.lo + (phi * v1.hi + av1[r]);
+                                ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r]);
+                                ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r]);
+                            }
+                        };
+#if MEDT_F4R_CARRY
+                        wq[0] = cq[0].lo; wq[1] = cq[0].hi; wq[2] = cq[1].lo; wq[3] = cq[1].hi;
+                        wk[0] = ck[0].lo; wk[1] = ck[0].hi; wk[2] = ck[1].lo; wk[3] = ck[1].hi;
+                        w0[0] = c0[0].lo; w0[1] = c0[0].hi; w0[2] = c0[1].lo; w0[3] = c0[1].hi;
+                        w1[0] = c1[0].lo; w1[1] = c1[0].hi; w1[2] = c1[1].lo; w1[3] = c1[1].hi;
+                        row(3); row(2);                              // the oldest piece dies here, before the new one is fetched
+                        __builtin_amdgcn_sched_barrier(0);
+                        {
+                            const f4 nq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 8);
+                            const f4 nk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 8);
+                            const f4 n0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 8);
+                            const f4 n1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 8);
+                            kc = *reinterpret_cast<const f4*>(kp + (j0 + 4 < L ? j0 + 4 : j0));   // next chunk's keys, half a chunk ahead
+                            wq[4] = nq.lo; wk[4] = nk.lo; w0[4] = n0.lo; w1[4] = n1.lo;
+                            cq[0] = cq[1]; cq[1] = nq;
+                            ck[0] = ck[1]; ck[1] = nk;
+                            c0[0] = c0[1]; c0[1] = n0;
+                            c1[0] = c1[1]; c1[1] = n1;
+                        }
+                        row(1); row(0);                              // the row that needs the new piece goes last
+#else
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            const f4 xq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 4 * t);
+                            const f4 xk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 4 * t);
+                            const f4 x0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 4 * t);
+                            const f4 x1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 4 * t);
+                            wq[2 * t] = xq.lo; wq[2 * t + 1] = xq.hi;
+                            wk[2 * t] = xk.lo; wk[2 * t + 1] = xk.hi;
+                            w0[2 * t] = x0.lo; w0[2 * t + 1] = x0.hi;
+                            w1[2 * t] = x1.lo; w1[2 * t + 1] = x1.hi;
+                        }
+                        row(0); row(1); row(2); row(3);
+#endif
+                        __builtin_amdgcn_sched_barrier(0);           // keep the unrolled chunks in order (register pressure)
+                    }
+            };
+            bool redo = false;
             if (active) {
-                float qa[4], qb[4], m[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float q = sq[i0 + 2 * r];
                     qa[r] = q * a_qk;
                     qb[r] = q * a_qr;
-                    m[r] = EXACT ? -INFINITY
-                                 : g.bound_shift + fabsf(qa[r]) * kmx + fabsf(qb[r]) * tqmax + kmx * tkmax;
                 }
-                f2 l2[4], av0[4], av1[4], ae0[4], ae1[4];
+                if constexpr (EXACT) {
+                    sweep_rows(std::true_type{});
+                } else {
+                    sweep_rows(std::false_type{});
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { l2[r] = av0[r] = av1[r] = ae0[r] = ae1[r] = (f2)(0.f); }
-                const float* kp = sq + L;
-                const float* vp = sq + 2 * L;
-#if MEDT_F4R_CARRY
-                // The windows of consecutive chunks overlap in two of their three 16-byte pieces: piece t of chunk c is
-                // piece t - 1 of chunk c + 1.  The loop is fully unrolled, so carrying the two pieces is a renaming, and a
-                // chunk fetches ONE new piece per table (7 ds_read_b128 per chunk instead of 11 + 2 ds_read2st64_b64).
-                // Measured on the roofline shape (profiles/r05_fwd_variants_*.json): 185 -> 169 us with the 4-byte movers.
-                // (-DMEDT_F4R_CARRY=0 builds the round-4 body for A/B runs.)
-                f4 cq[2], ck[2], c0[2], c1[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    cq[t] = *reinterpret_cast<const f4*>(tabl + 0 * CS + 4 * t);
-                    ck[t] = *reinterpret_cast<const f4*>(tabl + 2 * CS + 4 * t);
-                    c0[t] = *reinterpret_cast<const f4*>(tabl + 4 * CS + 4 * t);
-                    c1[t] = *reinterpret_cast<const f4*>(tabl + 6 * CS + 4 * t);
+                    for (int r = 0; r < 4; ++r) redo |= !(l2[r].x + l2[r].y > 1e-30f);      // bound too loose for this row
                 }
-                f4 kc = *reinterpret_cast<const f4*>(kp);
-#endif
-#pragma unroll
-                for (int j0 = 0; j0 < L; j0 += 4) {
-#if MEDT_F4R_CARRY
-                    const f4 k4 = kc;
-#else
-                    const f4 k4 = *reinterpret_cast<const f4*>(kp + j0);
-#endif
-                    const f4 v0 = *reinterpret_cast<const f4*>(vp + j0);
-                    const f4 v1 = *reinterpret_cast<const f4*>(vp + L + j0);
-                    f2 wq[6], wk[6], w0[6], w1[6];
-                    auto row = [&](const int r) {
-                        const f2 fqa = (f2)(qa[r]), fqb = (f2)(qb[r]);
-                        if constexpr (EXACT) {
-                            f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + k4.lo * wk[3 - r]);
-                            f2 zhi = fqa * k4.hi + (fqb * wq[4 - r] + k4.hi * wk[4 - r]);
-                            const float mn = fmaxf(m[r], fmaxf(fmaxf(zlo.x, zlo.y), fmaxf(zhi.x, zhi.y)));
-                            const f2 alpha = (f2)(__builtin_amdgcn_exp2f(m[r] - mn));
-                            m[r] = mn;
-                            zlo -= (f2)(mn);
-                            zhi -= (f2)(mn);
-                            f2 plo, phi;
-                            plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
-                            phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
-                            l2[r] = l2[r] * alpha + (plo + phi);
-                            av0[r] = plo * v0.lo + (phi * v0.hi + av0[r] * alpha);
-                            av1[r] = plo * v1.lo + (phi * v1.hi + av1[r] * alpha);
-                            ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r] * alpha);
-                            ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r] * alpha);
-                        } else {
-                            const f2 zi = (f2)(-m[r]);
-                            const f2 zlo = fqa * k4.lo + (fqb * wq[3 - r] + (k4.lo * wk[3 - r] + zi));
-                            const f2 zhi = fqa * k4.hi + (fqb * wq[4 - r] + (k4.hi * wk[4 - r] + zi));
-                            f2 plo, phi;
-                            plo.x = __builtin_amdgcn_exp2f(zlo.x); plo.y = __builtin_amdgcn_exp2f(zlo.y);
-                            phi.x = __builtin_amdgcn_exp2f(zhi.x); phi.y = __builtin_amdgcn_exp2f(zhi.y);
-                            l2[r] += plo + phi;
-                            av0[r] = plo * v0.lo + (phi * v0.hi + av0[r]);
-                            av1[r] = plo * v1.lo + (phi * v1.hi + av1[r]);
-                            ae0[r] = plo * w0[3 - r] + (phi * w0[4 - r] + ae0[r]);
-                            ae1[r] = plo * w1[3 - r] + (phi * w1[4 - r] + ae1[r]);
-                        }
-                    };
-#if MEDT_F4R_CARRY
-                    wq[0] = cq[0].lo; wq[1] = cq[0].hi; wq[2] = cq[1].lo; wq[3] = cq[1].hi;
-                    wk[0] = ck[0].lo; wk[1] = ck[0].hi; wk[2] = ck[1].lo; wk[3] = ck[1].hi;
-                    w0[0] = c0[0].lo; w0[1] = c0[0].hi; w0[2] = c0[1].lo; w0[3] = c0[1].hi;
-                    w1[0] = c1[0].lo; w1[1] = c1[0].hi; w1[2] = c1[1].lo; w1[3] = c1[1].hi;
-                    row(3); row(2);                              // the oldest piece dies here, before the new one is fetched
-                    __builtin_amdgcn_sched_barrier(0);
-                    {
-                        const f4 nq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 8);
-                        const f4 nk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 8);
-                        const f4 n0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 8);
-                        const f4 n1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 8);
-                        kc = *reinterpret_cast<const f4*>(kp + (j0 + 4 < L ? j0 + 4 : j0));   // next chunk's keys, half a chunk ahead
-                        wq[4] = nq.lo; wk[4] = nk.lo; w0[4] = n0.lo; w1[4] = n1.lo;
-                        cq[0] = cq[1]; cq[1] = nq;
-                        ck[0] = ck[1]; ck[1] = nk;
-                        c0[0] = c0[1]; c0[1] = n0;
-                        c1[0] = c1[1]; c1[1] = n1;
-                    }
-                    row(1); row(0);                              // the row that needs the new piece goes last
-#else
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const f4 xq = *reinterpret_cast<const f4*>(tabl + 0 * CS + j0 + 4 * t);
-                        const f4 xk = *reinterpret_cast<const f4*>(tabl + 2 * CS + j0 + 4 * t);
-                        const f4 x0 = *reinterpret_cast<const f4*>(tabl + 4 * CS + j0 + 4 * t);
-                        const f4 x1 = *reinterpret_cast<const f4*>(tabl + 6 * CS + j0 + 4 * t);
-                        wq[2 * t] = xq.lo; wq[2 * t + 1] = xq.hi;
-                        wk[2 * t] = xk.lo; wk[2 * t + 1] = xk.hi;
-                        w0[2 * t] = x0.lo; w0[2 * t + 1] = x0.hi;
-                        w1[2 * t] = x1.lo; w1[2 * t + 1] = x1.hi;
-                    }
-                    row(0); row(1); row(2); row(3);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);           // keep the unrolled chunks in order (register pressure)
+            }
+            if constexpr (!EXACT) {
+                // A row whose bound was too loose (its sum underflowed) is redone on the spot with the online softmax, by
+                // the whole wave (the branch is wave-uniform; the rows are still in LDS, nothing has been written yet).
+                // Normally never taken: no flag, no memset, no repair launch behind the kernel.
+                if (wave_any(redo)) {
+                    if (active) sweep_rows(std::true_type{});
                 }
+            }
+            if (active) {
                 // results replace this sequence's q|k|v rows in LDS: its lanes all sit in this wave and have issued
                 // every read of the sweep above (in-order LDS pipe)
                 MEDT_WAVE_LOCKSTEP();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float l = l2[r].x + l2[r].y;
-                    if (!EXACT) bad |= !(l > 1e-30f);
                     const float inv = __builtin_amdgcn_rcpf(l);
                     const float o[4] = {f_sv * (av0[r].x + av0[r].y) * inv, f_sve * (ae0[r].x + ae0[r].y) * inv,
                                         f_sv * (av1[r].x + av1[r].y) * inv, f_sve * (ae1[r].x + ae1[r].y) * inv};
@@ -987,7 +1020,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd4r_kernel(AxialGeom g, c
             if (lse_out) store_super<F, AXIS>(reg, NCH, lse_out, g.G, hg, 1, g, cur);
         }
     }
-    if (!EXACT && bad) atomicOr(flag, 1u);
     if (out_partials) {
         float v[2 * OCG];
 #pragma unroll
@@ -1064,8 +1096,8 @@ int MEDT_FAST_FN(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats 
                         GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
 #define MEDT_K_EXACT(a, b, c) attn_fwd3_kernel<a, b, c, true>
 #define MEDT_K_BOUND(a, b, c) attn_fwd3_kernel<a, b, c, false>
-    if (g.rows4 && flag) {
-        // gp = 2, large problem: four rows per lane (VALU bound instead of LDS bound), same repair protocol
+    if (g.rows4) {
+        // gp = 2, large problem: four rows per lane (VALU bound instead of LDS bound); repairs itself, one launch
         // width axis: 16-byte movers when the tensors allow it (MEDT_F4R_VEC=0: the 4-byte movers, for A/B)
         static const bool vec_on = [] { const char* e = getenv("MEDT_F4R_VEC"); return !(e && atoi(e) == 0); }();
         const bool vec = vec_on && g.axis == 1 && g.nt4 == 1 && (g.W & 3) == 0 && (g.HW & 3) == 0 &&
@@ -1080,15 +1112,11 @@ int MEDT_FAST_FN(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats 
         case 128 * 2 + 0: MEDT_R4_LAUNCH(EX, 0, 128); break; case 128 * 2 + 1: MEDT_R4_LAUNCH(EX, 1, 128); break;     \
         default: set_error("rows4: no instantiation"); return MEDT_EUNSUPPORTED;                                     \
     }
+        flag = nullptr;                       // (the four-rows kernel redoes a row whose bound was too loose itself)
         if (g.bound_path) {
-            if (hipMemsetAsync(flag, 0, sizeof(unsigned), s) != hipSuccess) { set_error("attn_fwd: memset failed"); return MEDT_ELAUNCH; }
             MEDT_R4_CASES(false)
-            const int rc = launch_status("attn_fwd4r (bound)");
-            if (rc) return rc;
-            MEDT_R4_CASES(true)
-            return launch_status("attn_fwd4r (repair)");
+            return launch_status("attn_fwd4r (bound)");
         }
-        flag = nullptr;
         MEDT_R4_CASES(true)
         return launch_status("attn_fwd4r");
     }
