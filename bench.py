@@ -133,7 +133,7 @@ def roofline_leg(device, C=16, L=64, images=256, iters=20):
     # loose itself since round 5: no flag memset, no repair launch behind it); C = 32 -> memset of the repair flag + the
     # bound-referenced one-row-per-lane kernel + the exact kernel's early exit;
     # MEDT_ROWS4=0 / MEDT_BOUND_PATH=0 select the other variants
-    kname = ("attn_fwd4r_kernel<AXIS=%d,L=%d,EXACT=false>" if C // 8 == 2 else "attn_fwd3_kernel<GP=%d,AXIS=%%d,L=%%d,EXACT=false>" % (C // 8))
+    kname = ("attn_fwd4r_kernel<AXIS=%d,L=%d,EXACT=false,VEC=" + ("true" if width else "false") + ">" if C // 8 == 2 else "attn_fwd3_kernel<GP=%d,AXIS=%%d,L=%%d,EXACT=false>" % (C // 8))
     # bound: the main pass is limited by VALU issue, not by HBM (7 L C flop per position against 4 C e bytes = 28 flop/B at
     # L = 64: 224 TFLOP/s at 8 TB/s, above the 157 TFLOP/s fp32 vector peak; PMC: VALU busy 70 %, HBM traffic = the algorithmic
     # bytes) -- `frac` stays the HBM fraction SURVEY.md 8(d) defines, `valu_frac` is the fraction of the roof that binds
