@@ -16,9 +16,9 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work
  *     is enqueued on it, nothing synchronises -> the calls are hipGraph-capturable.
  *   - tensors are contiguous NCHW float32 unless stated.
- *   - alignment: element alignment is enough for correctness everywhere.  The bandwidth-shaped kernels move 16 bytes per
- *     access when the tensors they touch are 16-byte aligned (what every device allocator returns) and fall back to
- *     element-wise movers otherwise -- the choice is made per call from the pointers, results are identical.
+ *   - alignment: tensors are expected 16-byte aligned (what every device allocator returns; sub-tensor views at channel or
+ *     image granularity keep it because H*W is a multiple of 4 for every shape of the networks).  Kernels that stage 16-byte
+ *     pieces through LDS check the pointers per call and fall back to element-wise movers when a tensor is not.
  *   - return 0 on success, <0 on error (MEDT_E*); medt_last_error() returns a
  *     thread-local message.  No global mutable state: safe to call concurrently
  *     from several host threads on different streams (nn.DataParallel's
