@@ -673,6 +673,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
 // (column c, c+1), c even, of row r' sits at window offsets (6 + c - 2r', +1).  Lanes with odd i0 read table
 // copy 1 (U[x]), lanes with even i0 copy 0 (U[x-3]), which makes the window base a multiple of 4 floats for
 // both and -- with the copy stride a multiple of 64 floats -- puts the two copies' windows on disjoint banks.
+// Round 5 (profiles/r05_attn_fwd_isa_account.txt): the three 16-byte pieces of a chunk's window are pieces t, t+1, t+2 of one
+// aligned sequence, and the next chunk's are t+1, t+2, t+3 -- two of the three are carried in registers across the unrolled
+// chunks (MEDT_F4R_CARRY): 7 x 16 B per 16 pairs.  EXACT = false redoes a row whose logit bound was too loose itself
+// (wave-uniform branch to the online-softmax sweep): one launch, no flag, no repair kernel behind it.
 // --------------------------------------------------------------------------- //
 #ifndef MEDT_F4R_CARRY
 #define MEDT_F4R_CARRY 1
