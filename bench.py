@@ -306,7 +306,7 @@ def main():
 
     from medt_amd import dp
     from medt_amd.optim import FlatAdam
-    torch.manual_seed(3000)                              # train.py:118
+    torch.manual_seed(3000)                              # (the reference seeds 3000 too, but at train.py:118-121, AFTER construction)
     model = build_model(args.model, args.imgsize, device)
     model.train()
     dp.broadcast_parameters(model)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MEDT_ABI_VERSION 8
+#define MEDT_ABI_VERSION 9
 
 #define MEDT_OK            0
 #define MEDT_EINVAL       -1   /* bad descriptor / null pointer / size mismatch            */
@@ -241,7 +241,10 @@ typedef struct medt_conv_desc {
     int32_t has_bn;               /* BatchNorm2d on the conv output                              */
     int32_t has_res;              /* residual added after BN (block identity / downsample)       */
     int32_t relu;                 /* ReLU last                                                   */
-    int32_t training, bn_groups;  /* as in medt_axial_desc                                       */
+    int32_t training, bn_groups;  /* as in medt_axial_desc.  `training` also means "a backward pass follows this forward":
+                                     for has_bn == 0 it changes no result, but a training-mode forward of a 3x3 layer whose
+                                     backward-data runs on the MFMA kernel leaves that kernel's flipped weights in `stats`
+                                     (below) -- pass the same value to medt_conv_block_bwd                                */
     float   eps, momentum;
     int32_t lean;                 /* scheduling hint, no effect on results.  1: the caller runs CU-filling kernels on ANOTHER
                                      stream at the same time (MedT's global branch at 256 px: persistent attention kernels that
@@ -250,7 +253,13 @@ typedef struct medt_conv_desc {
                                      workgroup -- measured: +0.5 ms on the 5.7 ms MedT-256 step, -0.02 ms on the MedT-128 step) */
 } medt_conv_desc;
 
-size_t medt_conv_stats_floats(const medt_conv_desc*);      /* 4*bn_groups*Cout if has_bn else 0 */
+/* Floats the caller must allocate for `stats` -- ALWAYS size it with this call, never by formula (ABI v9).  Layout:
+ *   [0, 4*bn_groups*Cout)                    saved BatchNorm statistics (mean, rstd, scale, shift) when has_bn, else empty;
+ *   [align_up(that, 64), + Cout*Cin*K*K)     only for training-mode K == 3 layers whose backward-data takes the MFMA kernel
+ *                                            (has_bn or not): the flipped / transposed weights, written by the forward (or by
+ *                                            the flush of the queue bound to its stream) and read by medt_conv_block_bwd.
+ * 0 means "no stats buffer needed" (pass NULL or a dummy).  The same buffer goes to medt_conv_block_fwd and _bwd. */
+size_t medt_conv_stats_floats(const medt_conv_desc*);
 size_t medt_conv_workspace_bytes(const medt_conv_desc*);   /* max over fwd and bwd              */
 
 /* z: conv output (N,Cout,Ho,Wo), kept for backward when has_bn (pass z == y otherwise). */

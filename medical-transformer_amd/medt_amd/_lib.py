@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: provides the HIP runtime the lib
 from .build import LIB_PATH
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MedtError(RuntimeError):

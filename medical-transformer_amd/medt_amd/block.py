@@ -8,8 +8,8 @@ save, and launch nothing -- the autograd graph, and with it the whole backward, 
 
 `block_forward` (default; MEDT_BLOCK_BWD=0 disables) wraps the same forward launch into ONE autograd Function whose backward is the
 one-launch block backward (medt_wopos_block_bwd): six dependent launches -> one.  That kernel is verified against the
-reference fixture on the CPU lane emulator (tests/test_lane_emu.py) and is OFF by default until it has been run and timed
-on the GPU.
+reference fixture on the CPU lane emulator (tests/test_lane_emu.py) and, since round 5, on the MI355X (tests/test_block_gpu.py);
+it is ON by default.
 """
 from __future__ import annotations
 

@@ -121,7 +121,9 @@ class ConvBlockFn(torch.autograd.Function):
                 raise L.MedtError("conv block: " + lib.medt_last_error().decode())
             ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
             bnp = _bn_ptrs(cfg.bn, training) if has_bn else None
-            q = DEFER.recording() if has_bn else None
+            # (recorded jobs write into stats at the flush: the BatchNorm finalisation, and the weight flip of a training-mode
+            #  3x3 layer with or without BatchNorm -- the queue keeps both buffers alive until then)
+            q = DEFER.recording() if (has_bn or stats.numel() > 1) else None
             L.check(lib.medt_conv_block_fwd(C.byref(desc), x.data_ptr(), w.data_ptr(), L.ptr(bias),
                                             C.byref(bnp) if has_bn else None, L.ptr(res), z.data_ptr(), y.data_ptr(),
                                             stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "medt_conv_block_fwd")

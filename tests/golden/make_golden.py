@@ -61,7 +61,10 @@ def probe_matrix(name: str, numel: int, seed: int) -> torch.Tensor:
 FULL_GRAD_KEYS = ("relative", "f_qr", "f_kr", "f_sv", "f_sve", "bn_similarity.weight", "adjust.weight", "adjust.bias")
 
 
-FACTORY_SEED = 3000      # reference train.py:118 (and bench.py): torch.manual_seed(3000) before the model is built
+FACTORY_SEED = 3000      # bench.py's initial state: torch.manual_seed(3000) BEFORE the model is built.  (The reference seeds 3000 at
+                         # train.py:118-121, AFTER building the model at :95-107 -- its initial weights are unseeded, so no fixture can hold
+                         # "the" state train.py starts from; this is a factory-initialised state of the same distribution, and the one
+                         # bench.py times.)
 
 
 def _run_reference(model_name, S, N, seed, mode, dtype, variant=0, factory_init=False):
@@ -177,7 +180,7 @@ def model_fixture(model_name, S, N, seed, mode):
 
 
 def factory_fixture(model_name, S, N):
-    """The state that is actually trained: FACTORY initialisation under torch.manual_seed(3000) (train.py:118 / bench.py), train
+    """bench.py's initial state: FACTORY initialisation under torch.manual_seed(3000) before construction (see FACTORY_SEED), train
     mode, bench.py's synthetic batch, gates frozen.  Reference float64 logits / loss / gradient summaries, the reference's own
     float32 noise on this state (eight float32 runs), and a checksum of the initial state_dict so that a consumer can tell
     that its own same-seed initialisation is the reference's."""
@@ -217,7 +220,7 @@ def factory_fixture(model_name, S, N):
     return fx
 
 
-def sensitivity_fixture(model_name, S, N, seed):
+def sensitivity_fixture(model_name, S, N, seed, factory_init=False):
     """How far the REFERENCE's own float64 training-mode logits move when its input image is perturbed by one rounding of a
     given precision (relative +-eps, uniform): the conditioning of the train-mode network (batch-statistic BatchNorm through
     ~100 layers).  eps = 2^-9 is ONE bfloat16 rounding of the input -- what any bf16 storage inside the network amounts to
@@ -228,7 +231,7 @@ def sensitivity_fixture(model_name, S, N, seed):
         ref.load_state_dict(O.randomize_state(ref.state_dict(), seed))
     ref = ref.double()
     ref.train()
-    x, _ = seeded_input(seed + 1, N, 3, S)
+    x, _ = seeded_input(FACTORY_SEED if factory_init else seed + 1, N, 3, S)      # (factory state: bench.py's batch, as in factory_fixture)
     sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
     with torch.no_grad():
         base = ref(x.double())
@@ -238,8 +241,8 @@ def sensitivity_fixture(model_name, S, N, seed):
             g = torch.Generator().manual_seed(5)
             xp = x.double() * (1 + eps * (torch.rand(x.shape, generator=g, dtype=torch.float64) * 2 - 1))
             out[name] = ((ref(xp) - base).abs().max() / base.abs().max()).item()
-    return {"model": model_name, "S": S, "N": N, "seed": seed, "mode": "train",
-            "logits_rel_change_for_input_rounding": out}
+    return {"model": model_name, "S": S, "N": N, "seed": FACTORY_SEED if factory_init else seed, "mode": "train",
+            "state": "factory" if factory_init else "randomize_state", "logits_rel_change_for_input_rounding": out}
 
 
 def layer_fixture(kind, C, L, width, stride, N, seed):
@@ -381,12 +384,21 @@ def main():
         ("axialunet", 64, 2, 103, "train"),
         ("logo", 128, 1, 104, "evalgrad"),
         ("MedT", 256, 1, 105, "eval"),
+        ("MedT", 256, 2, 108, "train"),          # BASELINE configs[4]'s per-GPU shard (bs 16 over 8 GPUs): every gradient, train mode
+        ("MedT", 256, 2, 108, "evalgrad"),
     ]
     if "sensitivity_gatedaxialunet_S128_N8.json".startswith(only):
         import json
         with open(os.path.join(HERE, "sensitivity_gatedaxialunet_S128_N8.json"), "w") as f:
             json.dump(sensitivity_fixture("gatedaxialunet", 128, 8, 107), f, indent=1)
         print("wrote sensitivity_gatedaxialunet_S128_N8.json")
+    # the same question at bench.py's factory state (round 6): is "no tolerance exists for bf16 storage in train mode" a property of
+    # the network or of randomize_state's weights?
+    if "sensitivity_factory_gatedaxialunet_S128_N8.json".startswith(only):
+        import json
+        with open(os.path.join(HERE, "sensitivity_factory_gatedaxialunet_S128_N8.json"), "w") as f:
+            json.dump(sensitivity_fixture("gatedaxialunet", 128, 8, FACTORY_SEED, factory_init=True), f, indent=1)
+        print("wrote sensitivity_factory_gatedaxialunet_S128_N8.json")
     # the trained state itself: factory initialisation under seed 3000, BASELINE configs[2] (MedT bs 4) and configs[1] (gated bs 8)
     for name, S, N in (("MedT", 128, 4), ("gatedaxialunet", 128, 8)):
         fn = f"factory_{name}_S{S}_N{N}.npz"

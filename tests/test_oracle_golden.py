@@ -167,7 +167,7 @@ def test_fast_bn_mode_is_the_same_arithmetic():
 
 
 def test_oracle_at_the_factory_state_matches_reference_fixture():
-    """The state that is actually trained (factory initialisation under seed 3000, train mode, bench.py's batch; fixture generated
+    """bench.py's initial state (factory initialisation under seed 3000 before construction, train mode, bench.py's batch; fixture generated
     from the reference by make_golden.py::factory_fixture): the product's module surface gives the reference's initial state
     (checksum), and the oracle reproduces the reference's float64 logits and loss on it (fixture logits are stored in float32)."""
     import lib as droplib
