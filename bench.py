@@ -389,10 +389,29 @@ def main():
 
         with torch.no_grad():
             result["fwd_ms_per_image"] = time_fwd(infer, x, 50)
-            result["fwd_ms_per_image_bs1"] = time_fwd(infer, x[:1].contiguous(), 50)
+            result["fwd_ms_per_image_graph"] = result["fwd_ms_per_image"]
+            # test.py's loop (reference test.py:106-119: loader batch size 1): since round 6 it gathers `--gather` (default 4)
+            # loader items per replay -- eval mode, running statistics: the images do not interact -- so a batch-size-1 loader
+            # costs one replay per FOUR images plus the concatenation; one image per replay is reported beside it
+            singles = [x[k:k + 1].contiguous() for k in range(x.shape[0])]
+            def gathered(xs):
+                return infer(torch.cat(xs))
+            for _ in range(3):
+                gathered(singles)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                gathered(singles)
+            torch.cuda.synchronize()
+            result["fwd_ms_per_image_bs1"] = (time.perf_counter() - t1) / 50 / len(singles) * 1e3
+            result["fwd_ms_per_image_bs1_single_replay"] = time_fwd(infer, x[:1].contiguous(), 50)
             result["fwd_ms_per_image_eager"] = time_fwd(model, x, 10)
-            result["fwd_path"] = "hipGraph replay of the eval-mode forward (InferStep); eager = one Python-issued launch per kernel"
-        log(f"eval fwd {result['fwd_ms_per_image']:.3f} ms/image replayed (bs {args.batch}), {result['fwd_ms_per_image_bs1']:.3f} at bs 1, "
+            result["fwd_path"] = ("fwd_ms_per_image (= _graph): hipGraph replay of the eval-mode forward (InferStep) at the bench batch -- "
+                                  "NOT comparable with BENCH_r01-r04's fwd_ms_per_image, which was the eager forward (now "
+                                  "fwd_ms_per_image_eager: one Python-issued launch per kernel); _bs1: test.py's loop, batch-size-1 "
+                                  f"loader items gathered {len(singles)} per replay (test.py --gather); _bs1_single_replay: one image per replay")
+        log(f"eval fwd {result['fwd_ms_per_image']:.3f} ms/image replayed (bs {args.batch}), {result['fwd_ms_per_image_bs1']:.3f} for a "
+            f"batch-size-1 loader gathered {len(singles)} per replay, {result['fwd_ms_per_image_bs1_single_replay']:.3f} one image per replay, "
             f"{result['fwd_ms_per_image_eager']:.3f} eager")
         if not args.no_roofline:
             result["roofline"] = roofline_leg(device)

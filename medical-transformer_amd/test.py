@@ -36,6 +36,9 @@ parser.add_argument('--device', default='cuda', type=str)
 parser.add_argument('--loaddirec', default='load', type=str)
 parser.add_argument('--imgsize', type=int, default=None)
 parser.add_argument('--gray', default='no', type=str)
+parser.add_argument('--gather', type=int, default=4,
+                    help='(not in the reference) loader items run per forward replay: in eval mode every image is normalised '
+                         'with the running statistics, so batching changes no result; 1 = one replay per image')
 
 
 def main():
@@ -66,14 +69,32 @@ def main():
     # forward + the device-side counts as ONE replayed hipGraph per image shape (medt_amd.trainer.InferStep): an eager
     # forward is ~110 dependent launches issued from Python and is host-bound
     infer = InferStep(model)
+    # The reference's loop runs ONE image per forward (test.py:106-119, batch size 1).  One replay costs the local branch's
+    # dependent chain whatever the batch (0.8 ms for one image, 0.74 ms for four: bench.py's fwd_ms_per_image_bs1 / fwd_ms_per_image),
+    # and in eval mode the images of a batch do not interact -- so --gather loader items of the same shape share a replay.  The
+    # last, shorter batch is padded with copies of its last image (same graph; the padding's outputs are dropped).
+    def run(items):
+        xs = torch.cat([it[0] for it in items] + [items[-1][0]] * (gather - len(items))).to(device)
+        ys = torch.cat([it[1].long().reshape(1, *it[0].shape[2:]) for it in items] + [items[-1][1].long().reshape(1, *items[-1][0].shape[2:])] * (gather - len(items))).to(device)
+        y_out, counts = infer(xs, ys)
+        scores.append(counts[:len(items)].clone())
+        yHaT = (y_out[:len(items)].detach().cpu().numpy() >= 0.5).astype(np.uint8) * 255
+        for k, it in enumerate(items):
+            imwrite(fulldir + it[2], yHaT[k, 1, :, :])
+
+    gather = max(1, args.gather)
+    pending = []
     for batch_idx, (X_batch, y_batch, *rest) in enumerate(valloader):
         image_filename = rest[0][0] if isinstance(rest[0][0], str) else '%s.png' % str(batch_idx + 1).zfill(3)
-        X_batch = X_batch.to(device)
-        # what performancemetrics_*.m computes offline from the PNGs, counted on the device
-        y_out, counts = infer(X_batch, y_batch.to(device).long().reshape(X_batch.shape[0], *X_batch.shape[2:]))
-        scores.append(counts.clone())
-        yHaT = (y_out.detach().cpu().numpy() >= 0.5).astype(np.uint8) * 255
-        imwrite(fulldir + image_filename, yHaT[0, 1, :, :])
+        if pending and pending[0][0].shape != X_batch.shape:
+            run(pending)
+            pending = []
+        pending.append((X_batch, y_batch, image_filename))
+        if len(pending) == gather:
+            run(pending)
+            pending = []
+    if pending:
+        run(pending)
     if scores:
         f1, iou, pa = metrics.segmentation_scores(torch.cat(scores))
         print("images {}  F1 {:.4f}  mIoU {:.4f}  PA {:.4f}".format(len(f1), f1.mean().item(), iou.mean().item(),

@@ -85,6 +85,20 @@ def test_train_then_test_cli_roundtrip(tmp_path, device):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(os.listdir(res)) == 16
+    # --gather: 16 images in replays of 3 (a padded last batch) and one image per replay (the reference's loop) write the same maps
+    import numpy as np
+    from PIL import Image
+    outs = {}
+    for gth in ("3", "1"):
+        rg = str(tmp_path / ("res" + gth))
+        r = subprocess.run([sys.executable, os.path.join(PKG, "test.py"), "--loaddirec", ckpt, "--val_dataset", d, "--direc",
+                            rg, "--batch_size", "1", "--modelname", "gatedaxialunet", "--imgsize", "128", "--gray", "no",
+                            "--gather", gth], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[gth] = {f: np.asarray(Image.open(os.path.join(rg, f))) for f in sorted(os.listdir(rg))}
+        assert len(outs[gth]) == 16
+    diff = sum(int((outs["3"][f] != outs["1"][f]).sum()) for f in outs["1"])
+    assert diff <= 4, diff                     # (pixels whose logit sits within rounding of the 0.5 threshold)
 
 
 def test_prefetcher_cpu_passthrough(tmp_path):

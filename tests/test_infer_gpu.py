@@ -124,3 +124,38 @@ def test_replayed_forward_is_faster_than_eager(device):
         eager, replay = t(model, 10), t(infer, 30)
     print(f"MedT 128 bs 4 eval forward: eager {eager * 1e3:.3f} ms, replayed {replay * 1e3:.3f} ms")
     assert replay < 0.5 * eager
+
+
+@pytest.mark.parametrize("name,S,K", [("MedT", 128, 4), ("gatedaxialunet", 128, 4)])
+def test_gathered_eval_replay_equals_single_image_replays(name, S, K, device):
+    """test.py --gather (round 6): K loader items of batch size 1 share one replay.  In eval mode BatchNorm is an affine of the
+    running statistics, so the images of a batch do not interact ARITHMETICALLY; whether the bits agree as well depends on
+    whether the batch size changes a kernel choice (tile shapes / split contractions sum in another order).  Held: label
+    maps (logit >= 0.5, reference test.py:123-124) and the device-side counts identical, logits equal to 1e-5 of their range;
+    bit-equality is reported."""
+    from medt_amd.trainer import InferStep
+    if device.type == "cpu":
+        pytest.skip("GPU only")
+    model = _model(name, S, device).eval()
+    infer = InferStep(model)
+    x, y = H.seeded_input(31, K, 3, S)
+    x, y = x.to(device), y.to(device)
+    singles, counts1 = [], []
+    for k in range(K):
+        o, c = infer(x[k:k + 1].contiguous(), y[k:k + 1].contiguous())
+        singles.append(o.clone())
+        counts1.append(c.clone())
+    want, wc = torch.cat(singles), torch.cat(counts1)
+    got, gc = infer(x, y)
+    err = H.rel_err(got, want)
+    print(f"{name}: one replay of {K} images vs {K} single-image replays: bit-equal {torch.equal(got, want)}, rel err {err:.1e}")
+    assert err < 1e-5
+    safe = (want - 0.5).abs() > 1e-4 * want.abs().max()
+    assert torch.equal((got >= 0.5)[safe], (want >= 0.5)[safe])
+    if bool(safe.all()):
+        assert torch.equal(gc, wc)
+    # the padded last batch of test.py: copies of the last image behind it change nothing for the images in front
+    xp = torch.cat([x[:2], x[1:2], x[1:2]])
+    yp = torch.cat([y[:2], y[1:2], y[1:2]])
+    gp, _ = infer(xp, yp)
+    assert torch.equal(gp[:2], got[:2]) and torch.equal(gp[2], gp[1]) and torch.equal(gp[3], gp[1])
