@@ -1318,9 +1318,16 @@ __device__ __forceinline__ void wave8_attention_bwd(const float (&gin)[CW / 4], 
     // 1. [ReLU mask,] bn_output backward over the group; this wave's d(sv) rows and normalised q | k | v rows
     blk8_bn_bwd<KO>(gm, sv, bo, grp, CW, sl * KO, img, Ro, part_o, nullptr, training, d_o);
     float* D = T;                                          // [CW][256], rows sl * KO .. of this image: this wave's
+    float dlt[2] = {0.f, 0.f};                             // Delta_i = sum_c d(sv)[c,i] sv[c,i] per head
 #pragma unroll
-    for (int k = 0; k < KO; ++k) D[(sl * KO + k) * 256 + img * 64 + lane] = d_o[k];
+    for (int k = 0; k < KO; ++k) {
+        D[(sl * KO + k) * 256 + img * 64 + lane] = d_o[k];
+        dlt[k / GP] = fmaf(d_o[k], sv[k], dlt[k / GP]);
+    }
     MEDT_WAVE_LOCKSTEP();
+    // (round 6: from here on d(sv) of this lane is read back from the wave's own rows of D -- one ds_read per use instead of eight
+    //  registers held through the two heads' sweeps; sv is dead)
+    const float* Dl = D + (sl * KO) * 256 + img * 64 + lane;
     // 2. softmax backward of this lane's rows, both heads; bn_similarity's two sums over the group
     const int i = AXIS == 1 ? (lane & 7) : (lane >> 3), sj = AXIS == 1 ? 1 : 8, base = lane - i * sj;
     // (the logits, probabilities and dZ are recomputed behind the barrier -- a dozen FMAs per pair -- instead of being held in
@@ -1331,26 +1338,22 @@ __device__ __forceinline__ void wave8_attention_bwd(const float (&gin)[CW / 4], 
 #pragma unroll
         for (int c = 0; c < HQ; ++c) qk = fmaf(qv[c], Qh[(HQ + c) * 256 + kj], qk);
 #pragma unroll
-        for (int c = 0; c < GP; ++c) dP = fmaf(dl[c], Qh[(GP + c) * 256 + kj], dP);
+        for (int c = 0; c < GP; ++c) dP = fmaf(dl[c * 256], Qh[(GP + c) * 256 + kj], dP);
         S = qk;
         P = __builtin_amdgcn_exp2f(fmaf(qk, a_qk, -lsv));
         dZv = P * (dP - dlt);
     };
-    float dlt[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const float* Qh = Q + (sl * KQ + hh * NCH) * 256 + img * 64;
         const float a_qk = blk_ldu(bs.st + 2 * bs.n + grp * G + 2 * sl + hh) * MEDT_LOG2E;
         float qv[HQ], v0 = 0.f, v1 = 0.f;
-        dlt[hh] = 0.f;
-#pragma unroll
-        for (int c = 0; c < GP; ++c) dlt[hh] = fmaf(d_o[hh * GP + c], sv[hh * GP + c], dlt[hh]);
 #pragma unroll
         for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * 256 + lane];
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             float S, P, dZv;
-            pair(Qh, qv, d_o + hh * GP, dlt[hh], a_qk, ls[hh], base + j * sj, S, P, dZv);
+            pair(Qh, qv, Dl + hh * GP * 256, dlt[hh], a_qk, ls[hh], base + j * sj, S, P, dZv);
             v0 += dZv;
             v1 = fmaf(dZv, S, v1);
         }
@@ -1390,7 +1393,7 @@ __device__ __forceinline__ void wave8_attention_bwd(const float (&gin)[CW / 4], 
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             float S, dZv;
-            pair(Qh, qv, d_o + hh * GP, dlt[hh], a_qk, ls[hh], base + j * sj, S, Pj[j], dZv);
+            pair(Qh, qv, Dl + hh * GP * 256, dlt[hh], a_qk, ls[hh], base + j * sj, S, Pj[j], dZv);
             dS[j] = fmaf(ce, dZv, fmaf(cu, S, cw));
             E[j * 64 + lane] = dS[j];
         }

@@ -124,7 +124,14 @@ static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float
     return launch_status("conv2d_fwd");
 }
 
-int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride) {
+static int conv_thin_mode() {          // MEDT_CONV_THIN: 0 off, 1 forward only, 2 backward-data only, default both
+    static const int m = [] { const char* e = getenv("MEDT_CONV_THIN"); return e ? atoi(e) : 3; }();
+    return m;
+}
+int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride, int H, int W, int pad) {
+    // (the same order as conv2d_fwd's dispatch; H = 0: a caller that only runs 1x1 layers)
+    if (H > 0 && (conv_thin_mode() & 1) && !conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo) && conv_thin_ok(N, groups, Cin, H, W, Cout, K, stride, pad))
+        return conv_thin_parts_per_group(N, groups, Cin, H, W, Cout, K, stride, pad);
     if (conv_fwd_ws_ok(Cin, Cout, K, stride, (long)N * HoWo)) return cdiv((N / groups) * HoWo, 64);
     if (!conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo)) return conv2d_parts_per_group(N, groups, HoWo);
     if (conv_mfma_scratch_floats(N, groups, HoWo, Cin, Cout, K) > 0) return conv2d_parts_per_group(N, groups, HoWo);
@@ -281,6 +288,9 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
     if (!y_bf16 && conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
         (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
         return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
+    // thin-channel 3x3 layers (Cout < 32 or Cin * 9 < 256: refused above) on the LDS-patch MFMA kernel of round 6
+    if (!y_bf16 && (conv_thin_mode() & 1) && !conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) && conv_thin_ok(N, groups, Cin, H, W, Cout, K, stride, pad))
+        return conv_thin_fwd(x, w, bias, nullptr, y, partials, N, groups, Cin, H, W, Cout, relu, s);
     if (conv_fwd_ws_ok(Cin, Cout, K, stride, (long)N * Ho * Wo))
         return conv2d_fwd_ws(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
     switch (K) {
@@ -534,16 +544,30 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
 }
 
 // the backward-data of this layer runs as a forward MFMA convolution with flipped weights (conv_mfma_bwd_data_s1)
+// backward-data as a forward convolution of dY with the flipped weights: the MFMA tile kernels, or (round 6) the thin-channel kernel
+static bool conv2d_bwd_data_thin(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    return (conv_thin_mode() & 2) && stride == 1 && K == 3 && pad == 1 && !conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) &&
+           conv_thin_ok(N, 1, Cout, H, W, Cin, K, 1, 1);
+}
 bool conv2d_bwd_data_flips(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
-    return stride == 1 && K - 1 - pad >= 0 && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W);
+    return stride == 1 && K - 1 - pad >= 0 &&
+           (conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) || conv2d_bwd_data_thin(N, Cin, H, W, Cout, K, stride, pad));
 }
 
 int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratch, float* ksplit_scratch, int N, int Cin,
                     int H, int W, int Cout, int K, int stride, int pad, hipStream_t s, const float* add, bool wt_ready) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     if (abl_skip(N >= 16 ? (K == 3 ? "conv3_dgrad_l" : "conv1_dgrad_l") : (K == 3 ? "conv3_dgrad_g" : "conv1_dgrad_g"))) return MEDT_OK;
-    // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K   (the `add` epilogue is VALU-path only)
-    if (!add && wt_scratch && conv2d_bwd_data_flips(N, Cin, H, W, Cout, K, stride, pad) &&
+    // as a forward convolution of dY: "Cout" = Cin, contraction over Cout*K*K
+    if (wt_scratch && conv2d_bwd_data_thin(N, Cin, H, W, Cout, K, stride, pad)) {      // (its epilogue takes the fan-in addend)
+        if (!wt_ready) {
+            int rc = conv_flip_weights(w, wt_scratch, Cout, Cin, K, s);
+            if (rc) return rc;
+        }
+        return conv_thin_fwd(dy, wt_scratch, nullptr, add, dx, nullptr, N, 1, Cout, H, W, Cin, 0, s);
+    }
+    // (the `add` epilogue: thin kernel above and the VALU path only)
+    if (!add && wt_scratch && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) && conv2d_bwd_data_flips(N, Cin, H, W, Cout, K, stride, pad) &&
         (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K) == 0))
         return conv_mfma_bwd_data_s1(dy, w, wt_scratch, ksplit_scratch, dx, N, Cin, H, W, Cout, K, pad, s, wt_ready);
     switch (K) {

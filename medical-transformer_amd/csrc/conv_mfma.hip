@@ -480,6 +480,349 @@ int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, 
     return launch_status("conv_stem7_fwd");
 }
 
+// --------------------------------------------------------------------------- //
+// THIN-CHANNEL 3x3 convolutions on the matrix cores (round 6).  conv_use_mfma refuses Cout < 32 and Cin * 9 < 256 -- the 64 x 64
+// implicit-GEMM tile would be mostly padding -- so the global stem (conv2 8 -> 128, conv3 128 -> 8 at 64 x 64), the decoders
+// (decoder4 64 -> 32, decoder5 32 -> 16, decoderf 16 -> 16 on 32 ... 128-wide maps), decoder5_p and every backward-data twin of
+// those ran the VALU direct kernels at ~10 TFLOP/s (16 - 32 us each for 150 - 300 MFLOP; lib/models/axialnet.py:530-531, 571-588,
+// 650-652 of the reference).  Here the LDS-patch scheme of conv3x3_rows16_fwd_kernel with the tile turned around:
+//   * MFMA M = 16 OUTPUT CHANNELS (a row block; NRB = 1 or 2 row blocks per workgroup -- 8 channels run a half-empty block),
+//     MFMA N = 16 consecutive output COLUMNS of one image row, K-step = 4 input channels of one tap;
+//   * a workgroup owns RG * TR rows x 16 * TCW columns of one image (TCW = min(4, W / 16) column tiles over the four waves,
+//     RG = 4 / TCW row groups); a wave owns one column tile x TR rows x all NRB row blocks: its B fragments of a K-step are
+//     (TR + 2) x 3 shifted reads of ONE patch column strip for 9 TR NRB MFMAs;
+//   * per chunk of CC input channels (16, or 8 when Cin is 8) the zero-padded halo patch Ps[CC][RG TR + 2][16 TCW + 2] and the
+//     weight slab As[16 NRB][9 CC] are staged in LDS once -- every load of the NEXT chunk is in flight under the MFMAs of this one;
+//   * conflict-free fragment reads: patch channel stride CST = 16 (mod 64)  [bank = 16 (l >> 4) + (l & 15) + const],
+//     weight row stride 9 CC + 4  [bank = 20 | 12 (l & 15) + 9 (l >> 4) + const: 16 multiples of 4 plus residues 0..3];
+//   * epilogue: bias / ReLU / the fan-in addend of a backward-data call (`add`), BatchNorm partial sums in double (one row per
+//     workgroup tile, channel-block columns), 64-byte row segments of y.
+// Backward-data = the same kernel on dY with the flipped weights (conv2d_bwd_data: wt[c][o][8 - t]).
+// --------------------------------------------------------------------------- //
+struct ThinPlan { int ok, CC, NRB, TR, KG, TCW, RG, RST, CST, AST, rows_wg, cols_wg, wgs_img, ppg, grid_y; size_t lds; };
+
+ThinPlan conv_thin_plan(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    static const bool off = [] { const char* e = getenv("MEDT_CONV_THIN"); return e && e[0] == '0'; }();
+    static const int force_tr = [] { const char* e = getenv("MEDT_THIN_TR"); return e ? atoi(e) : 0; }();      // (debugging: rows per wave)
+    ThinPlan p{};
+    if (off || K != 3 || stride != 1 || pad != 1 || W < 16 || (W & 15) || (Cin & 7) || Cin < 8 || Cout < 1 || groups < 1 || N % groups) return p;
+    if ((long)N * H * W < 4096) return p;                        // (tiny maps: the split-K / small-map kernels)
+    p.CC = (Cin & 15) ? 8 : 16;
+    p.TCW = W >= 64 ? 4 : (W >= 32 ? 2 : 1);
+    if (W % (16 * p.TCW)) return p;
+    p.RG = 4 / p.TCW;
+    // the largest (TR, NRB) that still gives the chip a workgroup per CU; else the finest split
+    const int rbs = cdiv(Cout, 16);
+    int best_tr = 0, best_nrb = 0;
+    long best_wgs = -1;
+    for (int tr = 4; tr >= 1; tr >>= 1) {
+        if (H % (p.RG * tr) || (force_tr && tr != force_tr)) continue;
+        for (int nrb = 2; nrb >= 1; --nrb) {
+            if (nrb > rbs) continue;
+            if (p.CC == 8 && nrb == 1 && rbs > 1) continue;     // (instances: CC = 8 only with two row blocks unless Cout <= 16)
+            const long wgs = (long)N * (H / (p.RG * tr)) * (W / (16 * p.TCW)) * cdiv(rbs, nrb);
+            const bool better = best_wgs < 0 || (best_wgs < 256 && wgs > best_wgs);
+            if (better) { best_tr = tr; best_nrb = nrb; best_wgs = wgs; }
+        }
+    }
+    if (best_wgs < 0) return p;
+    p.TR = best_tr; p.NRB = best_nrb;
+    p.rows_wg = p.RG * p.TR; p.cols_wg = 16 * p.TCW;
+    p.RST = p.cols_wg + 2;
+    const int pr = p.rows_wg + 2;
+    p.CST = pr * p.RST;
+    p.CST += ((16 - p.CST) % 64 + 64) % 64;                      // = 16 (mod 64)
+    p.AST = 9 * p.CC + 4;
+    p.wgs_img = (H / p.rows_wg) * (W / p.cols_wg);
+    p.ppg = (N / groups) * p.wgs_img;
+    p.grid_y = cdiv(rbs, p.NRB);
+    // K-groups (see the kernel): deep contractions at one row per wave on a grid that does not fill the SIMDs by itself
+    static const int force_kg = [] { const char* e = getenv("MEDT_THIN_KG"); return e ? atoi(e) : 0; }();
+    const int nch = Cin / p.CC;
+    p.KG = 1;
+    if (p.CC == 16 && p.TR == 1 && best_wgs <= 512) p.KG = (nch % 4 == 0) ? 4 : ((nch % 2 == 0) ? 2 : 1);
+    if (force_kg && p.CC == 16 && p.TR == 1 && nch % force_kg == 0 && (force_kg == 1 || force_kg == 2 || force_kg == 4)) p.KG = force_kg;
+    p.lds = (size_t)p.KG * ((size_t)p.CC * p.CST + (size_t)16 * p.NRB * p.AST) * sizeof(float) + 4 * 2 * 16 * 2 * sizeof(double);
+    p.ok = 1;
+    return p;
+}
+
+bool conv_thin_ok(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    return conv_thin_plan(N, groups, Cin, H, W, Cout, K, stride, pad).ok != 0;
+}
+int conv_thin_parts_per_group(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
+    return conv_thin_plan(N, groups, Cin, H, W, Cout, K, stride, pad).ppg;
+}
+
+struct ThinArgs {
+    const float *x, *w, *bias, *add;
+    float *y, *partials;
+    int Cin, H, W, Cout, relu;
+    int TCW, RG, RST, CST, PR, PC, cwg;          // geometry of the plan; cwg = column workgroups per image row band
+    unsigned m_pc, m_prpc;                       // ceil(2^32 / PC), ceil(2^32 / (PR PC)): exact quotients for u < 2^16
+};
+
+// KG > 1 (deep contractions on few workgroups -- conv3 128 -> 8 and conv2's backward-data at 64 x 64: 256 tiles, 8 chunks): KG groups of
+// four waves share the workgroup's output tile and split the CHUNKS (group kg takes chunks kg, kg + KG, ...), each with its own patch /
+// weight-slab region, in lockstep behind the same two barriers per round; the groups' totals are combined through LDS in fixed order.
+// With one workgroup per CU a single four-wave group had one wave per SIMD and paid a full global round trip + two barriers per chunk
+// (measured: 40 us for conv3's 302 MFLOP, 8 rounds); KG = 4 runs two rounds with four waves per SIMD.
+template <int CC, int NRB, int TR, int KG>
+__global__ __launch_bounds__(MEDT_THREADS * KG) void conv3x3_thin_fwd_kernel(ThinArgs a) {
+    constexpr int AST = 9 * CC + 4, KS = CC / 4;
+    // patch staging, main columns: a load instruction of a wave = RG "units" (c, patch row) x 16 TCW columns; unit v = pr * CC + c, so
+    // the RG units of one load share the patch row and have consecutive channels: scalar base + one chunk-invariant lane offset
+    constexpr int NU = CC * (TR + 2) / 4;                // loads per wave and chunk at most (RG = 1: PR = TR + 2 rows, 4 units per round)
+    constexpr int NH = (2 * CC * (4 * TR + 2) + MEDT_THREADS - 1) / MEDT_THREADS;     // halo-column elements per thread at most
+    constexpr int WROWS = MEDT_THREADS / CC;             // weight-slab rows per pass: thread (ar, ae) loads columns ae + CC m, m < 9
+    constexpr int WP = (16 * NRB + WROWS - 1) / WROWS;   // passes
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x & (MEDT_THREADS - 1), lane = tid & 63;                     // tid: inside the K-group
+    const int wv = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3), kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const int tc = wv % a.TCW, rg = wv / a.TCW;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+    const int rows_wg = a.RG * TR, bands = H / rows_wg;
+    int b = blockIdx.x;
+    const int cw = b % a.cwg; b /= a.cwg;
+    const int band = b % bands, n = b / bands;
+    const int r0 = band * rows_wg, c0 = cw * 16 * a.TCW, o0 = blockIdx.y * 16 * NRB;
+    const int kg_floats = CC * a.CST + 16 * NRB * AST;  // one K-group's staging region
+    float* Ps = smem + kg * kg_floats;                  // [CC][CST]
+    float* As = Ps + CC * a.CST;                        // [16 NRB][AST]
+    double* Rd = reinterpret_cast<double*>(smem + KG * kg_floats);     // [4 waves][NRB][16][2]
+    const int Ktot = Cin * 9, PR = a.PR, mainw = 16 * a.TCW;
+    const float* xn = a.x + (size_t)n * Cin * HW;
+    const int ug = lane / mainw, ucol = lane - ug * mainw;             // unit inside the load's group, main column
+    const int lane_g = ug * HW + ucol, lane_p = ug * a.CST + 1 + ucol; // chunk-invariant lane parts of the global / LDS offsets
+    const int nrounds = (PR * CC) / (4 * a.RG);                        // loads per wave and chunk (RG | CC, 4 RG | PR CC: PR CC = 16 k)
+    // halo columns (patch columns 0 and PC - 1) of every unit: element h = tid + 256 i -> (unit, side)
+    int hp[NH], hg[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int h = tid + MEDT_THREADS * i, v = h >> 1, side = h & 1, pr = v / CC, c = v - pr * CC;
+        const int gr = r0 - 1 + pr, gc = side ? c0 + mainw : c0 - 1;
+        const bool in = h < 2 * PR * CC;
+        hp[i] = in ? c * a.CST + pr * a.RST + (side ? mainw + 1 : 0) : -1;
+        hg[i] = (in && gr >= 0 && gr < H && gc >= 0 && gc < W) ? c * HW + gr * W + gc : -1;
+    }
+    const int ar = tid / CC, ae = tid - ar * CC;
+    float rp[NU], rh[NH], ra[WP][9];
+    auto fetch = [&](int ch0) {
+        const float* xc = xn + (size_t)ch0 * HW;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            if (j < nrounds) {                           // (wave-uniform)
+                const int v0 = (j * 4 + wv) * a.RG, pr = v0 / CC, cb = v0 - pr * CC, gr = r0 - 1 + pr;
+                const float v = xc[cb * HW + min(max(gr, 0), H - 1) * W + c0 + lane_g];
+                rp[j] = (gr >= 0 && gr < H) ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {                  // unconditional loads (no branch per element), then select
+            const float v = xc[max(hg[i], 0)];
+            rh[i] = hg[i] >= 0 ? v : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < WP; ++q) {
+            const int o = min(o0 + ar + WROWS * q, Cout - 1);       // rows past Cout: their accumulators are never stored
+            const float* wr = a.w + (size_t)o * Ktot + ch0 * 9 + ae;
+#pragma unroll
+            for (int m = 0; m < 9; ++m) ra[q][m] = wr[CC * m];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            if (j < nrounds) {
+                const int v0 = (j * 4 + wv) * a.RG, pr = v0 / CC, cb = v0 - pr * CC;
+                Ps[cb * a.CST + pr * a.RST + lane_p] = rp[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (hp[i] >= 0) Ps[hp[i]] = rh[i];
+#pragma unroll
+        for (int q = 0; q < WP; ++q)
+            if (ar + WROWS * q < 16 * NRB) {
+#pragma unroll
+                for (int m = 0; m < 9; ++m) As[(ar + WROWS * q) * AST + ae + CC * m] = ra[q][m];
+            }
+    };
+    f32x4 acc[NRB][TR];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int t = 0; t < TR; ++t) acc[rb][t] = (f32x4)(0.f);
+    const float* arow = As + (lane & 15) * AST + (lane >> 4) * 9;
+    const float* prow = Ps + (lane >> 4) * a.CST + (rg * TR) * a.RST + 16 * tc + (lane & 15);
+    const int nit = Cin / (CC * KG);                     // rounds: K-group kg takes chunk it * KG + kg
+    fetch(kg * CC);
+    for (int it = 0; it < nit; ++it) {
+        stage();
+        __syncthreads();
+        if (it + 1 < nit) fetch(((it + 1) * KG + kg) * CC);      // flies during the MFMAs below
+        // BLOCKED summation: the chunk's 9 CC products per output are summed in fresh accumulators and added to the running totals
+        // once per chunk.  One MFMA chain over a deep contraction (conv3: 1152 terms) measured 2x the rounding error of the VALU
+        // kernel it replaces (rms 9.3e-7 vs 4.7e-7 of the output's rms, which splits the contraction over four waves) -- enough to
+        // fail the 2-image training fixture's gradient bound in the ill-conditioned batch-statistics network (profiles/r06_thin_precision.txt).
+        // With one output tile per wave the k-steps alternate between two chains (an MFMA need not wait for its predecessor).
+        constexpr int NA = (TR * NRB == 1) ? 2 : 1;
+        f32x4 cacc[NA][NRB][TR];
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int t = 0; t < TR; ++t) cacc[q][rb][t] = (f32x4)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float av[NRB][9], bv[TR + 2][3];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) av[rb][t] = arow[rb * 16 * AST + ks * 36 + t];
+#pragma unroll
+            for (int r = 0; r < TR + 2; ++r)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) bv[r][kw] = prow[ks * 4 * a.CST + r * a.RST + kw];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int t = 0; t < TR; ++t)
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb)
+                            cacc[(ks * 9 + kh * 3 + kw) % NA][rb][t] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][kh * 3 + kw], bv[t + kh][kw], cacc[(ks * 9 + kh * 3 + kw) % NA][rb][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {            // (element-wise: the lane emulator's vector shim has no operator+=)
+                    float c = cacc[0][rb][t][r];
+                    if (NA == 2) c += cacc[1][rb][t][r];
+                    acc[rb][t][r] += c;
+                }
+            }
+        __syncthreads();
+    }
+    if (KG > 1) {
+        // the K-groups' totals meet in LDS (the staging regions are free behind the loop's last barrier): group 0 adds groups 1 .. KG - 1
+        // in that order -- a fixed summation order, bit-reproducible
+        float* X = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wv) * (NRB * TR * 4 * 64) + lane;
+        if (kg > 0) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[((rb * TR + t) * 4 + r) * 64] = acc[rb][t][r];
+        }
+        __syncthreads();
+        if (kg == 0)
+#pragma unroll
+        for (int q = 1; q < KG; ++q) {
+            const float* Y = smem + ((q - 1) * 4 + wv) * (NRB * TR * 4 * 64) + lane;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rb][t][r] += Y[((rb * TR + t) * 4 + r) * 64];
+        }
+    }
+    // D[(lane>>4)*4 + r][lane&15] of (rb, t)  ->  o = o0 + 16 rb + (lane>>4)*4 + r,  position (r0 + rg TR + t, c0 + 16 tc + (lane&15))
+    const int col = c0 + 16 * tc + (lane & 15), row0 = r0 + rg * TR;
+    if (kg == 0)
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * rb + (lane >> 4) * 4 + r;
+            if (o < Cout) {
+                const float bo = a.bias ? a.bias[o] : 0.f;
+                const size_t e0 = ((size_t)n * Cout + o) * HW + (size_t)row0 * W + col;
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    float v = acc[rb][t][r] + bo;
+                    if (a.add) v += a.add[e0 + (size_t)t * W];
+                    s1[r] += v;
+                    s2[r] = fmaf(v, v, s2[r]);
+                    a.y[e0 + (size_t)t * W] = a.relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+        if (a.partials) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double pa = s1[r], pb = s2[r];           // (double from the cross-lane tree on: block_sum_d, medt_common.h)
+#pragma unroll
+                for (int m = 8; m > 0; m >>= 1) { pa += __shfl_xor(pa, m, 64); pb += __shfl_xor(pb, m, 64); }   // over lane & 15
+                if ((lane & 15) == 0) {
+                    double* d = Rd + ((wv * NRB + rb) * 16 + (lane >> 4) * 4 + r) * 2;
+                    d[0] = pa; d[1] = pb;
+                }
+            }
+        }
+    }
+    if (a.partials) {
+        __syncthreads();                                 // (every K-group arrives; only group 0 has written Rd and goes on)
+        if (kg == 0 && tid < 16 * NRB) {                            // the four waves hold the four quarters of the workgroup's positions
+            const int o = o0 + tid;
+            if (o < Cout) {
+                double sa = 0.0, sb = 0.0;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) { sa += Rd[(w4 * 16 * NRB + tid) * 2]; sb += Rd[(w4 * 16 * NRB + tid) * 2 + 1]; }
+                double* dst = reinterpret_cast<double*>(a.partials) + ((size_t)blockIdx.x * Cout + o) * 2;
+                dst[0] = sa;
+                dst[1] = sb;
+            }
+        }
+    }
+}
+
+int conv_thin_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* partials, int N, int groups,
+                  int Cin, int H, int W, int Cout, int relu, hipStream_t s) {
+    const ThinPlan p = conv_thin_plan(N, groups, Cin, H, W, Cout, 3, 1, 1);
+    if (!p.ok) { set_error("conv_thin_fwd: shape not supported"); return MEDT_EUNSUPPORTED; }
+    if (abl_skip("conv_thin")) return MEDT_OK;
+    ThinArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.add = add; a.y = y; a.partials = partials;
+    a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+    a.TCW = p.TCW; a.RG = p.RG; a.RST = p.RST; a.CST = p.CST; a.PR = p.rows_wg + 2; a.PC = p.cols_wg + 2; a.cwg = W / p.cols_wg;
+    a.m_pc = (unsigned)(0x100000000ull / (unsigned)a.PC) + 1u;
+    a.m_prpc = (unsigned)(0x100000000ull / (unsigned)(a.PR * a.PC)) + 1u;
+    const dim3 grid((unsigned)(N * p.wgs_img), (unsigned)p.grid_y), block(MEDT_THREADS * p.KG);
+#define MEDT_THIN(CCv, NRBv, TRv, KGv) hipLaunchKernelGGL((conv3x3_thin_fwd_kernel<CCv, NRBv, TRv, KGv>), grid, block, p.lds, s, a)
+#define MEDT_THIN_TR(CCv, NRBv)                         \
+    do {                                                \
+        if (p.TR == 4) MEDT_THIN(CCv, NRBv, 4, 1);      \
+        else if (p.TR == 2) MEDT_THIN(CCv, NRBv, 2, 1); \
+        else MEDT_THIN(CCv, NRBv, 1, 1);                \
+    } while (0)
+    if (p.KG > 1) {                                      // (CC = 16, one row per wave; > 64 KB of LDS with four K-groups)
+        static unsigned char attr[4][64];
+        int rc;
+        if ((rc = lds_opt_in((const void*)conv3x3_thin_fwd_kernel<16, 1, 1, 4>, attr[0], "conv3x3_thin_fwd")) ||
+            (rc = lds_opt_in((const void*)conv3x3_thin_fwd_kernel<16, 2, 1, 4>, attr[1], "conv3x3_thin_fwd")) ||
+            (rc = lds_opt_in((const void*)conv3x3_thin_fwd_kernel<16, 1, 1, 2>, attr[2], "conv3x3_thin_fwd")) ||
+            (rc = lds_opt_in((const void*)conv3x3_thin_fwd_kernel<16, 2, 1, 2>, attr[3], "conv3x3_thin_fwd"))) return rc;
+        if (p.NRB == 2) { if (p.KG == 4) MEDT_THIN(16, 2, 1, 4); else MEDT_THIN(16, 2, 1, 2); }
+        else { if (p.KG == 4) MEDT_THIN(16, 1, 1, 4); else MEDT_THIN(16, 1, 1, 2); }
+    }
+    else if (p.CC == 16 && p.NRB == 2) MEDT_THIN_TR(16, 2);
+    else if (p.CC == 16) MEDT_THIN_TR(16, 1);
+    else if (p.NRB == 2) MEDT_THIN_TR(8, 2);
+    else MEDT_THIN_TR(8, 1);
+#undef MEDT_THIN_TR
+#undef MEDT_THIN
+    return launch_status("conv3x3_thin_fwd");
+}
+
 // Weight gradient of the same layers: dW[o][c][t] = sum_q dY[o][q] * X[c][q + t].  A workgroup owns 64 output channels x
 // one 16-channel chunk x all 9 taps (9 accumulator tiles per wave) over a chunk of 64-position tiles: the dY tile and the
 // halo patch are staged once per position tile and the 9 taps read shifted windows of the patch -- 144 MFMAs per wave per

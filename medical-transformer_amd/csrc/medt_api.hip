@@ -458,7 +458,7 @@ static int conv_geom(const medt_conv_desc* d, ConvGeom* g) {
     g->HoWo = g->Ho * g->Wo;
     g->ppg = conv_stem7_ok(d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad)
                  ? conv_stem7_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo)
-                 : conv_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo, d->Cin, d->Cout, d->K, d->stride);
+                 : conv_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo, d->Cin, d->Cout, d->K, d->stride, d->H, d->W, d->pad);
     g->ppg_bwd = conv2d_parts_per_group(d->N, d->has_bn ? d->bn_groups : 1, g->HoWo);       // bn_act_bwd_stats: 256 positions / part
     g->splits = conv2d_bwd_weight_splits(d->N, d->Cin, d->Cout, d->K, g->Ho, g->Wo);
     g->out_elems = (size_t)d->N * d->Cout * g->HoWo;

@@ -50,7 +50,13 @@ int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
 // ---- conv.hip ------------------------------------------------------------------
 // partials (optional): [group][part][Cout][2], part = 256-position chunk of the group's npg*Ho*Wo positions
 int conv2d_parts_per_group(int N, int groups, int HoWo);       // VALU kernel (256 positions per part)
-int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride);   // whichever kernel runs
+int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, int stride, int H = 0, int W = 0, int pad = 0);   // whichever kernel runs
+// thin-channel 3x3 stride-1 layers on the matrix cores (conv_mfma.hip, round 6): one partial row per workgroup tile
+bool conv_thin_ok(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
+int conv_thin_parts_per_group(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
+// add (optional, y's shape): y = conv + add (the fan-in addend of a backward-data call)
+int conv_thin_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* partials, int N, int groups,
+                  int Cin, int H, int W, int Cout, int relu, hipStream_t s);
 // the LDS-patch MFMA kernel of the 7x7 stride-2 stems (conv_mfma.hip): 128 positions per part
 bool conv_stem7_ok(int Cin, int H, int W, int Cout, int K, int stride, int pad);
 int conv_stem7_parts_per_group(int N, int groups, int HoWo);

@@ -61,6 +61,19 @@ CONV_CASES = [
     (8, 128, 3, 1, 1, False, True, False, True, 4, 64, 1),      # conv2 at BASELINE size (dgrad wave-split at 16384 positions)
     (64, 32, 3, 1, 1, True, False, False, False, 4, 32, 1),     # decoder4: bias, no BatchNorm
     (72, 24, 3, 2, 1, False, True, True, True, 6, 18, 3),       # ragged: stride 2, 81-position maps, grouped statistics
+    # round 6: the thin-channel LDS-patch MFMA kernel (conv3x3_thin_fwd_kernel: forward and, on the flipped weights, backward-data) --
+    # the four BASELINE-size cases above (conv2 / conv3 at 64 x 64, decoder4) run it too
+    (32, 16, 3, 1, 1, True, False, False, False, 4, 64, 1),     # decoder5 at BASELINE size (one row per workgroup, four column tiles)
+    (16, 16, 3, 1, 1, True, False, False, True, 4, 128, 1),     # decoderf at BASELINE size (four rows per wave, two column workgroups per row band)
+    (32, 16, 3, 1, 1, True, False, False, False, 64, 16, 1),    # decoder5_p: 16-wide maps (one column tile, four row groups)
+    (16, 24, 3, 1, 1, False, True, True, True, 4, 32, 2),       # 32-wide maps (two column tiles x two row groups), grouped BatchNorm, residual, Cout % 16 != 0
+    (8, 40, 3, 1, 1, False, True, False, True, 2, 64, 1),       # 8-channel chunks, three row blocks over two workgroups (the last one half empty)
+    (8, 128, 3, 1, 1, False, True, False, True, 2, 64, 1),      # conv2 at 2 images: two rows per wave (the plan follows the workgroup count)
+    (16, 16, 3, 1, 1, True, False, False, True, 2, 128, 1),     # decoderf at 2 images: two rows per wave, 16-channel chunk
+    (32, 48, 3, 1, 1, False, True, False, False, 1, 64, 1),     # two row blocks x two rows per wave
+    (128, 8, 3, 1, 1, False, True, False, True, 2, 64, 1),      # conv3 / decoder5 / decoder5_p at the 2-image fixtures' sizes
+    (32, 16, 3, 1, 1, True, False, False, False, 2, 64, 1),
+    (32, 16, 3, 1, 1, True, False, False, False, 32, 16, 1),
     # MedT's local branch at BASELINE size (16 patch groups x 4 images): the BatchNorm backward + 1x1 dgrad of these blocks is
     # ONE launch (bn_dgrad1x1_small_kernel: 256 / 512 threads, 1 / 2 / 4 input channels per thread)
     (128, 64, 1, 1, 0, False, True, False, True, 64, 4, 16),    # layer3_p.1-3 conv_down (T=256, 16 values per thread)
