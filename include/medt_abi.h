@@ -209,6 +209,26 @@ size_t medt_wopos_block_workspace_bytes(const medt_block_desc*);      /* 0: not 
 int medt_wopos_block_fwd(const medt_block_desc*, const medt_block_params*, const float* x, float* y,
                          const medt_block_saved*, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The STRIDE-2 first block of a layer with its downsample path as one launch (round 6, ABI v9): AxialBlock_wopos(C -> width ->
+ * 2*width, stride 2) + downsample = Sequential(conv1x1(C, 2*width, stride 2), BatchNorm2d) -- lib/models/axialnet.py:368-391 with
+ * :596-606 -- x (N,C,H,W) -> y (N,2*width,H/2,W/2).  `blk` fields as above except: width.stats / y_w describe the width layer
+ * WITH its AvgPool2d(2) (y_w: (N,width,H/2,W/2), pooled and ReLU'd), z2 / stats2: (N,2*width,H/2,W/2).  zd / yd / statsd: the
+ * downsample block's conv output, its BatchNorm output (the identity added behind bn2) and its saved statistics
+ * (medt_conv_stats_floats of that block).  Fused shape: 4x4 maps, C = width = 128, 4 images per BatchNorm group (layer4_p.0 of
+ * MedT at 128 px); medt_wopos_block_s2_workspace_bytes() returns 0 otherwise (or with MEDT_BLOCK_S2=0). */
+typedef struct medt_block_s2_params {
+    medt_block_params blk;
+    const float*      w_ds;      /* downsample[0].weight (2*width, C)                           :600 */
+    medt_bn_ptrs      bn_ds;     /* downsample[1]                                               :601 */
+} medt_block_s2_params;
+typedef struct medt_block_s2_saved {
+    medt_block_saved blk;
+    float *zd, *yd, *statsd;
+} medt_block_s2_saved;
+size_t medt_wopos_block_s2_workspace_bytes(const medt_block_desc*);
+int medt_wopos_block_s2_fwd(const medt_block_desc*, const medt_block_s2_params*, const float* x, float* y,
+                            const medt_block_s2_saved*, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same block's BACKWARD as one launch: dy -> dx through bn2, conv_up, the two attention layers, bn1 and conv_down,
  * the identity's gradient and `dx_add` (the other consumers' contribution to d(x), may be NULL) summed in the last phase;
  * every parameter gradient in `grads` is written (not accumulated) -- when a queue is bound to the stream the weight

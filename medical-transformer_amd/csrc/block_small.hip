@@ -240,7 +240,7 @@ __device__ __forceinline__ void wave_conv1x1(const float* __restrict__ w, int ro
 }
 
 // One AxialAttention_wopos layer on the tile A (CW x 64) -> A (in place), through Q (2CW x 64).  AXIS 0: along H, 1: along W.
-template <int CW, int GP, int AXIS, bool RELU, bool PK>
+template <int CW, int GP, int AXIS, bool RELU, bool PK, bool WY = true>          // WY: write the layer output to y (global) too
 __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, float* A, float* Q, const float* prm_q,
                                                const float* prm_s, const float* prm_o, double* part_q, double* part_s,
                                                double* part_o, float* qkv_raw, float* stacked, float* lse, float* y, int n0,
@@ -327,7 +327,7 @@ __device__ __forceinline__ void wave_attention(const float* __restrict__ w_qkv, 
         float v = fmaf(o[c], sc[c], sh[c]);
         if (RELU) v = fmaxf(v, 0.f);
         A[(g * GP + hf * HV + c) * 64 + lane] = v;
-        y[((typename BlkIdx<PK>::type)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = v;
+        if (WY) y[((typename BlkIdx<PK>::type)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = v;
     }
     MEDT_LDS_BARRIER();                                   // the layer's output tile in A; Q is free
     BLK_STAMP(stamp0 + 2);                             // bn_output + tile
@@ -750,6 +750,199 @@ __global__ __launch_bounds__(1024) void wopos_block8_fwd_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------ //
+// The STRIDE-2 "first" block of a layer on 4x4 maps (round 6): layer4_p.0 of MedT at 128 px -- AxialBlock_wopos(128 -> planes 128
+// -> 256, stride 2) + its downsample path (conv1x1 stride 2 + BatchNorm), reference lib/models/axialnet.py:368-391, :596-606:
+//   conv_down + bn1 + ReLU | height layer | width layer (its output AvgPool2d(2) behind bn_output, :251-252) | ReLU |
+//   conv_up + bn2 on the 2x2 maps | + BatchNorm(conv1x1_s2(x)) | ReLU
+// ran five launches of 9-26 us (81 us of the critical local forward chain for 6 MFLOP per patch group).  Same workgroup as the
+// block kernel above (1024 threads, lane = position, the eight-channel / two-waves-per-head slices) through the width layer;
+// behind the pooling a group has only 16 positions, so the two 256-channel contractions (conv_up, downsample) run on the matrix
+// cores: a wave owns 16 output channels (MFMA M) x the group's 16 pooled positions (N), k-step = 4 input channels, its weight
+// rows fetched as eight 16-byte loads per lane in flight under the attention phases; both BatchNorms' statistics are sums over
+// the 16 lanes of a DPP row (the accumulator layout puts a channel's 16 positions in one row).
+// Writes exactly the tensors the five per-stage forwards save (z1, y1 | qkv_raw, stacked, lse, y of both layers -- the width
+// layer's y is the pooled, ReLU'd (N, CW, 2, 2) tensor -- | zd, yd | z2), so the per-stage backward does not care.
+// ------------------------------------------------------------------------------------------------------------------------ //
+struct BlkS2Args {
+    float *z1, *y1, *qkv_h, *stk_h, *lse_h, *y_h, *qkv_w, *stk_w, *lse_w, *y_w, *z2, *zd, *yd, *y;
+    BlkBnP bn[9];                    // bn1 | height: qkv, similarity, output | width: qkv, similarity, output | bn2 | downsample's
+    double* part[9];                 // [groups][CH][2] sum / sum of squares (training)
+    int training;
+    float eps;
+};
+constexpr int S2_PST = 20;           // row stride of the pooled tiles: the four k-rows of a B fragment on disjoint 16-bank windows
+
+template <int CI, int CW, int GP>
+__global__ __launch_bounds__(1024) void wopos_block_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
+                                                                  const float* __restrict__ w_qh, const float* __restrict__ w_qw,
+                                                                  const float* __restrict__ w_up, const float* __restrict__ w_ds,
+                                                                  BlkS2Args a) {
+    constexpr bool PK = true;
+    constexpr int HW = 16, G = CW / GP, CA = CW / 16, CO = 2 * CW;
+    static_assert(CO == 256 && CI % 16 == 0 && CW % 16 == 0, "a wave = 16 output channels of the 2x2 stage");
+    constexpr int CHS[9] = {CW, 2 * CW, G, CW, 2 * CW, G, CW, CO, CO};
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                    // [CI][64]   block input (conv_down, and the stride-2 samples of the downsample path)
+    float* A = X + CI * 64;                             // [CW][64]   the running activation tile
+    float* Q = A + CW * 64;                             // [2CW][64]  normalised q | k | v; behind the width layer: the pooled tiles
+    float* prm = Q + 2 * CW * 64;                       // BatchNorm parameters of the nine BatchNorms, [CH][4] each
+    float* P = Q;                                       // [CW][S2_PST]  relu(avgpool(width layer output)): conv_up's B operand
+    float* Xs = Q + CW * S2_PST;                        // [CI][S2_PST]  x at the even positions: the downsample's B operand
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, n0 = grp * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ni = lane >> 4, p = lane & 15;
+    int poff[9];
+    {
+        int o = 0;
+#pragma unroll
+        for (int b = 0; b < 9; ++b) { poff[b] = o; o += CHS[b] * 4; }
+    }
+    // ---- everything global the block needs before its first result, in one batch: the input tile and the BatchNorm parameters
+    {
+        constexpr int NX4 = CI * 64 / 4 / 1024;          // float4 per thread
+        float4 xv[NX4];
+#pragma unroll
+        for (int k = 0; k < NX4; ++k) {
+            const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4);
+            xv[k] = *reinterpret_cast<const float4*>(x + ((unsigned)(n0 + img) * CI) * HW + (unsigned)rem * 4);
+        }
+        float pv[2][4];
+        int pdst[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                    // 1424 channels over 1024 threads: two rounds
+            const int t = tid + h * 1024;
+            pv[h][0] = 0.f; pv[h][1] = 0.f; pv[h][2] = 0.f; pv[h][3] = 1.f;
+            pdst[h] = -1;
+            int o = 0;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) {
+                if (t >= o && t < o + CHS[b]) {
+                    const int ch = t - o;
+                    pv[h][0] = a.bn[b].weight[ch];
+                    pv[h][1] = a.bn[b].bias[ch];
+                    if (!a.training) { pv[h][2] = a.bn[b].rmean[ch]; pv[h][3] = a.bn[b].rvar[ch]; }
+                    pdst[h] = poff[b] + ch * 4;
+                }
+                o += CHS[b];
+            }
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < NX4; ++k) {
+            const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4), c = rem >> 2, p4 = rem & 3;
+            *reinterpret_cast<float4*>(X + c * 64 + img * 16 + p4 * 4) = xv[k];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (pdst[h] >= 0) { prm[pdst[h]] = pv[h][0]; prm[pdst[h] + 1] = pv[h][1]; prm[pdst[h] + 2] = pv[h][2]; prm[pdst[h] + 3] = pv[h][3]; }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_down + bn1 + ReLU                                                              (axialnet.py:373-375)
+    {
+        float acc[CA], sc[CA], sh[CA];
+        wave_conv1x1<CA, CI, PK>(w_down, wv * CA, X, acc);
+#pragma unroll
+        for (int k = 0; k < CA; ++k) a.z1[((unsigned)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
+        wave_bn<CA, PK>(acc, prm + poff[0], a.part[0] + (size_t)grp * CW * 2, wv * CA, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int k = 0; k < CA; ++k) {
+            const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]), 0.f);
+            A[(wv * CA + k) * 64 + lane] = v;
+            a.y1[((unsigned)(n0 + ni) * CW + wv * CA + k) * HW + p] = v;
+        }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- height layer, width layer (its ReLU comes behind the pooling)                          (:377-379)
+    wave_attention<CW, GP, 0, false, PK>(w_qh, A, Q, prm + poff[1], prm + poff[2], prm + poff[3],
+                                         a.part[1] + (size_t)grp * 2 * CW * 2, a.part[2] + (size_t)grp * G * 2,
+                                         a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h, a.y_h, n0, a.training, a.eps, wv, 3);
+    wave_attention<CW, GP, 1, false, PK, false>(w_qw, A, Q, prm + poff[4], prm + poff[5], prm + poff[6],
+                                                a.part[4] + (size_t)grp * 2 * CW * 2, a.part[5] + (size_t)grp * G * 2,
+                                                a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w, nullptr, n0, a.training, a.eps, wv, 6);
+    // the weight rows of this wave's 16 output channels of conv_up and of the downsample convolution: A fragments of the matrix
+    // cores (lane (m, kk) holds columns 16 t + 4 kk .. + 3 of row 16 wv + m in register t), requested here -- behind the layers, whose projections need the registers -- and in flight under the pooling phase
+    const int m16 = lane & 15, kk = lane >> 4;
+    float4 wu[CW / 16], wd[CI / 16];
+#pragma unroll
+    for (int t = 0; t < CW / 16; ++t) wu[t] = *reinterpret_cast<const float4*>(w_up + (unsigned)(16 * wv + m16) * CW + 16 * t + 4 * kk);
+#pragma unroll
+    for (int t = 0; t < CI / 16; ++t) wd[t] = *reinterpret_cast<const float4*>(w_ds + (unsigned)(16 * wv + m16) * CI + 16 * t + 4 * kk);
+    MEDT_SCHED_FENCE();
+    // ---- AvgPool2d(2, 2) + ReLU -> P (and y_w, the width layer's saved output); x at the even positions -> Xs     (:251-252, :381, :596)
+    {
+#pragma unroll
+        for (int h = 0; h < CW * 16 / 1024; ++h) {
+            const int e = tid + h * 1024, c = e >> 4, q = e & 15, img = q >> 2, ph = (q >> 1) & 1, pw = q & 1;
+            const float* s4 = A + c * 64 + img * 16 + ph * 8 + pw * 2;
+            const float v = fmaxf(0.25f * ((s4[0] + s4[1]) + (s4[4] + s4[5])), 0.f);
+            P[c * S2_PST + q] = v;
+            a.y_w[((unsigned)(n0 + img) * CW + c) * 4 + (q & 3)] = v;
+        }
+#pragma unroll
+        for (int h = 0; h < CI * 16 / 1024; ++h) {
+            const int e = tid + h * 1024, c = e >> 4, q = e & 15, img = q >> 2, ph = (q >> 1) & 1, pw = q & 1;
+            Xs[c * S2_PST + q] = X[c * 64 + img * 16 + ph * 8 + pw * 2];
+        }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_up + bn2, downsample + its BatchNorm, sum, ReLU on the 2x2 maps                     (:385-389, :596-606)
+    {
+        // k-step (t, e): A = w[16 wv + m][16 t + 4 kk + e], B = tile[16 t + 4 kk + e][n]: two independent accumulator chains per output
+        medt_f4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0, d0 = u0, d1 = u0;
+        const float* Pb = P + 4 * kk * S2_PST + m16;
+        const float* Xb = Xs + 4 * kk * S2_PST + m16;
+#pragma unroll
+        for (int t = 0; t < CW / 16; ++t) {
+            u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wu[t].x, Pb[(16 * t + 0) * S2_PST], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wu[t].y, Pb[(16 * t + 1) * S2_PST], u1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wu[t].z, Pb[(16 * t + 2) * S2_PST], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wu[t].w, Pb[(16 * t + 3) * S2_PST], u1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < CI / 16; ++t) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t].x, Xb[(16 * t + 0) * S2_PST], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t].y, Xb[(16 * t + 1) * S2_PST], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t].z, Xb[(16 * t + 2) * S2_PST], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t].w, Xb[(16 * t + 3) * S2_PST], d1, 0, 0, 0);
+        }
+        // D: register r of lane (n = lane & 15, rr = lane >> 4) = output channel 16 wv + 4 rr + r at pooled position n
+        const int n = m16, rr = kk, img = n >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = 16 * wv + 4 * rr + r;
+            const unsigned eo = ((unsigned)(n0 + img) * CO + ch) * 4 + (n & 3);
+            const float uv = u0[r] + u1[r], dv = d0[r] + d1[r];
+            a.z2[eo] = uv;
+            a.zd[eo] = dv;
+            float su = 0.f, m2u = 0.f, sd = 0.f, m2d = 0.f;
+            if (a.training) {                           // the channel's 16 values sit in the 16 lanes of this DPP row
+                su = blk_row_sum(uv);
+                const float du = uv - su * (1.f / 16.f);
+                m2u = blk_row_sum(du * du);
+                sd = blk_row_sum(dv);
+                const float dd = dv - sd * (1.f / 16.f);
+                m2d = blk_row_sum(dd * dd);
+            }
+            float scu, shu, scd, shd;
+            blk_scale_shift<true>(su, m2u, 16.f, prm + poff[7] + ch * 4, a.eps, a.training, scu, shu);
+            blk_scale_shift<true>(sd, m2d, 16.f, prm + poff[8] + ch * 4, a.eps, a.training, scd, shd);
+            if (a.training && n == 0) {
+                double s, ss;
+                centered_to_raw(su, m2u, su * (1.f / 16.f), 16.0, s, ss);
+                a.part[7][((size_t)grp * CO + ch) * 2] = s;
+                a.part[7][((size_t)grp * CO + ch) * 2 + 1] = ss;
+                centered_to_raw(sd, m2d, sd * (1.f / 16.f), 16.0, s, ss);
+                a.part[8][((size_t)grp * CO + ch) * 2] = s;
+                a.part[8][((size_t)grp * CO + ch) * 2 + 1] = ss;
+            }
+            const float idv = fmaf(dv, scd, shd);
+            a.yd[eo] = idv;
+            a.y[eo] = fmaxf(fmaf(uv, scu, shu) + idv, 0.f);
+        }
+    }
+}
+
 static bool block_fused_enabled() {
     static const bool on = [] {
         const char* e = getenv("MEDT_BLOCK_FUSED");
@@ -831,6 +1024,50 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
     return launch_status("wopos_block_fwd");
 }
 
+
+// Shape of the stride-2 first-block kernel: 4x4 maps, (C, width) = (128, 128) -> 256 channels on 2x2 maps, 4 images per group
+// (layer4_p.0 of MedT at 128 px).  MEDT_BLOCK_S2=0 disables.
+int& block_s2_mode() {
+    static int mode = [] { const char* e = getenv("MEDT_BLOCK_S2"); return (e && e[0] == '0') ? 0 : 1; }();
+    return mode;
+}
+bool wopos_block_s2_ok(const medt_block_desc& d) {
+    if (!block_fused_enabled() || !block_s2_mode()) return false;
+    if (d.N <= 0 || d.bn_groups <= 0 || d.N != 4 * d.bn_groups || d.G != 8 || d.bn_groups > 4096) return false;
+    return d.H == 4 && d.W == 4 && d.C == 128 && d.width == 128;
+}
+size_t wopos_block_s2_part_doubles(const medt_block_desc& d) {
+    return (size_t)d.bn_groups * 2 * (d.width + 2 * (2 * d.width + d.G + d.width) + 2 * 2 * d.width);
+}
+int wopos_block_s2_fwd(const medt_block_desc& d, const medt_block_s2_params& p, const float* x, float* y,
+                       const medt_block_s2_saved& sv, double* parts, hipStream_t s) {
+    if (abl_skip("block_fwd")) return MEDT_OK;
+    BlkS2Args a;
+    const medt_block_saved& b0 = sv.blk;
+    a.z1 = b0.z1; a.y1 = b0.y1;
+    a.qkv_h = (float*)b0.height.qkv_raw; a.stk_h = (float*)b0.height.stacked; a.lse_h = b0.height.lse; a.y_h = b0.y_h;
+    a.qkv_w = (float*)b0.width.qkv_raw; a.stk_w = (float*)b0.width.stacked; a.lse_w = b0.width.lse; a.y_w = b0.y_w;
+    a.z2 = b0.z2; a.zd = sv.zd; a.yd = sv.yd; a.y = y;
+    const medt_bn_ptrs* bns[9] = {&p.blk.bn1, &p.blk.height.bn_qkv, &p.blk.height.bn_similarity, &p.blk.height.bn_output,
+                                  &p.blk.width.bn_qkv, &p.blk.width.bn_similarity, &p.blk.width.bn_output, &p.blk.bn2, &p.bn_ds};
+    const int CO = 2 * d.width;
+    const int chs[9] = {d.width, 2 * d.width, d.G, d.width, 2 * d.width, d.G, d.width, CO, CO};
+    size_t off = 0, nprm = 0;
+    for (int b = 0; b < 9; ++b) {
+        a.bn[b] = BlkBnP{bns[b]->weight, bns[b]->bias, bns[b]->running_mean, bns[b]->running_var};
+        a.part[b] = parts + off;
+        off += (size_t)d.bn_groups * chs[b] * 2;
+        nprm += (size_t)chs[b] * 4;
+    }
+    a.training = d.training ? 1 : 0;
+    a.eps = d.eps;
+    const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
+    static unsigned char attr[64];
+    if (int rc = lds_opt_in((const void*)wopos_block_s2_fwd_kernel<128, 128, 16>, attr, "wopos_block_s2_fwd")) return rc;
+    hipLaunchKernelGGL((wopos_block_s2_fwd_kernel<128, 128, 16>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.blk.w_down,
+                       p.blk.height.w_qkv, p.blk.width.w_qkv, p.blk.w_up, p.w_ds, a);
+    return launch_status("wopos_block_s2_fwd");
+}
 
 // ------------------------------------------------------------------------------------------------------------------------ //
 // The block's BACKWARD in one workgroup per BatchNorm group (same shapes, same workgroup: lane = position, 16 waves).

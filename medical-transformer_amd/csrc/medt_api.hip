@@ -697,6 +697,59 @@ int medt_wopos_block_fwd(const medt_block_desc* d, const medt_block_params* p, c
     return MEDT_OK;
 }
 
+size_t medt_wopos_block_s2_workspace_bytes(const medt_block_desc* d) {
+    if (!d || !wopos_block_s2_ok(*d)) return 0;
+    return align_up(wopos_block_s2_part_doubles(*d) * sizeof(double), 256) + 256;
+}
+
+int medt_wopos_block_s2_fwd(const medt_block_desc* d, const medt_block_s2_params* p, const float* x, float* y,
+                            const medt_block_s2_saved* sv, void* ws, size_t ws_bytes, void* stream) {
+    if (!d || !p || !x || !y || !sv) { set_error("block s2 fwd: null argument"); return MEDT_EINVAL; }
+    if (!wopos_block_s2_ok(*d)) { set_error("block s2 fwd: shape not supported by the fused kernel"); return MEDT_EUNSUPPORTED; }
+    const medt_block_params& bp = p->blk;
+    const medt_block_saved& b0 = sv->blk;
+    if (!bp.w_down || !bp.w_up || !bp.height.w_qkv || !bp.width.w_qkv || !p->w_ds || !b0.z1 || !b0.y1 || !b0.stats1 || !b0.y_h ||
+        !b0.y_w || !b0.z2 || !b0.stats2 || !b0.height.qkv_raw || !b0.height.stacked || !b0.height.lse || !b0.height.stats ||
+        !b0.width.qkv_raw || !b0.width.stacked || !b0.width.lse || !b0.width.stats || !sv->zd || !sv->yd || !sv->statsd) {
+        set_error("block s2 fwd: null pointer"); return MEDT_EINVAL;
+    }
+    const medt_bn_ptrs* bns[9] = {&bp.bn1, &bp.height.bn_qkv, &bp.height.bn_similarity, &bp.height.bn_output,
+                                  &bp.width.bn_qkv, &bp.width.bn_similarity, &bp.width.bn_output, &bp.bn2, &p->bn_ds};
+    for (int b = 0; b < 9; ++b) {
+        if (!bns[b]->weight || !bns[b]->bias) { set_error("block s2 fwd: null BatchNorm parameter"); return MEDT_EINVAL; }
+        if (!d->training && (!bns[b]->running_mean || !bns[b]->running_var)) {
+            set_error("block s2 fwd: eval mode needs running statistics"); return MEDT_EINVAL;
+        }
+    }
+    Carver c(ws, ws_bytes);
+    double* parts = c.take<double>(wopos_block_s2_part_doubles(*d));
+    if (!ws || !c.ok()) { set_error("block s2 workspace too small: need %zu", c.off); return MEDT_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = wopos_block_s2_fwd(*d, *p, x, y, *sv, parts, s);
+    if (rc) return rc;
+    // saved statistics + ordered running-stat updates of the nine BatchNorms (recorded when a queue is bound, like medt_wopos_block_fwd)
+    const int tr = d->training ? 1 : 0, gs = d->bn_groups, W = d->width, G = d->G, CO = 2 * d->width;
+    const double rows = (double)(d->N / gs) * d->H * d->W, sims = rows * d->H, rows2 = rows / 4;
+    AxialGeom gh;
+    {
+        medt_axial_desc ad{d->N, W, d->H, d->W, G, 0, 0, 1, d->training, gs, d->eps, d->momentum, 0, 0, 0};
+        if ((rc = axial_geom(ad, &gh))) return rc;
+    }
+    LayerStats sh(b0.height.stats, gh), sw(b0.width.stats, gh);
+    const int chs[9] = {W, 2 * W, G, W, 2 * W, G, W, CO, CO};
+    const double cnt[9] = {rows, rows, sims, rows, rows, sims, rows, rows2, rows2};
+    BnStats outs[9] = {BnStats(b0.stats1, gs * W), sh.qkv, sh.sim, sh.out, sw.qkv, sw.sim, sw.out, BnStats(b0.stats2, gs * CO),
+                       BnStats(sv->statsd, gs * CO)};
+    const float* pp = reinterpret_cast<const float*>(parts);
+    Queue* q = queue_for(s);
+    for (int b = 0; b < 9; ++b) {
+        if (q) q->fin.push_back(FinJob{make_fin(pp, 1, chs[b], cnt[b], *bns[b], outs[b]), gs, tr, d->momentum, d->eps});
+        else if ((rc = bn_finalize(pp, 1, gs, chs[b], cnt[b], *bns[b], d->momentum, d->eps, tr, outs[b], s))) return rc;
+        pp += (size_t)gs * chs[b] * 2 * 2;           // doubles
+    }
+    return MEDT_OK;
+}
+
 size_t medt_wopos_block_bwd_workspace_bytes(const medt_block_desc* d) {
     if (!d || !wopos_block_bwd_ok(*d)) return 0;
     return wopos_block_bwd_ws_bytes(*d);

@@ -171,6 +171,11 @@ bool wopos_block_ok(const medt_block_desc& d);
 size_t wopos_block_part_doubles(const medt_block_desc& d);
 int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const float* x, float* y,
                     const medt_block_saved& sv, double* parts, hipStream_t s);
+// the stride-2 first block + downsample path (round 6; layer4_p.0 of MedT-128)
+bool wopos_block_s2_ok(const medt_block_desc& d);
+size_t wopos_block_s2_part_doubles(const medt_block_desc& d);
+int wopos_block_s2_fwd(const medt_block_desc& d, const medt_block_s2_params& p, const float* x, float* y,
+                       const medt_block_s2_saved& sv, double* parts, hipStream_t s);
 // ... and its backward (default; MEDT_BLOCK_BWD=0 disables): launch + recorded / immediate parameter-gradient jobs
 bool wopos_block_bwd_ok(const medt_block_desc& d);
 size_t wopos_block_bwd_ws_bytes(const medt_block_desc& d);

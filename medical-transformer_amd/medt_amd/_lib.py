@@ -73,6 +73,14 @@ class BlockSaved(C.Structure):
                 ("stats2", C.c_void_p)]
 
 
+class BlockS2Params(C.Structure):
+    _fields_ = [("blk", BlockParams), ("w_ds", C.c_void_p), ("bn_ds", BnPtrs)]
+
+
+class BlockS2Saved(C.Structure):
+    _fields_ = [("blk", BlockSaved), ("zd", C.c_void_p), ("yd", C.c_void_p), ("statsd", C.c_void_p)]
+
+
 class BlockGrads(C.Structure):
     _fields_ = [("w_down", C.c_void_p), ("bn1_weight", C.c_void_p), ("bn1_bias", C.c_void_p), ("height", AxialGrads),
                 ("width", AxialGrads), ("w_up", C.c_void_p), ("bn2_weight", C.c_void_p), ("bn2_bias", C.c_void_p)]
@@ -104,6 +112,9 @@ SIGNATURES = {
     "medt_wopos_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "medt_wopos_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams), C.c_void_p, C.c_void_p,
                                        C.POINTER(BlockSaved), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "medt_wopos_block_s2_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
+    "medt_wopos_block_s2_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockS2Params), C.c_void_p, C.c_void_p,
+                                          C.POINTER(BlockS2Saved), C.c_void_p, C.c_size_t, C.c_void_p]),
     "medt_wopos_block_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "medt_wopos_block_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(BlockSaved), C.c_void_p, C.c_void_p, C.POINTER(BlockGrads), C.c_void_p,

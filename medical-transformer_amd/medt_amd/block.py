@@ -35,8 +35,10 @@ def fused_forward(blk, x, bn_groups: int):
     """None when the block / shape is not one the fused kernel is built for; else the precomputed stage outputs
     {"down": (z1, y1, stats1), "h": (qkv_raw, stacked, lse, stats, y_h), "w": (...), "up": (z2, y, stats2)}."""
     from . import ops
-    if not ENABLED or ops.lean() or not x.is_cuda or x.dtype != torch.float32 or blk.downsample is not None:
+    if not ENABLED or ops.lean() or not x.is_cuda or x.dtype != torch.float32:
         return None
+    if blk.downsample is not None:
+        return fused_forward_s2(blk, x, bn_groups)
     h, w = blk.hight_block, blk.width_block
     if h._has_pos or w._has_pos or h._gate_mode or w._gate_mode or h.stride != 1 or w.stride != 1:
         return None
@@ -94,6 +96,74 @@ def fused_forward(blk, x, bn_groups: int):
     if q is not None:                      # the recorded statistics jobs read the partial sums and write the stats blocks
         q.hold(ws, stats1, sv[0][3], sv[1][3], stats2)
     return {"down": (z1, y1, stats1), "h": sv[0], "w": sv[1], "up": (z2, y, stats2)}
+
+
+def fused_forward_s2(blk, x, bn_groups: int):
+    """The stride-2 FIRST block of a layer with its downsample path (reference lib/models/axialnet.py:368-391 + :596-606; layer4_p.0
+    of MedT at 128 px) as one launch (medt_wopos_block_s2_fwd, round 6): the same dictionary as fused_forward plus
+    "ds": (zd, yd, statsd) for the downsample conv block; the width layer's y is the pooled (N, width, H/2, W/2) tensor."""
+    h, w, ds = blk.hight_block, blk.width_block, blk.downsample
+    if h._has_pos or w._has_pos or h._gate_mode or w._gate_mode or h.stride != 1 or w.stride != 2:
+        return None
+    if len(ds) != 2 or not isinstance(ds[0], torch.nn.Conv2d) or not isinstance(ds[1], torch.nn.BatchNorm2d):
+        return None
+    bns = (blk.bn1, h.bn_qkv, h.bn_similarity, h.bn_output, w.bn_qkv, w.bn_similarity, w.bn_output, blk.bn2, ds[1])
+    training = blk.bn1.training
+    if any(b.training != training or b.momentum is None or b.eps != blk.bn1.eps or b.momentum != blk.bn1.momentum
+           or b.running_mean is None for b in bns):
+        return None
+    N, Cc, H, W = x.shape
+    width = blk.conv_down.weight.shape[0]
+    Co = blk.conv_up.weight.shape[0]
+    if Co != 2 * width or H % 2 or W % 2:
+        return None
+    for cv, cin, cout, st in ((blk.conv_down, Cc, width, 1), (blk.conv_up, width, Co, 1), (ds[0], Cc, Co, 2)):
+        if (tuple(cv.kernel_size) != (1, 1) or tuple(cv.stride) != (st, st) or tuple(cv.padding) != (0, 0) or cv.groups != 1
+                or cv.in_channels != cin or cv.out_channels != cout or cv.bias is not None):
+            return None
+    if h.width or not w.width or h.groups != w.groups or h.training != training or w.training != training or blk.training != training:
+        return None
+    if h.qkv_transform.weight.shape[:2] != (2 * width, width) or w.qkv_transform.weight.shape[:2] != (2 * width, width):
+        return None
+    lib = L.lib()
+    desc = L.BlockDesc(N, Cc, width, H, W, h.groups, int(training), bn_groups, blk.bn1.eps, float(blk.bn1.momentum))
+    ws_bytes = lib.medt_wopos_block_s2_workspace_bytes(C.byref(desc))
+    if ws_bytes == 0:
+        return None
+    x = x.contiguous()
+    dev = x.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    G, H2, W2 = h.groups, H // 2, W // 2
+    z1 = torch.empty((N, width, H, W), **f32)
+    y1 = torch.empty_like(z1)
+    stats1 = torch.empty((4 * bn_groups * width,), **f32)
+    sv = []
+    for l in range(2):
+        sv.append((torch.empty((N, 2 * width, H, W), **f32), torch.empty((N, width, H, W), **f32),
+                   torch.empty((N, G, H, W), **f32), torch.empty((4 * bn_groups * (2 * width + G + width),), **f32),
+                   torch.empty((N, width, H, W) if l == 0 else (N, width, H2, W2), **f32)))
+    z2 = torch.empty((N, Co, H2, W2), **f32)
+    y = torch.empty_like(z2)
+    stats2 = torch.empty((4 * bn_groups * Co,), **f32)
+    zd = torch.empty_like(z2)
+    yd = torch.empty_like(z2)
+    statsd = torch.empty((4 * bn_groups * Co,), **f32)
+    ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+    params = L.BlockS2Params(L.BlockParams(L.ptr(blk.conv_down.weight), _bn_ptrs(blk.bn1, training), _axial_params(h, training),
+                                           _axial_params(w, training), L.ptr(blk.conv_up.weight), _bn_ptrs(blk.bn2, training)),
+                             L.ptr(ds[0].weight), _bn_ptrs(ds[1], training))
+    saved = L.BlockS2Saved(L.BlockSaved(z1.data_ptr(), y1.data_ptr(), stats1.data_ptr(),
+                                        L.AxialSaved(sv[0][0].data_ptr(), sv[0][1].data_ptr(), sv[0][2].data_ptr(), sv[0][3].data_ptr()),
+                                        sv[0][4].data_ptr(),
+                                        L.AxialSaved(sv[1][0].data_ptr(), sv[1][1].data_ptr(), sv[1][2].data_ptr(), sv[1][3].data_ptr()),
+                                        sv[1][4].data_ptr(), z2.data_ptr(), stats2.data_ptr()),
+                           zd.data_ptr(), yd.data_ptr(), statsd.data_ptr())
+    q = DEFER.recording()
+    L.check(lib.medt_wopos_block_s2_fwd(C.byref(desc), C.byref(params), x.data_ptr(), y.data_ptr(), C.byref(saved),
+                                        ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream), "medt_wopos_block_s2_fwd")
+    if q is not None:
+        q.hold(ws, stats1, sv[0][3], sv[1][3], stats2, statsd)
+    return {"down": (z1, y1, stats1), "h": sv[0], "w": sv[1], "up": (z2, y, stats2), "ds": (zd, yd, statsd)}
 
 
 # --------------------------------------------------------------------------- #
@@ -183,7 +253,7 @@ class WoposBlockFn(torch.autograd.Function):
 
 def block_forward(blk, x, bn_groups: int, sink):
     """The block as ONE autograd node (one-launch forward and backward), or None when that path is not taken."""
-    if not BWD_ENABLED or not torch.is_grad_enabled():
+    if not BWD_ENABLED or not torch.is_grad_enabled() or blk.downsample is not None:
         return None
     # (the one-launch backward exists for fewer shapes than the forward: ask before committing this block to the one-node path)
     N, Cc, H, W = x.shape

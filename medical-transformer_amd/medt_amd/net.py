@@ -67,15 +67,17 @@ def axial_block_forward(blk, x, bn_groups: int = 1):
     pre = BLOCK.fused_forward(blk, x, bn_groups)
     if pre is None:
         pre = {"down": None, "h": None, "w": None, "up": None}
+    pre.setdefault("ds", None)
     out = ops.conv_block(x, blk.conv_down, blk.bn1, relu=True, training=blk.bn1.training, bn_groups=bn_groups,
                          x_sink=sink, x_role="final", pre=pre["down"])
     out = blk.hight_block.run(out, bn_groups, False, pre["h"])
     out = blk.width_block.run(out, bn_groups, True, pre["w"])    # + the block's ReLU (:333)
     if blk.downsample is not None:
         identity = ops.conv_block(x, blk.downsample[0], blk.downsample[1], relu=False,
-                                  training=blk.downsample[1].training, bn_groups=bn_groups, x_sink=sink, x_role="deposit")
+                                  training=blk.downsample[1].training, bn_groups=bn_groups, x_sink=sink, x_role="deposit",
+                                  pre=pre["ds"])
         return ops.conv_block(out, blk.conv_up, blk.bn2, res=identity, relu=True, training=blk.bn2.training,
-                              bn_groups=bn_groups)
+                              bn_groups=bn_groups, pre=pre["up"])
     return ops.conv_block(out, blk.conv_up, blk.bn2, res=x, relu=True, training=blk.bn2.training,
                           bn_groups=bn_groups, res_sink=sink, pre=pre["up"])
 

@@ -286,14 +286,18 @@ def layer_fixture(kind, C, L, width, stride, N, seed):
     return fx
 
 
-def block_fixture(inplanes, planes, S, groups_n, npg, seed):
+def block_fixture(inplanes, planes, S, groups_n, npg, seed, stride=1):
     """One AxialBlock_wopos of the reference (lib/models/axialnet.py:346-391) applied to `groups_n` patch groups of `npg`
     images ONE AFTER THE OTHER -- what medt_net's patch loop (:661-700) does with every block of the local branch: each
     group is normalised with its own batch statistics, the running statistics receive the groups' updates in order, the
     parameter gradients are the sums over the groups.  Everything stored in full (float64)."""
     ax = ref_loader.load()
     torch.manual_seed(seed)
-    blk = ax.AxialBlock_wopos(inplanes, planes, groups=8, base_width=64, kernel_size=S)
+    downsample = None
+    if stride != 1 or inplanes != planes * 2:
+        # what medt_net._make_layer builds for the first block of a layer (lib/models/axialnet.py:596-606)
+        downsample = torch.nn.Sequential(ax.conv1x1(inplanes, planes * 2, stride), torch.nn.BatchNorm2d(planes * 2))
+    blk = ax.AxialBlock_wopos(inplanes, planes, stride=stride, downsample=downsample, groups=8, base_width=64, kernel_size=S)
     sd = O.randomize_state(blk.state_dict(), seed)
     blk.load_state_dict(sd)
     blk = blk.double()
@@ -302,9 +306,9 @@ def block_fixture(inplanes, planes, S, groups_n, npg, seed):
     g = torch.Generator().manual_seed(seed + 1)
     N = groups_n * npg
     x = torch.randn((N, inplanes, S, S), generator=g, dtype=torch.float64).relu_().requires_grad_(True)
-    w = torch.randn((N, inplanes, S, S), generator=g, dtype=torch.float64)
+    w = torch.randn((N, planes * 2, S // stride, S // stride), generator=g, dtype=torch.float64)
     import json
-    fx = {"meta": np.array([inplanes, planes, S, groups_n, npg, seed]), "x": x.detach().numpy(), "dout": w.numpy(),
+    fx = {"meta": np.array([inplanes, planes, S, groups_n, npg, seed] + ([stride] if stride != 1 else [])), "x": x.detach().numpy(), "dout": w.numpy(),
           "state_layout": np.array(json.dumps([[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]))}
     blk.eval()
     fx["out_eval"] = torch.cat([blk(x[i * npg:(i + 1) * npg]) for i in range(groups_n)]).detach().numpy()
@@ -373,6 +377,12 @@ def main():
     fn = "block_wopos_C128_P64_S4_G2.npz"
     if fn.startswith(only):
         np.savez_compressed(os.path.join(HERE, fn), **block_fixture(128, 64, 4, 2, 4, 21))
+        print("wrote", fn)
+    # layer4_p.0 of MedT at BASELINE's batch size: the stride-2 first block + its downsample path (128 -> 128 -> 256 channels, 4x4 ->
+    # 2x2 maps): the shape of the one-launch stride-2 block forward (round 6), two patch groups
+    fn = "block_wopos_s2_C128_P128_S4_G2.npz"
+    if fn.startswith(only):
+        np.savez_compressed(os.path.join(HERE, fn), **block_fixture(128, 128, 4, 2, 4, 22, stride=2))
         print("wrote", fn)
     model_cases = [
         ("gatedaxialunet", 128, 2, 101, "train"),

@@ -119,6 +119,79 @@ def test_block_vs_reference_fixture(fused, device):
             assert H.rel_err(blk.state_dict()[k[4:]].double(), fx[k]) < 1e-3, k
 
 
+# ---- round 6: the stride-2 FIRST block of a layer with its downsample path as one forward launch (medt_wopos_block_s2_fwd; layer4_p.0
+# of MedT at 128 px: 128 -> 128 -> 256 channels, 4x4 -> 2x2 maps).  The per-stage backward runs behind it (adopt mode).
+def _s2_block(device):
+    import json
+    import lib as droplib
+    from oracle import medt_oracle as O
+    fx = H.load_golden("block_wopos_s2_C128_P128_S4_G2.npz")
+    inplanes, planes, S, groups_n, npg, seed, stride = [int(v) for v in fx["meta"]]
+    ds = torch.nn.Sequential(droplib.models.axialnet.conv1x1(inplanes, planes * 2, stride), torch.nn.BatchNorm2d(planes * 2))
+    blk = droplib.models.axialnet.AxialBlock_wopos(inplanes, planes, stride=stride, downsample=ds, groups=8, base_width=64, kernel_size=S)
+    layout = json.loads(str(fx["state_layout"]))
+    assert [k for k, _, _ in layout] == list(blk.state_dict().keys())
+    blk.load_state_dict(O.randomize_state({k: v.clone() for k, v in blk.state_dict().items()}, seed))
+    return fx, blk.to(device), groups_n
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "per-stage"])
+def test_stride2_block_vs_reference_fixture(fused, device):
+    """tests/golden/block_wopos_s2_*.npz: the REFERENCE's AxialBlock_wopos(stride=2, downsample=conv1x1 s2 + BatchNorm) applied to two
+    patch groups one after the other (float64): eval and train outputs, dx, all 23 parameter gradients, running statistics."""
+    import ctypes
+    import numpy as np
+    from medt_amd import _lib, block, net
+    fx, blk, groups_n = _s2_block(device)
+    x = torch.from_numpy(fx["x"]).float().to(device)
+    d = _lib.BlockDesc(x.shape[0], 128, 128, 4, 4, 8, 1, groups_n, 1e-5, 0.1)
+    if fused and (not block.ENABLED or _lib.lib().medt_wopos_block_s2_workspace_bytes(ctypes.byref(d)) == 0):
+        pytest.skip("stride-2 block forward disabled (MEDT_BLOCK_S2=0 / MEDT_BLOCK_FUSED=0)")
+    old = block.ENABLED
+    block.ENABLED = fused and old
+    try:
+        blk.eval()
+        with torch.no_grad():
+            assert H.rel_err(net.axial_block_forward(blk, x, groups_n), fx["out_eval"]) < 1e-3
+        blk.train()
+        xg = x.clone().requires_grad_(True)
+        y = net.axial_block_forward(blk, xg, groups_n)
+        e = H.rel_err(y, fx["out_train"])
+        assert e < 1e-3, e
+        (y * torch.from_numpy(fx["dout"]).float().to(device)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        block.ENABLED = old
+    assert H.rel_err(xg.grad, fx["dx"]) < 1e-3
+    gscale = max(np.abs(fx[k]).max() for k in fx if k.startswith("grad/"))
+    params = dict(blk.named_parameters())
+    n = 0
+    for k in fx:
+        if k.startswith("grad/"):
+            want = torch.from_numpy(fx[k])
+            scale = max(want.abs().max().item(), 1e-3 * gscale)
+            err = (params[k[5:]].grad.double().cpu() - want).abs().max().item() / scale
+            assert err < 1e-3, (k, err)
+            n += 1
+        if k.startswith("buf/"):
+            assert H.rel_err(blk.state_dict()[k[4:]].double(), fx[k]) < 1e-3, k
+    assert n == 23
+
+
+def test_stride2_block_is_one_forward_launch(device):
+    from medt_amd import block, net
+    from medt_amd.defer import StepQueue
+    fx, blk, groups_n = _s2_block(device)
+    if not block.ENABLED or block.fused_forward(blk.train(), torch.from_numpy(fx["x"]).float().to(device), groups_n) is None:
+        pytest.skip("stride-2 block forward disabled")
+    q = StepQueue()
+    with q.active():
+        with torch.no_grad():
+            net.axial_block_forward(blk, torch.from_numpy(fx["x"]).float().to(device), groups_n)
+        assert q.pending() == 9                 # nine BatchNorm bookkeeping jobs from ONE call; the adopting stages record nothing
+    torch.cuda.synchronize()
+
+
 def test_fused_block_is_taken_and_counts_one_launch(device):
     """The block really runs as one forward launch: eight BatchNorm bookkeeping jobs are recorded by a single call, and the
     adopt-mode stages launch nothing (their workspaces are never requested)."""

@@ -69,16 +69,17 @@ def test_block_oracle_matches_reference_fixture(fn):
     """O.axial_block with grouped BatchNorm statistics == the reference's AxialBlock_wopos applied to the patch groups one after
     the other (medt_net's patch loop, axialnet.py:661-700): outputs, every gradient, the running statistics in patch order."""
     fx = H.load_golden(fn)
-    inplanes, planes, S, groups_n, npg, seed = [int(v) for v in fx["meta"]]
+    inplanes, planes, S, groups_n, npg, seed = [int(v) for v in fx["meta"][:6]]
+    stride = int(fx["meta"][6]) if len(fx["meta"]) > 6 else 1      # (round 6: the stride-2 first block with its downsample path)
     layout = json.loads(str(fx["state_layout"]))
     blank = {k: torch.zeros(shape, dtype=getattr(torch, dt)) for k, shape, dt in layout}
     st = {("m." + k): v for k, v in O.randomize_state(blank, seed).items()}
     x = torch.from_numpy(fx["x"]).double()
-    out = O.axial_block(x, O.clone_state(st, torch.float64), "m", 1, False, groups_n)
+    out = O.axial_block(x, O.clone_state(st, torch.float64), "m", stride, False, groups_n)
     assert H.rel_err(out, fx["out_eval"]) < 1e-10
     st_t = O.clone_state(st, torch.float64, requires_grad=True)
     xg = x.clone().requires_grad_(True)
-    out = O.axial_block(xg, st_t, "m", 1, True, groups_n)
+    out = O.axial_block(xg, st_t, "m", stride, True, groups_n)
     assert H.rel_err(out, fx["out_train"]) < 1e-10
     (out * torch.from_numpy(fx["dout"])).sum().backward()
     assert H.rel_err(xg.grad, fx["dx"]) < 1e-9
