@@ -772,33 +772,194 @@ struct BlkS2Args {
     float eps;
 };
 constexpr int S2_PST = 20;           // row stride of the pooled tiles: the four k-rows of a B fragment on disjoint 16-bank windows
+constexpr int S2_LDT = 68;           // row stride of the 64-position tiles: 68 = 4 (mod 64) -- the four k-rows of a B fragment (channels
+                                     // 4 kk + e, 16 positions each) and the four channel rows of an accumulator write fall on disjoint 16-bank windows
+
+// The 1x1 contractions of this kernel on the MATRIX CORES.  The kernel's first version ran them like wopos_block_fwd_kernel does
+// (wave_conv1x1: packed VALU FMAs, weight rows through the scalar unit) and took 79 us -- as long as the five launches it replaced:
+// 5.2 MMAC per workgroup at the ~35 MAC / cycle that scheme reaches on one CU (s_load latency, one LDS read per FMA pair).
+// out[16 rows][64 positions] = w[row0 .. +15][CIN] x T[CIN][64]: four 16 x 16 accumulators (position tiles) per 16-row block,
+// k-step = 4 input channels; A fragments = eight / four 16-byte loads per lane (lane (m, kk): columns 16 t + 4 kk .. + 3 of row
+// row0 + m), B fragments = one conflict-free ds_read_b32 per MFMA.
+// acc[pt][r] = output channel row0 + 4 (lane >> 4) + r at position 16 pt + (lane & 15).
+template <int CIN>
+__device__ __forceinline__ void blk_mfma_proj(const float* __restrict__ w, int row0, const float* T, medt_f4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kk = lane >> 4;
+    float4 wf[CIN / 16];
+#pragma unroll
+    for (int t = 0; t < CIN / 16; ++t) wf[t] = *reinterpret_cast<const float4*>(w + (unsigned)(row0 + m) * CIN + 16 * t + 4 * kk);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc[pt] = medt_f4{0.f, 0.f, 0.f, 0.f};
+    const float* Tb = T + 4 * kk * S2_LDT + m;
+#pragma unroll
+    for (int t = 0; t < CIN / 16; ++t) {
+        const float we[4] = {wf[t].x, wf[t].y, wf[t].z, wf[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+                acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[e], Tb[(16 * t + e) * S2_LDT + 16 * pt], acc[pt], 0, 0, 0);
+    }
+}
+// BatchNorm parameters of the four channels a lane row holds (ch0 = row0 + 4 (lane >> 4)), requested before the contraction
+struct BlkAccPrm { float g[4], b[4], rm[4], rv[4]; };
+__device__ __forceinline__ void blk_acc_prm(const BlkBnP& bn, int ch0, int training, BlkAccPrm& q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        q.g[r] = bn.weight[ch0 + r];
+        q.b[r] = bn.bias[ch0 + r];
+        q.rm[r] = training ? 0.f : bn.rmean[ch0 + r];
+        q.rv[r] = training ? 1.f : bn.rvar[ch0 + r];
+    }
+}
+// BatchNorm of those channels over the group's 64 positions: a channel's values are acc[0..3][r] in the 16 lanes of this lane's DPP
+// row -- two row sums per channel (sum, centred sum of squares), no LDS, no barrier.
+__device__ __forceinline__ void blk_acc_bn(const medt_f4 (&acc)[4], const BlkAccPrm& q, double* part, int ch0, int training, float eps,
+                                           float (&sc)[4], float (&sh)[4]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.f, m2 = 0.f;
+        if (training) {
+            s = blk_row_sum((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]));
+            const float mean = s * (1.f / 64.f);
+            float d2 = 0.f;
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) { const float d = acc[pt][r] - mean; d2 = fmaf(d, d, d2); }
+            m2 = blk_row_sum(d2);
+            if ((lane & 15) == 0) {
+                double sd, ssd;
+                centered_to_raw(s, m2, mean, 64.0, sd, ssd);
+                part[(size_t)(ch0 + r) * 2] = sd;
+                part[(size_t)(ch0 + r) * 2 + 1] = ssd;
+            }
+        }
+        const float prm[4] = {q.g[r], q.b[r], q.rm[r], q.rv[r]};
+        blk_scale_shift<true>(s, m2, 64.f, prm, eps, training, sc[r], sh[r]);
+    }
+}
+
+// One AxialAttention_wopos layer on the padded tile A (CW x 64 positions, row stride S2_LDT) -> A in place through Q (2CW rows):
+// wave_attention with the projection on the matrix cores (one 16-row block of the 2CW q | k | v rows per wave; 2CW / 16 waves work,
+// the others wait at the barrier) and bn_qkv in the accumulator layout.  The L x L part is wave_attention's, row stride aside.
+template <int CW, int GP, int AXIS, bool RELU, bool WY>
+__device__ __forceinline__ void wave_attention_m(const float* __restrict__ w_qkv, float* A, float* Q, const BlkBnP& bnq,
+                                                 const float* prm_s, const float* prm_o, double* part_q, double* part_s,
+                                                 double* part_o, float* qkv_raw, float* stacked, float* lse, float* y, int n0,
+                                                 int training, float eps, int wv) {
+    constexpr int G = CW / GP, HQ = GP / 2, NCH = 2 * GP, L = 4, HW = 16, HV = GP / 2, LDT = S2_LDT;
+    static_assert(G * 2 == 16, "two waves per head");
+    const int lane = threadIdx.x & 63, ni = lane >> 4, p = lane & 15;
+    // 1. qkv_transform rows 16 wv .. + 15, bn_qkv                                            (axialnet.py:228)
+    if (wv < 2 * CW / 16) {
+        const int ch0 = 16 * wv + 4 * (lane >> 4);
+        BlkAccPrm q;
+        blk_acc_prm(bnq, ch0, training, q);
+        medt_f4 acc[4];
+        blk_mfma_proj<CW>(w_qkv, 16 * wv, A, acc);
+        float sc[4], sh[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qkv_raw[((unsigned)(n0 + pt) * 2 * CW + ch0 + r) * HW + p] = acc[pt][r];
+        blk_acc_bn(acc, q, part_q, ch0, training, eps, sc, sh);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Q[(ch0 + r) * LDT + 16 * pt + p] = fmaf(acc[pt][r], sc[r], sh[r]);
+    }
+    MEDT_LDS_BARRIER();                                   // q | k | v of every head in LDS; A is free
+    // 2. logits of this lane's row, bn_similarity, softmax, P.V for half of the head's value channels   (:232-241)
+    const int g = wv >> 1, hf = wv & 1;
+    const float* Qh = Q + g * NCH * LDT;
+    const int i = AXIS == 1 ? (p & 3) : (p >> 2), sj = AXIS == 1 ? 1 : 4, base = lane - i * sj;
+    float qv[HQ], z[L];
+#pragma unroll
+    for (int c = 0; c < HQ; ++c) qv[c] = Qh[c * LDT + lane];
+    float v0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        float qk = 0.f;
+#pragma unroll
+        for (int c = 0; c < HQ; ++c) qk = fmaf(qv[c], Qh[(HQ + c) * LDT + base + j * sj], qk);
+        z[j] = qk;
+        v0 += qk;
+    }
+    float a_qk;
+    {
+        float s1 = 0.f, m2 = 0.f;
+        if (training) {
+            s1 = blk_wave_sum(v0);
+            const float mz = s1 * (1.f / (64.f * L));
+            float v1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < L; ++j) v1 = fmaf(z[j] - mz, z[j] - mz, v1);
+            m2 = blk_wave_sum(v1);
+        }
+        float scale, shift;
+        blk_scale_shift<true>(s1, m2, 64.f * L, prm_s + g * 4, eps, training, scale, shift);
+        if (training && hf == 0 && lane == 0) {
+            double sd, ssd;
+            centered_to_raw(s1, m2, s1 * (1.f / (64.f * L)), 64.0 * L, sd, ssd);
+            part_s[(size_t)g * 2] = sd;
+            part_s[(size_t)g * 2 + 1] = ssd;
+        }
+        a_qk = scale * MEDT_LOG2E;                      // the shift is constant along a softmax row
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < L; ++j) { z[j] *= a_qk; m = fmaxf(m, z[j]); }
+    float l = 0.f, acc[HV];
+#pragma unroll
+    for (int c = 0; c < HV; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const float pj = __builtin_amdgcn_exp2f(z[j] - m);
+        l += pj;
+#pragma unroll
+        for (int c = 0; c < HV; ++c) acc[c] = fmaf(pj, Qh[(GP + hf * HV + c) * LDT + base + j * sj], acc[c]);
+    }
+    const float inv = __builtin_amdgcn_rcpf(l);
+    float o[HV], sc[HV], sh[HV];
+#pragma unroll
+    for (int c = 0; c < HV; ++c) {
+        o[c] = acc[c] * inv;
+        stacked[((unsigned)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = o[c];
+    }
+    if (hf == 0) lse[((unsigned)(n0 + ni) * G + g) * HW + p] = m + __log2f(l);
+    // 3. bn_output (+ ReLU)                                                                     (:242)
+    wave_bn<HV, true>(o, prm_o, part_o, g * GP + hf * HV, training, eps, sc, sh);
+#pragma unroll
+    for (int c = 0; c < HV; ++c) {
+        float v = fmaf(o[c], sc[c], sh[c]);
+        if (RELU) v = fmaxf(v, 0.f);
+        A[(g * GP + hf * HV + c) * LDT + lane] = v;
+        if (WY) y[((unsigned)(n0 + ni) * CW + g * GP + hf * HV + c) * HW + p] = v;
+    }
+    MEDT_LDS_BARRIER();                                   // the layer's output tile in A; Q is free
+}
 
 template <int CI, int CW, int GP>
 __global__ __launch_bounds__(1024) void wopos_block_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
                                                                   const float* __restrict__ w_qh, const float* __restrict__ w_qw,
                                                                   const float* __restrict__ w_up, const float* __restrict__ w_ds,
                                                                   BlkS2Args a) {
-    constexpr bool PK = true;
-    constexpr int HW = 16, G = CW / GP, CA = CW / 16, CO = 2 * CW;
-    static_assert(CO == 256 && CI % 16 == 0 && CW % 16 == 0, "a wave = 16 output channels of the 2x2 stage");
-    constexpr int CHS[9] = {CW, 2 * CW, G, CW, 2 * CW, G, CW, CO, CO};
+    constexpr int HW = 16, G = CW / GP, CO = 2 * CW, LDT = S2_LDT;
+    static_assert(CO == 256 && CI % 16 == 0 && CW % 16 == 0 && CW / 16 <= 16 && 2 * CW / 16 <= 16, "16-row blocks over 16 waves");
+    // the BatchNorms whose parameters sit in LDS (read per channel by wave-uniform index: wave_bn): the two bn_similarity / bn_output
+    constexpr int PCH[4] = {G, CW, G, CW};
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;                                    // [CI][64]   block input (conv_down, and the stride-2 samples of the downsample path)
-    float* A = X + CI * 64;                             // [CW][64]   the running activation tile
-    float* Q = A + CW * 64;                             // [2CW][64]  normalised q | k | v; behind the width layer: the pooled tiles
-    float* prm = Q + 2 * CW * 64;                       // BatchNorm parameters of the nine BatchNorms, [CH][4] each
+    float* X = smem;                                    // [CI][LDT]   block input
+    float* A = X + CI * LDT;                            // [CW][LDT]   the running activation tile
+    float* Q = A + CW * LDT;                            // [2CW][LDT]  normalised q | k | v; behind the width layer: the pooled tiles
+    float* prm = Q + 2 * CW * LDT;                      // [G | CW | G | CW][4]
     float* P = Q;                                       // [CW][S2_PST]  relu(avgpool(width layer output)): conv_up's B operand
     float* Xs = Q + CW * S2_PST;                        // [CI][S2_PST]  x at the even positions: the downsample's B operand
     const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, n0 = grp * 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ni = lane >> 4, p = lane & 15;
-    int poff[9];
-    {
-        int o = 0;
-#pragma unroll
-        for (int b = 0; b < 9; ++b) { poff[b] = o; o += CHS[b] * 4; }
-    }
-    // ---- everything global the block needs before its first result, in one batch: the input tile and the BatchNorm parameters
+    const int p = lane & 15;
+    const int poff[4] = {0, G * 4, G * 4 + CW * 4, 2 * G * 4 + CW * 4};
+    // ---- the input tile and the LDS-resident BatchNorm parameters, one batch of loads
     {
         constexpr int NX4 = CI * 64 / 4 / 1024;          // float4 per thread
         float4 xv[NX4];
@@ -807,74 +968,81 @@ __global__ __launch_bounds__(1024) void wopos_block_s2_fwd_kernel(const float* _
             const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4);
             xv[k] = *reinterpret_cast<const float4*>(x + ((unsigned)(n0 + img) * CI) * HW + (unsigned)rem * 4);
         }
-        float pv[2][4];
-        int pdst[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                    // 1424 channels over 1024 threads: two rounds
-            const int t = tid + h * 1024;
-            pv[h][0] = 0.f; pv[h][1] = 0.f; pv[h][2] = 0.f; pv[h][3] = 1.f;
-            pdst[h] = -1;
+        float pv[4] = {0.f, 0.f, 0.f, 1.f};
+        int pdst = -1;
+        {
+            constexpr int BNI[4] = {2, 3, 5, 6};
             int o = 0;
 #pragma unroll
-            for (int b = 0; b < 9; ++b) {
-                if (t >= o && t < o + CHS[b]) {
-                    const int ch = t - o;
-                    pv[h][0] = a.bn[b].weight[ch];
-                    pv[h][1] = a.bn[b].bias[ch];
-                    if (!a.training) { pv[h][2] = a.bn[b].rmean[ch]; pv[h][3] = a.bn[b].rvar[ch]; }
-                    pdst[h] = poff[b] + ch * 4;
+            for (int b = 0; b < 4; ++b) {
+                if (tid >= o && tid < o + PCH[b]) {
+                    const int ch = tid - o;
+                    pv[0] = a.bn[BNI[b]].weight[ch];
+                    pv[1] = a.bn[BNI[b]].bias[ch];
+                    if (!a.training) { pv[2] = a.bn[BNI[b]].rmean[ch]; pv[3] = a.bn[BNI[b]].rvar[ch]; }
+                    pdst = poff[b] + ch * 4;
                 }
-                o += CHS[b];
+                o += PCH[b];
             }
         }
         MEDT_SCHED_FENCE();
 #pragma unroll
         for (int k = 0; k < NX4; ++k) {
             const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4), c = rem >> 2, p4 = rem & 3;
-            *reinterpret_cast<float4*>(X + c * 64 + img * 16 + p4 * 4) = xv[k];
+            *reinterpret_cast<float4*>(X + c * LDT + img * 16 + p4 * 4) = xv[k];
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (pdst[h] >= 0) { prm[pdst[h]] = pv[h][0]; prm[pdst[h] + 1] = pv[h][1]; prm[pdst[h] + 2] = pv[h][2]; prm[pdst[h] + 3] = pv[h][3]; }
+        if (pdst >= 0) { prm[pdst] = pv[0]; prm[pdst + 1] = pv[1]; prm[pdst + 2] = pv[2]; prm[pdst + 3] = pv[3]; }
     }
     MEDT_LDS_BARRIER();
-    // ---- conv_down + bn1 + ReLU                                                              (axialnet.py:373-375)
-    {
-        float acc[CA], sc[CA], sh[CA];
-        wave_conv1x1<CA, CI, PK>(w_down, wv * CA, X, acc);
+    // ---- conv_down + bn1 + ReLU: 16-row blocks on the first CW / 16 waves                       (axialnet.py:373-375)
+    if (wv < CW / 16) {
+        const int ch0 = 16 * wv + 4 * (lane >> 4);
+        BlkAccPrm q;
+        blk_acc_prm(a.bn[0], ch0, a.training, q);
+        medt_f4 acc[4];
+        blk_mfma_proj<CI>(w_down, 16 * wv, X, acc);
+        float sc[4], sh[4];
 #pragma unroll
-        for (int k = 0; k < CA; ++k) a.z1[((unsigned)(n0 + ni) * CW + wv * CA + k) * HW + p] = acc[k];
-        wave_bn<CA, PK>(acc, prm + poff[0], a.part[0] + (size_t)grp * CW * 2, wv * CA, a.training, a.eps, sc, sh);
+        for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-        for (int k = 0; k < CA; ++k) {
-            const float v = fmaxf(fmaf(acc[k], sc[k], sh[k]), 0.f);
-            A[(wv * CA + k) * 64 + lane] = v;
-            a.y1[((unsigned)(n0 + ni) * CW + wv * CA + k) * HW + p] = v;
-        }
+            for (int r = 0; r < 4; ++r) a.z1[((unsigned)(n0 + pt) * CW + ch0 + r) * HW + p] = acc[pt][r];
+        blk_acc_bn(acc, q, a.part[0] + (size_t)grp * CW * 2, ch0, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(fmaf(acc[pt][r], sc[r], sh[r]), 0.f);
+                A[(ch0 + r) * LDT + 16 * pt + p] = v;
+                a.y1[((unsigned)(n0 + pt) * CW + ch0 + r) * HW + p] = v;
+            }
     }
     MEDT_LDS_BARRIER();
     // ---- height layer, width layer (its ReLU comes behind the pooling)                          (:377-379)
-    wave_attention<CW, GP, 0, false, PK>(w_qh, A, Q, prm + poff[1], prm + poff[2], prm + poff[3],
-                                         a.part[1] + (size_t)grp * 2 * CW * 2, a.part[2] + (size_t)grp * G * 2,
-                                         a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h, a.y_h, n0, a.training, a.eps, wv, 3);
-    wave_attention<CW, GP, 1, false, PK, false>(w_qw, A, Q, prm + poff[4], prm + poff[5], prm + poff[6],
-                                                a.part[4] + (size_t)grp * 2 * CW * 2, a.part[5] + (size_t)grp * G * 2,
-                                                a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w, nullptr, n0, a.training, a.eps, wv, 6);
+    wave_attention_m<CW, GP, 0, false, true>(w_qh, A, Q, a.bn[1], prm + poff[0], prm + poff[1], a.part[1] + (size_t)grp * 2 * CW * 2,
+                                             a.part[2] + (size_t)grp * G * 2, a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h,
+                                             a.y_h, n0, a.training, a.eps, wv);
+    wave_attention_m<CW, GP, 1, false, false>(w_qw, A, Q, a.bn[4], prm + poff[2], prm + poff[3], a.part[4] + (size_t)grp * 2 * CW * 2,
+                                              a.part[5] + (size_t)grp * G * 2, a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w,
+                                              nullptr, n0, a.training, a.eps, wv);
     // the weight rows of this wave's 16 output channels of conv_up and of the downsample convolution: A fragments of the matrix
-    // cores (lane (m, kk) holds columns 16 t + 4 kk .. + 3 of row 16 wv + m in register t), requested here -- behind the layers, whose projections need the registers -- and in flight under the pooling phase
+    // cores (lane (m, kk) holds columns 16 t + 4 kk .. + 3 of row 16 wv + m in register t), and the two BatchNorms' parameters of the
+    // lane row's four channels -- requested here, in flight under the pooling phase
     const int m16 = lane & 15, kk = lane >> 4;
     float4 wu[CW / 16], wd[CI / 16];
 #pragma unroll
     for (int t = 0; t < CW / 16; ++t) wu[t] = *reinterpret_cast<const float4*>(w_up + (unsigned)(16 * wv + m16) * CW + 16 * t + 4 * kk);
 #pragma unroll
     for (int t = 0; t < CI / 16; ++t) wd[t] = *reinterpret_cast<const float4*>(w_ds + (unsigned)(16 * wv + m16) * CI + 16 * t + 4 * kk);
+    BlkAccPrm q2, qd;
+    blk_acc_prm(a.bn[7], 16 * wv + 4 * kk, a.training, q2);
+    blk_acc_prm(a.bn[8], 16 * wv + 4 * kk, a.training, qd);
     MEDT_SCHED_FENCE();
     // ---- AvgPool2d(2, 2) + ReLU -> P (and y_w, the width layer's saved output); x at the even positions -> Xs     (:251-252, :381, :596)
     {
 #pragma unroll
         for (int h = 0; h < CW * 16 / 1024; ++h) {
             const int e = tid + h * 1024, c = e >> 4, q = e & 15, img = q >> 2, ph = (q >> 1) & 1, pw = q & 1;
-            const float* s4 = A + c * 64 + img * 16 + ph * 8 + pw * 2;
+            const float* s4 = A + c * LDT + img * 16 + ph * 8 + pw * 2;
             const float v = fmaxf(0.25f * ((s4[0] + s4[1]) + (s4[4] + s4[5])), 0.f);
             P[c * S2_PST + q] = v;
             a.y_w[((unsigned)(n0 + img) * CW + c) * 4 + (q & 3)] = v;
@@ -882,7 +1050,7 @@ __global__ __launch_bounds__(1024) void wopos_block_s2_fwd_kernel(const float* _
 #pragma unroll
         for (int h = 0; h < CI * 16 / 1024; ++h) {
             const int e = tid + h * 1024, c = e >> 4, q = e & 15, img = q >> 2, ph = (q >> 1) & 1, pw = q & 1;
-            Xs[c * S2_PST + q] = X[c * 64 + img * 16 + ph * 8 + pw * 2];
+            Xs[c * S2_PST + q] = X[c * LDT + img * 16 + ph * 8 + pw * 2];
         }
     }
     MEDT_LDS_BARRIER();
@@ -925,8 +1093,9 @@ __global__ __launch_bounds__(1024) void wopos_block_s2_fwd_kernel(const float* _
                 m2d = blk_row_sum(dd * dd);
             }
             float scu, shu, scd, shd;
-            blk_scale_shift<true>(su, m2u, 16.f, prm + poff[7] + ch * 4, a.eps, a.training, scu, shu);
-            blk_scale_shift<true>(sd, m2d, 16.f, prm + poff[8] + ch * 4, a.eps, a.training, scd, shd);
+            const float pu[4] = {q2.g[r], q2.b[r], q2.rm[r], q2.rv[r]}, pd[4] = {qd.g[r], qd.b[r], qd.rm[r], qd.rv[r]};
+            blk_scale_shift<true>(su, m2u, 16.f, pu, a.eps, a.training, scu, shu);
+            blk_scale_shift<true>(sd, m2d, 16.f, pd, a.eps, a.training, scd, shd);
             if (a.training && n == 0) {
                 double s, ss;
                 centered_to_raw(su, m2u, su * (1.f / 16.f), 16.0, s, ss);
@@ -1061,7 +1230,8 @@ int wopos_block_s2_fwd(const medt_block_desc& d, const medt_block_s2_params& p, 
     }
     a.training = d.training ? 1 : 0;
     a.eps = d.eps;
-    const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
+    (void)nprm;
+    const size_t lds = ((size_t)(d.C + 3 * d.width) * S2_LDT + (size_t)(2 * d.G + 2 * d.width) * 4) * sizeof(float);
     static unsigned char attr[64];
     if (int rc = lds_opt_in((const void*)wopos_block_s2_fwd_kernel<128, 128, 16>, attr, "wopos_block_s2_fwd")) return rc;
     hipLaunchKernelGGL((wopos_block_s2_fwd_kernel<128, 128, 16>), dim3(d.bn_groups), dim3(1024), lds, s, x, p.blk.w_down,
