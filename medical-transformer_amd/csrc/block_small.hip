@@ -1112,6 +1112,112 @@ __global__ __launch_bounds__(1024) void wopos_block_s2_fwd_kernel(const float* _
     }
 }
 
+// The plain block (wopos_block_fwd_kernel's job: layer3_p.1-3, 128 -> 64 -> 128 channels on 4x4 maps) with the four 1x1 contractions
+// on the matrix cores (round 6; MEDT_BLOCK_MFMA=0 = the VALU kernel): phase stamps of the VALU kernel put conv_down + the two
+// projections + conv_up with their BatchNorms at 21 of its 26.6 us (profiles/r04_phase_stamps.txt) -- 2.1 MMAC at ~35 MAC / cycle.
+// Same tensors out (z1, y1, qkv_raw / stacked / lse / y of both layers, z2, y; the eight partial rows).
+template <int CI, int CW, int GP>
+__global__ __launch_bounds__(1024) void wopos_block_m_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_down,
+                                                                 const float* __restrict__ w_qh, const float* __restrict__ w_qw,
+                                                                 const float* __restrict__ w_up, BlkArgs a) {
+    constexpr int HW = 16, G = CW / GP, LDT = S2_LDT;
+    static_assert(CI / 16 <= 16 && 2 * CW / 16 <= 16, "16-row blocks over 16 waves");
+    constexpr int PCH[4] = {G, CW, G, CW};
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                    // [CI][LDT]   block input (the identity of the last stage)
+    float* A = X + CI * LDT;                            // [CW][LDT]   the running activation tile
+    float* Q = A + CW * LDT;                            // [2CW][LDT]  normalised q | k | v of the current attention layer
+    float* prm = Q + 2 * CW * LDT;                      // [G | CW | G | CW][4]: the bn_similarity / bn_output parameters
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, n0 = grp * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15;
+    const int poff[4] = {0, G * 4, G * 4 + CW * 4, 2 * G * 4 + CW * 4};
+    {
+        constexpr int NX4 = CI * 64 / 4 / 1024;          // float4 per thread
+        float4 xv[NX4];
+#pragma unroll
+        for (int k = 0; k < NX4; ++k) {
+            const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4);
+            xv[k] = *reinterpret_cast<const float4*>(x + ((unsigned)(n0 + img) * CI) * HW + (unsigned)rem * 4);
+        }
+        float pv[4] = {0.f, 0.f, 0.f, 1.f};
+        int pdst = -1;
+        {
+            constexpr int BNI[4] = {2, 3, 5, 6};
+            int o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (tid >= o && tid < o + PCH[b]) {
+                    const int ch = tid - o;
+                    pv[0] = a.bn[BNI[b]].weight[ch];
+                    pv[1] = a.bn[BNI[b]].bias[ch];
+                    if (!a.training) { pv[2] = a.bn[BNI[b]].rmean[ch]; pv[3] = a.bn[BNI[b]].rvar[ch]; }
+                    pdst = poff[b] + ch * 4;
+                }
+                o += PCH[b];
+            }
+        }
+        MEDT_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < NX4; ++k) {
+            const int e4 = tid + k * 1024, img = e4 / (CI * 4), rem = e4 - img * (CI * 4), c = rem >> 2, p4 = rem & 3;
+            *reinterpret_cast<float4*>(X + c * LDT + img * 16 + p4 * 4) = xv[k];
+        }
+        if (pdst >= 0) { prm[pdst] = pv[0]; prm[pdst + 1] = pv[1]; prm[pdst + 2] = pv[2]; prm[pdst + 3] = pv[3]; }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- conv_down + bn1 + ReLU                                                              (axialnet.py:373-375)
+    if (wv < CW / 16) {
+        const int ch0 = 16 * wv + 4 * (lane >> 4);
+        BlkAccPrm q;
+        blk_acc_prm(a.bn[0], ch0, a.training, q);
+        medt_f4 acc[4];
+        blk_mfma_proj<CI>(w_down, 16 * wv, X, acc);
+        float sc[4], sh[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.z1[((unsigned)(n0 + pt) * CW + ch0 + r) * HW + p] = acc[pt][r];
+        blk_acc_bn(acc, q, a.part[0] + (size_t)grp * CW * 2, ch0, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(fmaf(acc[pt][r], sc[r], sh[r]), 0.f);
+                A[(ch0 + r) * LDT + 16 * pt + p] = v;
+                a.y1[((unsigned)(n0 + pt) * CW + ch0 + r) * HW + p] = v;
+            }
+    }
+    MEDT_LDS_BARRIER();
+    // ---- height layer, width layer (+ ReLU)                                                   (:377-379)
+    wave_attention_m<CW, GP, 0, false, true>(w_qh, A, Q, a.bn[1], prm + poff[0], prm + poff[1], a.part[1] + (size_t)grp * 2 * CW * 2,
+                                             a.part[2] + (size_t)grp * G * 2, a.part[3] + (size_t)grp * CW * 2, a.qkv_h, a.stk_h, a.lse_h,
+                                             a.y_h, n0, a.training, a.eps, wv);
+    wave_attention_m<CW, GP, 1, true, true>(w_qw, A, Q, a.bn[4], prm + poff[2], prm + poff[3], a.part[4] + (size_t)grp * 2 * CW * 2,
+                                            a.part[5] + (size_t)grp * G * 2, a.part[6] + (size_t)grp * CW * 2, a.qkv_w, a.stk_w, a.lse_w,
+                                            a.y_w, n0, a.training, a.eps, wv);
+    // ---- conv_up + bn2 + identity + ReLU                                                       (:381-389)
+    if (wv < CI / 16) {
+        const int ch0 = 16 * wv + 4 * (lane >> 4);
+        BlkAccPrm q;
+        blk_acc_prm(a.bn[7], ch0, a.training, q);
+        medt_f4 acc[4];
+        blk_mfma_proj<CW>(w_up, 16 * wv, A, acc);
+        float sc[4], sh[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.z2[((unsigned)(n0 + pt) * CI + ch0 + r) * HW + p] = acc[pt][r];
+        blk_acc_bn(acc, q, a.part[7] + (size_t)grp * CI * 2, ch0, a.training, a.eps, sc, sh);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                a.y[((unsigned)(n0 + pt) * CI + ch0 + r) * HW + p] =
+                    fmaxf(fmaf(acc[pt][r], sc[r], sh[r]) + X[(ch0 + r) * LDT + 16 * pt + p], 0.f);
+    }
+}
+
 static bool block_fused_enabled() {
     static const bool on = [] {
         const char* e = getenv("MEDT_BLOCK_FUSED");
@@ -1178,6 +1284,15 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
             hipLaunchKernelGGL((wopos_block8_fwd_kernel<64, 32, 4, false>), dim3(d.bn_groups), dim3(1024), lds8, s, x, p.w_down,
                                p.height.w_qkv, p.width.w_qkv, p.w_up, a);
         return launch_status("wopos_block8_fwd");
+    }
+    static const bool mfma = [] { const char* e = getenv("MEDT_BLOCK_MFMA"); return !(e && e[0] == '0'); }();
+    if (mfma) {                                         // round 6: the contractions on the matrix cores
+        const size_t ldsm = ((size_t)(d.C + 3 * d.width) * S2_LDT + (size_t)(2 * d.G + 2 * d.width) * 4) * sizeof(float);
+        static unsigned char attrm[64];
+        if (int rcm = lds_opt_in((const void*)wopos_block_m_fwd_kernel<128, 64, 8>, attrm, "wopos_block_m_fwd")) return rcm;
+        hipLaunchKernelGGL((wopos_block_m_fwd_kernel<128, 64, 8>), dim3(d.bn_groups), dim3(1024), ldsm, s, x, p.w_down,
+                           p.height.w_qkv, p.width.w_qkv, p.w_up, a);
+        return launch_status("wopos_block_m_fwd");
     }
     const size_t lds = ((size_t)(d.C + 3 * d.width) * 64 + nprm) * sizeof(float);
     static unsigned char attr[2][64];
