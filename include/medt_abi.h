@@ -64,6 +64,9 @@ int    medt_queue_destroy(void* queue);
 int    medt_queue_bind(void* queue, void* stream);      /* queue == NULL: unbind the stream */
 size_t medt_queue_pending(const void* queue);            /* recorded, not yet flushed */
 int    medt_queue_flush(void* queue, void* stream);      /* enqueue everything recorded on `stream` */
+/* ... with the dedicated MFMA weight-gradient launches on `aux_stream` (another stream of the caller's, idle by now; NULL or == stream:
+ * medt_queue_flush), forked from and joined back into `stream` by events: after the call everything is ordered on `stream` (ABI v9) */
+int    medt_queue_flush2(void* queue, void* stream, void* aux_stream);
 int    medt_queue_discard(void* queue);                  /* drop everything recorded WITHOUT launching it (error paths: the
                                                             buffers the jobs point into are about to be released) */
 

@@ -47,12 +47,35 @@ int medt_queue_bind(void* q, void* stream) {
 
 size_t medt_queue_pending(const void* q) { return q ? ((const Queue*)q)->pending() : 0; }
 
-int medt_queue_flush(void* qv, void* stream) {
-    if (!qv) { set_error("queue flush: null queue"); return MEDT_EINVAL; }
-    Queue& q = *(Queue*)qv;
-    hipStream_t s = (hipStream_t)stream;
+// aux (optional): a second stream of the caller's that is idle by now -- the dedicated MFMA weight-gradient kernels (the LDS-patch
+// problems of the 16-wide maps, the few-tile problems) are issued THERE, side by side with the grouped launches on `stream`
+// (event fork / join: capturable), and the slab reductions follow the join.  Round 6: the local branch's flush tail was 152 us of
+// serial launches behind the step's longest chain while the other stream had been idle for ~90 us.
+static int queue_flush(Queue& q, hipStream_t s, hipStream_t aux) {
     int rc = MEDT_OK;
     if (abl_skip("flush")) rc = -1000;                      // (timing experiments: drop everything recorded)
+    std::vector<const MJob*> r16, rest;
+    for (const MJob& m : q.mwgrad) {
+        if (conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS)) r16.push_back(&m);
+        else if (m.K == 1 || m.K == 3) rest.push_back(&m);
+    }
+    const bool fork = aux && aux != s && !rc && !(r16.empty() && rest.empty());
+    static hipEvent_t ev[2] = {nullptr, nullptr};
+    if (fork && !ev[0]) {
+        if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) { set_error("queue flush: hipEventCreate failed"); return MEDT_ELAUNCH; }
+    }
+    hipStream_t sm = s;                                     // stream of the dedicated MFMA weight gradients
+    if (fork) {
+        if (hipEventRecord(ev[0], s) != hipSuccess || hipStreamWaitEvent(aux, ev[0], 0) != hipSuccess) {
+            set_error("queue flush: event fork failed"); return MEDT_ELAUNCH;
+        }
+        sm = aux;
+        // the LDS-patch problems of the 16-wide maps side by side in one launch (they fill each other's load gaps); so the others
+        if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), sm);
+        if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), sm);
+        if (hipEventRecord(ev[1], aux) != hipSuccess) { set_error("queue flush: event join failed"); return MEDT_ELAUNCH; }
+    }
     // order: statistics bookkeeping; first-stage sums and weight gradients; then the reductions of their partial slabs
     for (const FlipJob& f : q.flip)
         if (!rc) rc = conv_flip_weights(f.w, f.wt, f.Cout, f.Cin, f.K, s);
@@ -62,19 +85,25 @@ int medt_queue_flush(void* qv, void* stream) {
     if (!rc && !q.sfin.empty()) rc = wopos_small_bwd_finalize_grouped(q.sfin.data(), (int)q.sfin.size(), s);
     if (!rc && !q.csum.empty()) rc = channel_sum_grouped(q.csum.data(), (int)q.csum.size(), s);
     if (!rc && !q.wgrad.empty()) rc = conv_wgrad_grouped(q.wgrad.data(), (int)q.wgrad.size(), s);
-    {
-        // the LDS-patch problems of the 16-wide maps side by side in one launch (they fill each other's load gaps); so the others
-        std::vector<const MJob*> r16, rest;
-        for (const MJob& m : q.mwgrad) {
-            if (conv_wgrad_rows16_ok(m.Cin, m.H, m.W, m.Ho, m.Wo, m.K, m.stride, m.pad, m.QS)) r16.push_back(&m);
-            else if (m.K == 1 || m.K == 3) rest.push_back(&m);
-        }
+    if (fork) {
+        if (hipStreamWaitEvent(s, ev[1], 0) != hipSuccess) { set_error("queue flush: event join failed"); return MEDT_ELAUNCH; }
+    } else {
         if (!rc && !r16.empty()) rc = conv_wgrad_rows16_grouped(r16.data(), (int)r16.size(), s);
         if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
     }
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
     q.flip.clear(); q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
     return rc == -1000 ? MEDT_OK : rc;
+}
+
+int medt_queue_flush(void* qv, void* stream) {
+    if (!qv) { set_error("queue flush: null queue"); return MEDT_EINVAL; }
+    return queue_flush(*(Queue*)qv, (hipStream_t)stream, nullptr);
+}
+
+int medt_queue_flush2(void* qv, void* stream, void* aux_stream) {
+    if (!qv) { set_error("queue flush: null queue"); return MEDT_EINVAL; }
+    return queue_flush(*(Queue*)qv, (hipStream_t)stream, (hipStream_t)aux_stream);
 }
 
 int medt_queue_discard(void* qv) {

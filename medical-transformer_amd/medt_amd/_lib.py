@@ -95,6 +95,7 @@ SIGNATURES = {
     "medt_queue_bind": (C.c_int, [C.c_void_p, C.c_void_p]),
     "medt_queue_pending": (C.c_size_t, [C.c_void_p]),
     "medt_queue_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "medt_queue_flush2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "medt_queue_discard": (C.c_int, [C.c_void_p]),
     "medt_axial_stats_floats": (C.c_size_t, [C.POINTER(AxialDesc)]),
     "medt_axial_workspace_bytes": (C.c_size_t, [C.POINTER(AxialDesc)]),

@@ -20,7 +20,16 @@ ENABLED = os.environ.get("MEDT_DEFER", "1") != "0"
 # one queue per recording stream: the stream whose pass ends first (MedT's global branch) issues its own grouped
 # launches right there, under the other branch's latency-bound chain, instead of after the join (net.medt_forward)
 SPLIT = os.environ.get("MEDT_SPLIT_FLUSH", "1") != "0"
+# the pass's LAST flush (the longer branch's recorded jobs, behind the step's critical chain) runs its dedicated MFMA weight-gradient
+# launches on the other branch's stream, which is idle by then (medt_queue_flush2; net.medt_forward names the stream)
+TAIL_FORK = os.environ.get("MEDT_TAIL_FORK", "1") != "0"
 _current = None
+_aux = None            # torch.cuda.Stream of the other branch (two-branch networks), or None
+
+
+def set_aux_stream(stream):
+    global _aux
+    _aux = stream
 
 
 class StepQueue:
@@ -64,9 +73,13 @@ class StepQueue:
         if self.drop:
             return self.discard()
         cur = torch.cuda.current_stream().cuda_stream
+        aux = _aux.cuda_stream if (TAIL_FORK and _aux is not None and torch.is_grad_enabled()) else None
         for h in self._handles.values():
             self.issued += int(L.lib().medt_queue_pending(h))
-            L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
+            if aux is not None and aux != cur:
+                L.check(L.lib().medt_queue_flush2(h, cur, aux), "medt_queue_flush2")
+            else:
+                L.check(L.lib().medt_queue_flush(h, cur), "medt_queue_flush")
             self._keep[h].clear()
 
     def flush_current_stream(self):

@@ -132,6 +132,7 @@ def medt_forward(net, x):
     side = _side_stream(xin.device) if TWO_STREAMS else None
     if side is not None:
         side.wait_stream(main)
+    DEFER.set_aux_stream(side)             # (the pass's last flush forks its MFMA weight gradients onto the idle branch stream)
     # (the global branch's backward ends well before the local one's: its recorded weight-gradient jobs are issued on
     # its own stream as soon as its stem's backward has run, under the local chain -- defer.flush_current_stream)
     g = _stem(net, xin, first_of_branch=side is not None)

@@ -9,6 +9,6 @@ b() { name=$1; shift; echo -n "$name " >> $O/ab.txt; env "$@" timeout 300 python
 b DEFAULT A=1
 b S2_OFF MEDT_BLOCK_S2=0
 b DEFAULT2 A=1
-b S2_OFF2 MEDT_BLOCK_S2=0
+b MFMA_OFF MEDT_BLOCK_MFMA=0
 cat $O/ab.txt
 bash scripts/r6_trace.sh r6_call10/trace
