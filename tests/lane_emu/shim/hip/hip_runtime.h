@@ -77,6 +77,12 @@ static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+// (every emulated launch runs to completion before the call returns: events order nothing)
+typedef void* hipEvent_t;
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 // (one work-item runs at a time: read-modify-write is atomic by construction; the ORDER of float atomics is the emulator's)
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
