@@ -31,6 +31,7 @@
 #include "axial_tiles.h"
 #include "sim_tables.h"
 #include "defer.h"
+#include "fin_inline.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -165,6 +166,7 @@ struct SweepArgs {
     float* raw32;                  // bf16 storage only: qkv_raw widened to float32 once, for the 1x1 dgrad / wgrad behind bn_qkv's backward
     int tiles, nparts;             // tiles of S_T sequences per BN group; workgroups per BN group
     int qb_rpg;                    // rows per BN group of part_qb (the sweep's nparts rows first, then the fix kernel's)
+    BfinSrc ob;                    // on: bn_output's backward coefficients are derived here from axial_out_bwd_stats' partial rows (fin_inline.h)
 };
 
 // Sum K per-thread values over the workgroup (nw waves, fixed order); thread k < K stores value k to out[k].
@@ -224,8 +226,40 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     for (int ch = 0; ch < NCH; ++ch) {
         sc[ch] = a.qs.scale[grp * 2 * g.C + hg * NCH + ch];
         sh[ch] = a.qs.shift[grp * 2 * g.C + hg * NCH + ch];
+        if (!a.ob.on) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) cf[ch][k] = a.out_coef[((size_t)grp * g.OC + hg * NCH + ch) * 3 + k];
+            for (int k = 0; k < 3; ++k) cf[ch][k] = a.out_coef[((size_t)grp * g.OC + hg * NCH + ch) * 3 + k];
+        }
+    }
+    if (a.ob.on) {
+        // bn_output's backward finalised HERE (fin_inline.h: no bn_bwd_finalize launch in front of the sweep).  Eight lanes per
+        // channel, eight channels of the head at a time: every wave sums the partial rows (one load round trip), runs the double
+        // arithmetic once for all of them and broadcasts the three coefficients per channel; the first workgroup of the head writes
+        // the coefficients and the parameter gradients (one BatchNorm group).
+        const BfinJob& j = a.ob.j;
+        const int ln = threadIdx.x & 63, slot = ln >> 3, sub = ln & 7;
+#pragma unroll
+        for (int c0 = 0; c0 < NCH; c0 += 8) {
+            const int chl = min(c0 + slot, NCH - 1), chg = hg * NCH + chl;
+            double s1, s2;
+            fin_slot_sums(j.partials, j.ppg, g.OC, chg, sub, s1, s2);
+            s1 *= j.dscale;
+            s2 *= j.dscale;
+            float c3[3];
+            bn_bwd_coef(s1, s2, j.count, j.dscale, j.st.mean[chg], j.st.rstd[chg], j.weight[chg], j.training, c3);
+            if (blockIdx.x == 0 && threadIdx.x < 64 && sub == 0 && c0 + slot < NCH) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) j.coef[(size_t)chg * 3 + k] = c3[k];
+                if (j.dweight) j.dweight[chg] = (float)s2;
+                if (j.dbias) j.dbias[chg] = (float)s1;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (c0 + cc < NCH) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) cf[c0 + cc][k] = fin_bcast(c3[k], cc * 8);
+                }
+        }
     }
 #pragma unroll
     for (int c = 0; c < GP; ++c) {
@@ -962,9 +996,11 @@ int axial_bwd_tables(const AxialGeom& g, const float* relative, float* tables, h
 int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, BnStats sim,
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
-                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32) {
+                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32,
+                         const BfinSrc* ob) {
     if (abl_skip("sweep")) return MEDT_OK;
     SweepArgs a;
+    a.ob = ob ? *ob : no_bfin_src();
     a.g = g;
     a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.relative = relative; a.out_coef = out_coef;
     a.qs = qkv; a.ss = sim; a.gates = gates; a.pool = stride;

@@ -17,6 +17,7 @@
 // consecutive addresses).  All tensors stay NCHW: the reference's permute+contiguous copies
 // (:143-148, :181-184) become address arithmetic.
 #include "axial_tiles.h"
+#include "fin_inline.h"
 #include "sim_tables.h"
 #include <stdlib.h>
 
@@ -877,12 +878,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_kernel(
         return launch_status(#KERNEL);                                                                        \
     } while (0)
 
+// The one-launch exact kernel of axial_fast.hip runs: it can finalise bn_similarity itself (fin_inline.h).
+bool axial_attn_fwd_inlines(const AxialGeom& g, GatePtrs gates, const unsigned* flag) {
+    return fast_path_enabled() && gates.stride == 0 && g.pos && !(g.L & 3) && g.fast3 && !g.rows4 && !(g.bound_path && flag);
+}
+
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                   GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
+                   GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s,
+                   const FinSrc* simsrc) {
     if (abl_skip("attn_fwd")) return MEDT_OK;
+    if (simsrc && simsrc->on && !axial_attn_fwd_inlines(g, gates, flag)) { set_error("attn_fwd: no kernel to finalise bn_similarity in"); return MEDT_EINVAL; }
     if (fast_path_enabled() && gates.stride == 0) {            // (per-sequence gates: generic kernel)
-        const int rc = g.bf16 ? axial_attn_fwd_fast_bf16(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s)
-                              : axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s);
+        const int rc = g.bf16 ? axial_attn_fwd_fast_bf16(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s, simsrc)
+                              : axial_attn_fwd_fast(g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, s, simsrc);
         if (rc <= 0) return rc;
     }
     const size_t lds = axial_core_lds_bytes(g, false);

@@ -16,6 +16,7 @@
 // (axial_attn_fwd_fast), MEDT_FAST_BF16=1 -> bfloat16 storage (axial_attn_fwd_fast_bf16).  The storage type is a
 // compile-time constant of the hot loops (kBF); the two sets of kernels live in distinct namespaces.
 #include "axial_tiles.h"
+#include "fin_inline.h"
 #include <type_traits>
 
 #ifndef MEDT_FAST_BF16
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
                                                                  float* __restrict__ stacked,
                                                                  float* __restrict__ lse_out,
                                                                  float* __restrict__ out_partials,
-                                                                 unsigned* __restrict__ flag) {
+                                                                 unsigned* __restrict__ flag, FinSrc simsrc) {
     using F = Fast3<GP, L>;
     constexpr int HQ = F::HQ, NCH = F::NCH, OCG = F::OCG, RS = F::RS, CS = F::CS, S_T = F::S_T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -412,9 +413,23 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_fwd3_kernel(AxialGeom g, co
     if (EXACT && flag && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // nothing to repair
     const int grp = blockIdx.x / g.fparts, part = blockIdx.x - grp * g.fparts, hg = blockIdx.y;
     const float f_qr = gate(gates.f_qr), f_kr = gate(gates.f_kr), f_sve = gate(gates.f_sve), f_sv = gate(gates.f_sv);
-    const float a_qk = ss.scale[grp * g.SC + hg] * MEDT_LOG2E;
-    const float a_qr = ss.scale[grp * g.SC + g.G + hg] * f_qr * MEDT_LOG2E;
-    const float a_kr = ss.scale[grp * g.SC + 2 * g.G + hg] * f_kr * MEDT_LOG2E;
+    float s_qk, s_qr, s_kr;
+    if (simsrc.on) {
+        // bn_similarity finalised HERE from the statistics kernel's partial rows (fin_inline.h: no bn_finalize launch in front of
+        // this kernel); the first workgroup of each head also writes what the backward pass and the next step read
+        // (lanes 0 / 1 / 2 of every wave take the qk / qr / kr channel of the head: one run of the double arithmetic, then a broadcast)
+        const int l3 = min((int)(threadIdx.x & 63), 2), chl = l3 * g.G + hg;
+        const FinVals v = fin_channel_lane(simsrc, chl);
+        s_qk = fin_bcast(v.scale, 0); s_qr = fin_bcast(v.scale, 1); s_kr = fin_bcast(v.scale, 2);
+        if (blockIdx.x == 0 && threadIdx.x < 3) fin_save(simsrc, chl, v);
+    } else {
+        s_qk = ss.scale[grp * g.SC + hg];
+        s_qr = ss.scale[grp * g.SC + g.G + hg];
+        s_kr = ss.scale[grp * g.SC + 2 * g.G + hg];
+    }
+    const float a_qk = s_qk * MEDT_LOG2E;
+    const float a_qr = s_qr * f_qr * MEDT_LOG2E;
+    const float a_kr = s_kr * f_kr * MEDT_LOG2E;
     stage_tables_cols<GP>(tab, relative, L, a_kr);
     if (threadIdx.x < NCH) {                                  // bn_qkv's affine for this head group: LDS-resident
         red[128 + threadIdx.x] = qs.scale[grp * 2 * g.C + hg * NCH + threadIdx.x];
@@ -1097,7 +1112,12 @@ static void r4_launch(bool vec, const AxialGeom& g, const float* qkv_raw, BnStat
 }
 
 int MEDT_FAST_FN(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                        GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s) {
+                        GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s,
+                        const FinSrc* simsrc) {
+    const FinSrc nosrc = no_fin_src();
+    if (simsrc && simsrc->on && !(g.fast3 && !g.rows4 && !(g.bound_path && flag))) {
+        set_error("attn_fwd: bn_similarity cannot be finalised in this kernel (axial_attn_fwd_inlines)"); return MEDT_EINVAL;
+    }
 #define MEDT_K_EXACT(a, b, c) attn_fwd3_kernel<a, b, c, true>
 #define MEDT_K_BOUND(a, b, c) attn_fwd3_kernel<a, b, c, false>
     if (g.rows4) {
@@ -1127,11 +1147,12 @@ int MEDT_FAST_FN(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats 
     if (g.fast3 && g.bound_path && flag) {
         // large problems: bound-referenced softmax, then the (normally empty) repair pass
         if (hipMemsetAsync(flag, 0, sizeof(unsigned), s) != hipSuccess) { set_error("attn_fwd: memset failed"); return MEDT_ELAUNCH; }
-        int rc = [&]() -> int { MEDT_FAST3_DISPATCH(MEDT_K_BOUND, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag); }();
+        int rc = [&]() -> int { MEDT_FAST3_DISPATCH(MEDT_K_BOUND, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, nosrc); }();
         if (rc) return rc;
-        MEDT_FAST3_DISPATCH(MEDT_K_EXACT, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag);
+        MEDT_FAST3_DISPATCH(MEDT_K_EXACT, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, flag, nosrc);
     }
-    if (g.fast3) MEDT_FAST3_DISPATCH(MEDT_K_EXACT, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, (unsigned*)nullptr);
+    if (g.fast3) MEDT_FAST3_DISPATCH(MEDT_K_EXACT, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials, (unsigned*)nullptr,
+                                     (simsrc ? *simsrc : nosrc));
     MEDT_FAST_DISPATCH(attn_fwd4_kernel, g, qkv_raw, qkv, sim, relative, gates, stacked, lse, out_partials);
 }
 

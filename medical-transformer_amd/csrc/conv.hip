@@ -818,24 +818,50 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     return splits == 1 ? MEDT_OK : reduce_rows(scratch, splits, Cout * Ktot, dw, s);
 }
 
-// per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients); two stages, deterministic
+// per-channel sum over (n, pixels):  out[c] = sum x[n,c,:]   (bias gradients); deterministic.  One workgroup per (channel, split);
+// round 6: the number of splits follows the size -- a channel of <= 4096 values is ONE workgroup that writes the gradient itself
+// (no partial rows, no reduction job).  Sixteen splits everywhere made the local branch's five decoders 7936 workgroups of 4 - 1024
+// values each: 48 us of the step's final flush for 2 MB.
 #define CS_SPLITS 16
+int channel_sum_splits_for(int N, int HW) {
+    const long total = (long)N * HW;
+    long sp = (total + 4095) / 4096;
+    return sp < 1 ? 1 : (sp > CS_SPLITS ? CS_SPLITS : (int)sp);
+}
 __device__ __forceinline__ void channel_sum_body(const float* __restrict__ x, float* __restrict__ part, int N, int C,
-                                                 int HW, int c, int sp) {
+                                                 int HW, int c, int sp, int splits) {
     MEDT_STATIC_SHARED float red[MEDT_WAVES];
     float v[1] = {0.f};
     const long total = (long)N * HW;
-    const long per = (total + CS_SPLITS - 1) / CS_SPLITS, beg = sp * per, end = beg + per < total ? beg + per : total;
-    for (long q = beg + threadIdx.x; q < end; q += MEDT_THREADS) {
-        const int n = (int)(q / HW), p = (int)(q - (long)n * HW);
-        v[0] += x[((size_t)n * C + c) * HW + p];
+    const long per = (total + splits - 1) / splits, beg = sp * per, end = beg + per < total ? beg + per : total;
+    if (total < (1l << 31)) {
+        // 32-bit index arithmetic (a 64-bit division per element was most of this kernel's time), four loads in flight per lane
+        const unsigned e32 = (unsigned)end, hw = (unsigned)HW;
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (unsigned q = (unsigned)beg + threadIdx.x; q < e32; q += 4 * MEDT_THREADS) {
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned qq = min(q + u * MEDT_THREADS, e32 - 1), n = qq / hw, p = qq - n * hw;
+                t[u] = x[((size_t)n * C + c) * HW + p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q + u * MEDT_THREADS < e32) a4[u] += t[u];
+        }
+        v[0] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    } else {
+        for (long q = beg + threadIdx.x; q < end; q += MEDT_THREADS) {
+            const int n = (int)(q / HW), p = (int)(q - (long)n * HW);
+            v[0] += x[((size_t)n * C + c) * HW + p];
+        }
     }
     block_sum<1>(v, red, part + (size_t)sp * C + c);
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                                    int N, int C, int HW) {
-    channel_sum_body(x, part, N, C, HW, blockIdx.x, blockIdx.y);
+    channel_sum_body(x, part, N, C, HW, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s) {
@@ -869,27 +895,27 @@ using CBatch = JobBatch<CJob, 96>;
 __global__ __launch_bounds__(MEDT_THREADS) void channel_sum_grouped_kernel(CBatch b);
 
 int channel_sum(const float* x, float* out, float* scratch, int N, int C, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, CS_SPLITS), dim3(MEDT_THREADS), 0, s, x, scratch, N, C, HW);
+    const int splits = channel_sum_splits_for(N, HW);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, splits), dim3(MEDT_THREADS), 0, s, x, splits == 1 ? out : scratch, N, C, HW);
     int rc = launch_status("channel_sum");
-    if (rc) return rc;
-    return reduce_rows(scratch, CS_SPLITS, C, out, s);
+    if (rc || splits == 1) return rc;
+    return reduce_rows(scratch, splits, C, out, s);
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void channel_sum_grouped_kernel(CBatch b) {
     const int j = find_job(b, blockIdx.x);
     const CJob& c = b.job[j];
     const int local = blockIdx.x - b.start[j];
-    channel_sum_body(c.x, c.part, c.N, c.C, c.HW, local % c.C, local / c.C);
+    channel_sum_body(c.x, c.part, c.N, c.C, c.HW, local % c.C, local / c.C, c.splits);
 }
 
-int channel_sum_splits() { return CS_SPLITS; }
 
 int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += 96) {
         CBatch b;
         b.n = n - i0 < 96 ? n - i0 : 96;
         int blocks = 0;
-        for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[i0 + i]; b.start[i] = blocks; blocks += jobs[i0 + i].C * CS_SPLITS; }
+        for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[i0 + i]; b.start[i] = blocks; blocks += jobs[i0 + i].C * jobs[i0 + i].splits; }
         b.start[b.n] = blocks;
         hipLaunchKernelGGL(channel_sum_grouped_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
         int rc = launch_status("channel_sum_grouped");

@@ -44,7 +44,7 @@ struct SmallFinArgs {                // wopos_small_bwd_finalize: BatchNorm para
 };
 struct RJob { const float* src; float* dst; int P, K; };                         // reduce_rows
 struct FlipJob { const float* w; float* wt; int Cout, Cin, K; };                  // conv_flip_weights (forward pass, for the MFMA backward-data)
-struct CJob { const float* x; float* part; int N, C, HW; };                      // channel_sum, first stage
+struct CJob { const float* x; float* part; int N, C, HW, splits; };              // channel_sum: part[splits][C] (splits == 1: the gradient itself)
 struct WJob {                        // conv_wgrad_body<K, 64, 64> over a (gx, gy, gz) grid of (o-tile, k-tile, position chunk)
     const float *dy, *raw, *coef, *x;
     float* scratch;

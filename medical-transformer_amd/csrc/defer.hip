@@ -1,6 +1,9 @@
 // defer.hip -- the queue registry and flush of defer.h, and its C entry points (include/medt_abi.h: medt_queue_*).
 #include "defer.h"
+#include "fin_inline.h"
+#include <stdlib.h>
 #include <mutex>
+#include <stdio.h>
 
 namespace medt {
 
@@ -12,6 +15,12 @@ Queue* queue_for(hipStream_t s) {
     for (auto& e : g_bound)
         if (e.first == s) return e.second;
     return nullptr;
+}
+
+// fin_inline.h: consumer-side BatchNorm finalisation (MEDT_INLINE_FIN=0: the finalisation launches everywhere)
+bool inline_fin_enabled() {
+    static const bool on = [] { const char* e = getenv("MEDT_INLINE_FIN"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 }  // namespace medt

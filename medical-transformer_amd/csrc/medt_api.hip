@@ -2,6 +2,7 @@
 // Each entry point validates its descriptor, carves the caller's workspace and enqueues
 // the kernel chain on the caller's stream; nothing here allocates or synchronises.
 #include "defer.h"
+#include "fin_inline.h"
 #include <string.h>
 
 namespace medt {
@@ -133,13 +134,14 @@ struct BwdWs {
 // axial_bwd.hip, or the two generic L x L passes of axial_core.hip.
 static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, const medt_axial_params* p, const BwdWs& w,
                               const float* qkv_raw, const float* stacked, const float* lse, const float* dy, const LayerStats& st,
-                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s, Queue* q) {
+                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s, Queue* q,
+                              const BfinSrc* ob = nullptr) {
     const int tr = d->training ? 1 : 0;
     int rc;
     if (w.sweep) {
         if ((rc = axial_attn_bwd_sweep(g, w.plan, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out,
                                        d->stride, w.dqkv, w.part_qb, w.qb_rpg, w.part_sb, w.rel_part, w.pg_part, w.gram,
-                                       want_gates ? w.gate_raw : nullptr, s, w.raw32))) return rc;
+                                       want_gates ? w.gate_raw : nullptr, s, w.raw32, ob))) return rc;
         AxialGeom gs = g;
         gs.tpg = w.plan.nparts;                               // part_sb rows per group
         // (+ the sliding-window table sums of the fix kernel as extra blocks of this launch)
@@ -319,15 +321,28 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
                           st.qkv, s, &tj))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
     if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
-    if ((rc = bn_finalize(w.part_sim, sim_stats_parts(g), g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum, d->eps, tr,
-                          st.sim, s))) return rc;
+    // Round 6 (fin_inline.h): inside the networks (training mode, one BatchNorm group, few partial rows) bn_similarity and bn_output
+    // are finalised by the kernels that consume them -- the attention kernel and the output pass -- instead of by a bn_finalize
+    // launch each: 7 launches per layer become 5.
+    auto fin_src_of = [&](const float* partials, int parts, int CH, double count, const medt_bn_ptrs& bn, BnStats out) {
+        FinSrc fs = no_fin_src();
+        fs.f = make_fin(partials, parts, CH, count, bn, out);
+        fs.momentum = d->momentum; fs.eps = d->eps; fs.on = 1;
+        return fs;
+    };
+    const bool sim_inl = inline_fin_ok(tr, g.groups, sim_stats_parts(g)) && axial_attn_fwd_inlines(g, gates, w.flag);
+    const FinSrc sim_src = fin_src_of(w.part_sim, sim_stats_parts(g), g.SC, g.sim_count, p->bn_similarity, st.sim);
+    if (!sim_inl && (rc = bn_finalize(w.part_sim, sim_stats_parts(g), g.groups, g.SC, g.sim_count, p->bn_similarity, d->momentum,
+                                      d->eps, tr, st.sim, s))) return rc;
     // logits + softmax + gated sv|sve, bn_output batch statistics                                 :157-178
     if ((rc = axial_attn_fwd(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, sv->lse,
-                             tr ? w.part_out : nullptr, w.flag, s))) return rc;
-    if ((rc = bn_finalize(w.part_out, g.oparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
-                          st.out, s))) return rc;
+                             tr ? w.part_out : nullptr, w.flag, s, sim_inl ? &sim_src : nullptr))) return rc;
+    const bool out_inl = inline_fin_ok(tr, g.groups, g.oparts) && axial_out_fwd_inlines(*d);
+    const FinSrc out_src = fin_src_of(w.part_out, g.oparts, g.OC, g.row_count, p->bn_output, st.out);
+    if (!out_inl && (rc = bn_finalize(w.part_out, g.oparts, g.groups, g.OC, g.row_count, p->bn_output, d->momentum, d->eps, tr,
+                                      st.out, s))) return rc;
     // bn_output + pair-sum + AvgPool                                                              :179-187
-    return axial_out_fwd(*d, stacked, st.out, y, s);
+    return axial_out_fwd(*d, stacked, st.out, y, s, out_inl ? &out_src : nullptr);
 }
 
 int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, const float* y,
@@ -372,14 +387,21 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
     const float out_dscale = 1.f / (float)(d->stride * d->stride);
     if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
-    if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
-                              w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
+    // (round 6, fin_inline.h: where the single sweep runs inside the networks, IT derives bn_output's backward coefficients from the
+    //  partial rows and its first workgroup per head writes them and the parameter gradients -- no bn_bwd_finalize launch)
+    BfinSrc ob = no_bfin_src();
+    if (w.sweep && inline_fin_ok(tr, g.groups, ppg)) {
+        ob.j = BfinJob{w.part_ob, ppg, g.groups, g.OC, tr, g.row_count, out_dscale, st.out, p->bn_output.weight, w.coef_out,
+                       gr->bn_out_weight, gr->bn_out_bias};
+        ob.on = 1;
+    } else if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
+                                     w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
     // softmax / bn_similarity / logits backward: dqkv, the partial rows of bn_qkv's backward, of the tables and of the gates
     // (sigmoid gates: the gate reduction + sigmoid backward below run immediately and read what the relfix kernel writes,
     //  so that kernel must not be recorded for the flush -- MEDT_DEFER_RELFIX=1 -- in that mode)
     Queue* relfix_q = (d->gate_mode == 1 && p->f_qr && gr->gates) ? nullptr : queue_for(s);
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
-                                 gr->bn_sim_weight, gr->bn_sim_bias, s, relfix_q))) return rc;
+                                 gr->bn_sim_weight, gr->bn_sim_bias, s, relfix_q, ob.on ? &ob : nullptr))) return rc;
     // bn_qkv backward, qkv_transform backward
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
     static const bool bf16_fused = [] { const char* e = getenv("MEDT_BF16_FIN_APPLY"); return !(e && e[0] == '0'); }();
@@ -638,8 +660,9 @@ int medt_conv_block_bwd(const medt_conv_desc* d, const float* x, const float* w,
     Queue* q = queue_for(s);          // parameter gradients: recorded for the grouped flush when a queue is bound
     if (d->has_bias) {
         if (q) {
-            q->csum.push_back(CJob{grad_out, cw.bias_scratch, d->N, d->Cout, g.HoWo});
-            q->reduce.push_back(RJob{cw.bias_scratch, dbias, channel_sum_splits(), d->Cout});
+            const int splits = channel_sum_splits_for(d->N, g.HoWo);
+            q->csum.push_back(CJob{grad_out, splits == 1 ? dbias : cw.bias_scratch, d->N, d->Cout, g.HoWo, splits});
+            if (splits > 1) q->reduce.push_back(RJob{cw.bias_scratch, dbias, splits, d->Cout});
         } else if ((rc = channel_sum(grad_out, dbias, cw.bias_scratch, d->N, d->Cout, g.HoWo, s))) return rc;
     }
     return conv2d_bwd_weight(grad_out, nullptr, nullptr, x, dw, cw.dw_scratch, d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride,

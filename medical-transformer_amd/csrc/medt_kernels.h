@@ -33,7 +33,10 @@ int bn_bwd_finalize(const float* partials, int parts_per_group, int groups, int 
                     hipStream_t s);
 
 // bn_output apply + pair-sum + AvgPool2d(stride):  stacked (N,OC,H,W) -> y (N,C,H/s,W/s)
-int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s);
+struct FinSrc;
+// src (optional, fin_inline.h; only where axial_out_fwd_inlines()): bn_output finalised by the kernel from the attention kernel's partial rows
+bool axial_out_fwd_inlines(const medt_axial_desc& d);
+int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s, const FinSrc* src = nullptr);
 // d[i] = c0*d[i] + c1*raw[i] + c2 per (group, channel) with raw stored as bfloat16: materialises the bn_qkv backward
 // so the fp32 1x1 dgrad / wgrad kernels run without their (raw, coef) operands
 int bn_bwd_apply_raw_bf16(float* d, const float* raw_bf16, const float* coef, int N, int CH, int HW, int groups, hipStream_t s);
@@ -81,7 +84,7 @@ int conv2d_bwd_weight_splits(int N, int Cin, int Cout, int K, int Ho, int Wo);
 int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, const float* x, float* dw, float* scratch,
                       int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, int groups, hipStream_t s,
                       Queue* q = nullptr);
-int channel_sum_splits();
+int channel_sum_splits_for(int N, int HW);      // workgroups per channel (<= 16); 1: the sums go straight to their destination
 int channel_sum(const float* x, float* out, float* scratch /* 16*C floats */, int N, int C, int HW, hipStream_t s);
 
 // ---- conv_mfma.hip (fp32 matrix-core implicit GEMM; chosen by conv_use_mfma) -----------
@@ -157,12 +160,15 @@ size_t axial_core_lds_bytes(const AxialGeom& g, bool backward);
 struct GatePtrs { const float *f_qr, *f_kr, *f_sve, *f_sv; int stride; };
 
 // axial_fast.hip: 16-byte-LDS-read variants for has_pos && L % 4 == 0; return 1 when not applicable
+struct FinSrc;                   // fin_inline.h: statistics the kernel finalises itself from the producer's partial rows
+struct BfinSrc;
 int axial_attn_fwd_fast(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                        GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
+                        GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s,
+                        const FinSrc* simsrc = nullptr);
 // same kernels compiled for bfloat16 storage of qkv_raw / stacked (axial_fast.hip with -DMEDT_FAST_BF16=1)
 int axial_attn_fwd_fast_bf16(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                              GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag,
-                             hipStream_t s);
+                             hipStream_t s, const FinSrc* simsrc = nullptr);
 int fast3_max_subtiles(int gp, int L, int axis);
 int fast4_subtile_sequences(int L);
 int fast4_max_subtiles(int axis);
@@ -224,8 +230,12 @@ int sim_stats_parts(const AxialGeom& g);
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
                       const float* tables, float* partials, hipStream_t s);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
+// simsrc (optional, fin_inline.h; only where axial_attn_fwd_inlines()): bn_similarity is finalised by the kernel itself from the
+// statistics kernel's partial rows -- `sim` is not read, no bn_finalize launch in front
+bool axial_attn_fwd_inlines(const AxialGeom& g, GatePtrs gates, const unsigned* flag);
 int axial_attn_fwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
-                   GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s);
+                   GatePtrs gates, float* stacked, float* lse, float* out_partials, unsigned* flag, hipStream_t s,
+                   const FinSrc* simsrc = nullptr);
 // backward pass A: partials [group][tile][G][4] = sum dZ*{S_qk,S_qr,S_kr,1}
 int axial_attn_bwd_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStats sim, const float* relative,
                          GatePtrs gates, const float* stacked, const float* lse, const float* dy,
@@ -260,7 +270,8 @@ int axial_bwd_tables(const AxialGeom& g, const float* relative, float* tables, h
 int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, BnStats sim,
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
-                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32 = nullptr);
+                         float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32 = nullptr,
+                         const BfinSrc* ob = nullptr);       // ob (fin_inline.h): bn_output's backward finalised by the sweep, out_coef not read
 // u / w terms of dq | dk (apply != 0: training mode) and the bn_qkv partial rows [nparts, nparts + fparts) (q | k channels)
 int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
                        const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,

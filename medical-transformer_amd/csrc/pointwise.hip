@@ -5,6 +5,7 @@
 // HBM-bound streaming kernels: lanes run along the contiguous pixel dimension, weights and
 // per-channel constants come through the scalar path (wave-uniform addresses).
 #include "defer.h"
+#include "fin_inline.h"
 #include "sim_tables.h"
 #include <type_traits>
 
@@ -268,16 +269,31 @@ __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ in, i
     const int slice = threadIdx.x >> 6;
     float s = 0.f;
     if (k < K) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // 4 independent chains: loads overlap
+        // 16 independent chains, their loads issued together: the jobs with ~1000 rows (the relative-table partial rows of the
+        // single-sweep attention backward, one per sweep workgroup) were 65 dependent round trips per lane with four
+        float c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = 0.f;
         int p = slice;
-        for (; p + 12 < P; p += 16) {
-            s0 += in[(size_t)p * K + k];
-            s1 += in[(size_t)(p + 4) * K + k];
-            s2 += in[(size_t)(p + 8) * K + k];
-            s3 += in[(size_t)(p + 12) * K + k];
+        for (; p + 60 < P; p += 64) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = in[(size_t)(p + 4 * u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u] += t[u];
         }
-        for (; p < P; p += 4) s0 += in[(size_t)p * K + k];
-        s = (s0 + s1) + (s2 + s3);
+        if (p < P) {                                                // the last, partial batch: clamped loads, then a select
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = in[(size_t)min(p + 4 * u, P - 1) * K + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u] += p + 4 * u < P ? t[u] : 0.f;
+        }
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) c[u] += c[u + w];
+        s = c[0];
     }
     red[slice][threadIdx.x & 63] = s;
     __syncthreads();
@@ -580,38 +596,70 @@ int bn_bwd_finalize(const float* partials, int ppg, int groups, int CH, double c
 // --------------------------------------------------------------------------- //
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float* __restrict__ stk, BnStats st,
                                                                      float* __restrict__ y, int N, int C, int H, int W,
-                                                                     int OC, int stride, int npg, int relu, int bf16) {
+                                                                     int OC, int stride, int npg, int relu, int bf16, FinSrc src) {
     const int Ho = H / stride, Wo = W / stride;
     const size_t total = (size_t)N * C * Ho * Wo;
     const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
+    const int per = OC / C;                     // 2 (sv|sve pair) or 1 (wopos)
+    float fsc[2] = {0.f, 0.f}, fsh[2] = {0.f, 0.f};
+    if (src.on) {
+        // bn_output finalised HERE (fin_inline.h; the launcher guarantees whole workgroups of ONE output channel and one BatchNorm
+        // group): wave t sums the partial rows of stacked channel c * per + t; the first workgroup of the channel saves the result
+        MEDT_STATIC_SHARED double fsum[4];
+        const size_t idx0 = (size_t)blockIdx.x * MEDT_THREADS;
+        const int cb = (int)((idx0 / ((size_t)Wo * Ho)) % C);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave < per) {
+            double a, b;
+            fin_wave_sums(reinterpret_cast<const double*>(src.f.partials), src.f.ppg, OC, cb * per + wave, lane, a, b);
+            if (lane == 0) { fsum[2 * wave] = a; fsum[2 * wave + 1] = b; }
+        }
+        // (lane 0 of wave t finishes channel t -- one run of the double arithmetic per workgroup -- and hands scale | shift over)
+        MEDT_STATIC_SHARED float fss[4];
+        if (wave < per && lane == 0) {
+            const int ch = cb * per + wave;
+            const FinVals v = fin_vals(fsum[2 * wave], fsum[2 * wave + 1], src.f.count, src.eps, src.f.weight[ch], src.f.bias[ch]);
+            fss[2 * wave] = v.scale;
+            fss[2 * wave + 1] = v.shift;
+            const bool first = idx0 % ((size_t)Wo * Ho) == 0 && idx0 / ((size_t)Wo * Ho * C) == 0;
+            if (first) fin_save(src, ch, v);
+        }
+        __syncthreads();
+        for (int t = 0; t < per; ++t) { fsc[t] = fss[2 * t]; fsh[t] = fss[2 * t + 1]; }
+    }
     if (idx >= total) return;
     const int wo = (int)(idx % Wo);
     const int ho = (int)((idx / Wo) % Ho);
     const int c  = (int)((idx / ((size_t)Wo * Ho)) % C);
     const int n  = (int)(idx / ((size_t)Wo * Ho * C));
     const int grp = n / npg;
-    const int per = OC / C;                     // 2 (sv|sve pair) or 1 (wopos)
     float acc = 0.f;
     for (int t = 0; t < per; ++t) {
         const int ch = c * per + t;
-        const float sc = st.scale[grp * OC + ch], sh = st.shift[grp * OC + ch];
-        const size_t src = ((size_t)n * OC + ch) * H * W;
+        const float sc = src.on ? fsc[t] : st.scale[grp * OC + ch], sh = src.on ? fsh[t] : st.shift[grp * OC + ch];
+        const size_t srcp = ((size_t)n * OC + ch) * H * W;
         float a = 0.f;
         for (int dh = 0; dh < stride; ++dh)
             for (int dw = 0; dw < stride; ++dw)
-                a += fmaf(sc, ld_act(stk, src + (size_t)(ho * stride + dh) * W + wo * stride + dw, bf16), sh);
+                a += fmaf(sc, ld_act(stk, srcp + (size_t)(ho * stride + dh) * W + wo * stride + dw, bf16), sh);
         acc += a;
     }
     acc *= 1.f / (float)(stride * stride);
     y[idx] = relu ? fmaxf(acc, 0.f) : acc;
 }
 
-int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s) {
+bool axial_out_fwd_inlines(const medt_axial_desc& d) {
+    const int Ho = d.H / d.stride, Wo = d.W / d.stride, OC = d.has_pos ? 2 * d.C : d.C;
+    return d.bn_groups == 1 && (Ho * Wo) % MEDT_THREADS == 0 && OC / d.C <= 2;
+}
+
+int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, float* y, hipStream_t s, const FinSrc* src) {
     const int OC = d.has_pos ? 2 * d.C : d.C;
     const size_t total = (size_t)d.N * d.C * (d.H / d.stride) * (d.W / d.stride);
+    if (src && src->on && !axial_out_fwd_inlines(d)) { set_error("axial_out_fwd: shape cannot finalise bn_output in the kernel"); return MEDT_EINVAL; }
     hipLaunchKernelGGL(axial_out_fwd_kernel, dim3((unsigned)((total + MEDT_THREADS - 1) / MEDT_THREADS)),
                        dim3(MEDT_THREADS), 0, s, stacked, st, y, d.N, d.C, d.H, d.W, OC, d.stride, d.N / d.bn_groups,
-                       d.out_relu, d.act_dtype);
+                       d.out_relu, d.act_dtype, src ? *src : no_fin_src());
     return launch_status("axial_out_fwd");
 }
 
