@@ -699,6 +699,7 @@ struct FixArgs {
     GatePtrs gates;
     float *dqkv, *part_qb;
     int fparts, qb_rpg, qb_row0, apply;
+    SimBSrc sb;                    // on: bn_similarity's backward coefficients are derived here from the sweep's partial rows (fin_inline.h)
 };
 
 constexpr int FIX_PPT = 4;
@@ -713,6 +714,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
     float v[4 * HQ];
 #pragma unroll
     for (int k = 0; k < 4 * HQ; ++k) v[k] = 0.f;
+    // bn_similarity's backward coefficients (e, u, w) of the head's three channels: finalised HERE from the sweep's partial rows
+    // (fin_inline.h: no sim_bwd_finalize launch between the sweep and this kernel; the head's first workgroup writes them for the
+    // relfix kernel behind, and bn_similarity's parameter gradients), or read where the finalisation kernel left them
+    float scf[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (a.sb.on) {
+        sim_coef_inline(a.sb, hg, (int)(threadIdx.x & 63), blockIdx.x == 0 && threadIdx.x < 64, scf);
+    } else if (a.apply) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) scf[x][k] = a.sim_coef[((size_t)grp * g.SC + x * g.G + hg) * 3 + k];
+    }
     // FIX_PPT positions per thread (a thread's positions are 256 apart: every load instruction stays coalesced, four
     // independent chains of loads are in flight per lane)
 #pragma unroll
@@ -733,11 +746,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
         }
         if (a.apply) {
             const float f_qr = gate(a.gates.f_qr), f_kr = gate(a.gates.f_kr);
-            const float* cq = a.sim_coef + ((size_t)grp * g.SC + hg) * 3;
-            const float* cr = a.sim_coef + ((size_t)grp * g.SC + g.G + hg) * 3;
-            const float* ck = a.sim_coef + ((size_t)grp * g.SC + 2 * g.G + hg) * 3;
-            const float u_qk = cq[1], w_qk = cq[2];
-            const float u_qr = f_qr * f_qr * cr[1], w_qr = f_qr * cr[2], u_kr = f_kr * f_kr * ck[1], w_kr = f_kr * ck[2];
+            const float u_qk = scf[0][1], w_qk = scf[0][2];
+            const float u_qr = f_qr * f_qr * scf[1][1], w_qr = f_qr * scf[1][2], u_kr = f_kr * f_kr * scf[2][1], w_kr = f_kr * scf[2][2];
             const float* gr = a.gram + ((size_t)(n * g.Bo + sq) * g.G + hg) * NPG;      // Gq pairs | Sq | Gk pairs | Sk
             const float* tQ = a.tables + (size_t)i * NR;                             // U_c | T pairs (x2 off the diagonal)
             const float* tK = a.tables + (size_t)(g.L + i) * NR;
@@ -796,6 +806,25 @@ __device__ __forceinline__ void relfix_body(const RelfixArgs& a, const int blk, 
     const int L = g.L, TL = 2 * L - 1;
     const int grp = blk / g.G, hg = blk - grp * g.G;
     const size_t blk0 = (size_t)hg * a.sweep_gridx + (size_t)grp * a.nparts;
+    if (a.qb_on) {
+        // rider: bn_qkv's backward coefficients and parameter gradients of this head's channels (one BatchNorm group), one wave per
+        // channel -- the arithmetic of bn_bwd_finalize_body (pointwise.hip); no launch of its own between the fix kernel and the 1x1
+        // backward-data kernel
+        const BfinJob& j = a.qb;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int c = wave; c < a.qb_nch; c += MEDT_RT / 64) {
+            const int ch = hg * a.qb_nch + c;
+            double s1, s2;
+            fin_wave_sums(j.partials, j.ppg, j.CH, ch, lane, s1, s2);
+            s1 *= j.dscale;
+            s2 *= j.dscale;
+            if (lane == 0) {
+                bn_bwd_coef(s1, s2, j.count, j.dscale, j.st.mean[ch], j.st.rstd[ch], j.weight[ch], j.training, j.coef + (size_t)ch * 3);
+                if (j.dweight) j.dweight[ch] = (float)s2;
+                if (j.dbias) j.dbias[ch] = (float)s1;
+            }
+        }
+    }
     {   // per-position Gram sums of this (group, head): slice q sums the parts [q * per, (q + 1) * per), eight loads in
         // flight, then the slices are added in fixed order
         const int slice = threadIdx.x / MEDT_THREADS, t0 = threadIdx.x - slice * MEDT_THREADS;
@@ -893,20 +922,6 @@ __global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_kernel(RelfixA
     extern __shared__ float pgs[];
     MEDT_STATIC_SHARED double gred[RELFIX_THREADS / 64][4];
     relfix_body<HQ>(a, blockIdx.x, pgs, gred);
-}
-
-// the recorded relfix jobs of many layers in one launch (defer.h)
-using RelfixBatch = JobBatch<RelfixJob, 16>;
-static_assert(sizeof(RelfixBatch) <= 4000, "job table must fit the kernel-argument block");
-__global__ __launch_bounds__(RELFIX_THREADS) void attn_bwd_relfix_grouped_kernel(RelfixBatch b) {
-    extern __shared__ float pgs[];
-    MEDT_STATIC_SHARED double gred[RELFIX_THREADS / 64][4];
-    const int j = find_job(b, blockIdx.x);
-    const RelfixJob& a = b.job[j];
-    if (a.hq == 1) relfix_body<1>(a, blockIdx.x - b.start[j], pgs, gred);
-    else if (a.hq == 2) relfix_body<2>(a, blockIdx.x - b.start[j], pgs, gred);
-    else if (a.hq == 4) relfix_body<4>(a, blockIdx.x - b.start[j], pgs, gred);
-    else relfix_body<8>(a, blockIdx.x - b.start[j], pgs, gred);
 }
 
 __global__ __launch_bounds__(MEDT_THREADS) void bwd_tables_kernel(const float* __restrict__ relative, float* __restrict__ tables,
@@ -1026,8 +1041,9 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
 
 int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
                        const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,
-                       int qb_rpg, hipStream_t s) {
+                       int qb_rpg, hipStream_t s, const SimBSrc* sb) {
     FixArgs a;
+    a.sb = sb ? *sb : no_simb_src();
     a.g = g; a.qkv_raw = qkv_raw; a.sim_coef = sim_coef; a.tables = tables; a.gram = gram; a.qs = qkv; a.gates = gates;
     a.dqkv = dqkv; a.part_qb = part_qb; a.fparts = p.fparts; a.qb_rpg = qb_rpg; a.qb_row0 = p.nparts; a.apply = apply;
     const dim3 grid(g.groups * p.fparts, g.G), block(MEDT_THREADS);
@@ -1040,44 +1056,22 @@ int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_
 
 int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* relative, const float* sim_coef, BnStats sim,
                           GatePtrs gates, const float* pg_part, const float* gate_raw, int training, float eps,
-                          float* rel_rows, float* gate_rows, hipStream_t s, Queue* q) {
+                          float* rel_rows, float* gate_rows, hipStream_t s, const BfinSrc* qb) {
     RelfixArgs a;
+    a.qb = qb ? qb->j : BfinJob{};
+    a.qb_on = qb ? qb->on : 0;
+    a.qb_nch = 4 * g.hq;
     a.relative = relative; a.sim_coef = sim_coef; a.pg_part = pg_part; a.gate_raw = gate_raw; a.ss = sim;
     a.gates = gates; a.rel_rows = rel_rows; a.gate_rows = gate_raw ? gate_rows : nullptr; a.nparts = p.nparts;
     a.sweep_gridx = g.groups * p.nparts; a.training = training; a.eps = eps;
     a.L = g.L; a.G = g.G; a.SC = g.SC; a.hq = g.hq; a.sim_count = g.sim_count; a.blocks = g.groups * g.G;
     a.lds = (unsigned)((size_t)RELFIX_SLICES * g.L * p.npg_floats * sizeof(float));
-    // only the (recorded) row reductions read what this writes: with a queue bound it leaves the layer chain
-    // (measured on the MedT step: recording it lengthens the flush tail by more than it shortens the chain, 2.422 vs
-    //  2.412 ms -- on the chain it runs under the other branch's kernels -- so it is off unless MEDT_DEFER_RELFIX=1)
-    static const bool defer_on = [] { const char* e = getenv("MEDT_DEFER_RELFIX"); return e && e[0] == '1'; }();
-    if (q && defer_on) { q->relfix.push_back(a); return MEDT_OK; }
     const dim3 grid(a.blocks), block(RELFIX_THREADS);
     if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_relfix_kernel<1>), grid, block, a.lds, s, a);
     else if (g.hq == 2) hipLaunchKernelGGL((attn_bwd_relfix_kernel<2>), grid, block, a.lds, s, a);
     else if (g.hq == 4) hipLaunchKernelGGL((attn_bwd_relfix_kernel<4>), grid, block, a.lds, s, a);
     else hipLaunchKernelGGL((attn_bwd_relfix_kernel<8>), grid, block, a.lds, s, a);
     return launch_status("attn_bwd_relfix_kernel");
-}
-
-int axial_attn_bwd_relfix_grouped(const RelfixJob* jobs, int n, hipStream_t s) {
-    for (int i0 = 0; i0 < n; i0 += 16) {
-        RelfixBatch b;
-        b.n = n - i0 < 16 ? n - i0 : 16;
-        int blocks = 0;
-        unsigned lds = 0;
-        for (int i = 0; i < b.n; ++i) {
-            b.job[i] = jobs[i0 + i];
-            b.start[i] = blocks;
-            blocks += jobs[i0 + i].blocks;
-            if (jobs[i0 + i].lds > lds) lds = jobs[i0 + i].lds;
-        }
-        b.start[b.n] = blocks;
-        hipLaunchKernelGGL(attn_bwd_relfix_grouped_kernel, dim3(blocks), dim3(RELFIX_THREADS), lds, s, b);
-        int rc = launch_status("attn_bwd_relfix_grouped");
-        if (rc) return rc;
-    }
-    return MEDT_OK;
 }
 
 }  // namespace medt

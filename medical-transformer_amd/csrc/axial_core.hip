@@ -456,22 +456,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_stats_kernel(
     block_sum<4>(acc, S.red, partials + ((size_t)blockIdx.x * g.G + hg) * 4);
 }
 
-// bn_similarity backward finalisation: coef[grp][SC][3] = (e, u, w) with dS_x = e*dZ + u*S_x + w
-__device__ __forceinline__ void sim_coef(double a0, double sxh, double count, double mean, double rstd, double w,
-                                         int training, float* cf) {
-    const double e = w * rstd;
-    cf[0] = (float)e;
-    if (training) {
-        const double m1 = a0 / count, m2 = sxh / count;
-        const double u = -e * rstd * m2;
-        cf[1] = (float)u;
-        cf[2] = (float)(-e * m1 - u * mean);
-    } else {
-        cf[1] = 0.f;
-        cf[2] = 0.f;
-    }
-}
-
+// (sim_coef -- coef[grp][SC][3] = (e, u, w) with dS_x = e*dZ + u*S_x + w: fin_inline.h)
 __global__ __launch_bounds__(64) void sim_bwd_finalize_kernel(const float* __restrict__ partials, int tpg, int groups,
                                                               int G, int SC, double count, BnStats ss,
                                                               const float* __restrict__ weight, int training,

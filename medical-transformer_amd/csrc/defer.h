@@ -58,7 +58,7 @@ struct MJob {                        // conv_wgrad_mfma: the dedicated MFMA weig
     int N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits, npg;
 };
 
-struct RelfixJob {                   // attn_bwd_relfix (axial_bwd.hip): u / w terms of one layer's relative-table and gate gradients
+struct RelfixJob {                   // attn_bwd_relfix (axial_bwd.hip) kernel arguments: u / w terms of one layer's relative-table and gate gradients
     const float *relative, *sim_coef, *pg_part, *gate_raw;
     BnStats ss;
     GatePtrs gates;
@@ -67,10 +67,13 @@ struct RelfixJob {                   // attn_bwd_relfix (axial_bwd.hip): u / w t
     int L, G, SC, hq, nparts, sweep_gridx, training, blocks;
     unsigned lds;
     float eps;
+    // rider (round 6, fin_inline.h): bn_qkv's backward finalisation of this head's channels -- the kernel sits between the fix
+    // kernel that completes the partial rows and the 1x1 backward-data / weight-gradient kernels that apply the coefficients
+    BfinJob qb;
+    int qb_on, qb_nch;
 };
 
 struct Queue {
-    std::vector<RelfixJob> relfix;
     std::vector<FinJob> fin;
     std::vector<BfinJob> bfin;
     std::vector<SmallFinArgs> sfin;
@@ -80,7 +83,7 @@ struct Queue {
     std::vector<RJob> reduce;
     std::vector<FlipJob> flip;
     size_t pending() const {
-        return flip.size() + relfix.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + mwgrad.size() + reduce.size();
+        return flip.size() + fin.size() + bfin.size() + sfin.size() + csum.size() + wgrad.size() + mwgrad.size() + reduce.size();
     }
 };
 
@@ -94,7 +97,6 @@ int bn_bwd_finalize_grouped(const BfinJob* jobs, int n, hipStream_t s);
 int wopos_small_bwd_finalize_grouped(const SmallFinArgs* jobs, int n, hipStream_t s);
 int reduce_rows_grouped(const RJob* jobs, int n, hipStream_t s);
 int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s);
-int axial_attn_bwd_relfix_grouped(const RelfixJob* jobs, int n, hipStream_t s);
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);            // MFMA tiles (conv_mfma.hip)
 bool conv_wgrad_v4_ok(const float* dy, const float* raw, const float* x, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
                       int K, int stride, int pad);

@@ -88,7 +88,6 @@ static int queue_flush(Queue& q, hipStream_t s, hipStream_t aux) {
     // order: statistics bookkeeping; first-stage sums and weight gradients; then the reductions of their partial slabs
     for (const FlipJob& f : q.flip)
         if (!rc) rc = conv_flip_weights(f.w, f.wt, f.Cout, f.Cin, f.K, s);
-    if (!rc && !q.relfix.empty()) rc = axial_attn_bwd_relfix_grouped(q.relfix.data(), (int)q.relfix.size(), s);
     if (!rc && !q.fin.empty()) rc = bn_finalize_grouped(q.fin.data(), (int)q.fin.size(), s);
     if (!rc && !q.bfin.empty()) rc = bn_bwd_finalize_grouped(q.bfin.data(), (int)q.bfin.size(), s);
     if (!rc && !q.sfin.empty()) rc = wopos_small_bwd_finalize_grouped(q.sfin.data(), (int)q.sfin.size(), s);
@@ -101,7 +100,7 @@ static int queue_flush(Queue& q, hipStream_t s, hipStream_t aux) {
         if (!rc && !rest.empty()) rc = conv_wgrad_mfma_batch(rest.data(), (int)rest.size(), s);
     }
     if (!rc && !q.reduce.empty()) rc = reduce_rows_grouped(q.reduce.data(), (int)q.reduce.size(), s);
-    q.flip.clear(); q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
+    q.flip.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
     return rc == -1000 ? MEDT_OK : rc;
 }
 
@@ -118,7 +117,7 @@ int medt_queue_flush2(void* qv, void* stream, void* aux_stream) {
 int medt_queue_discard(void* qv) {
     if (!qv) { set_error("queue discard: null queue"); return MEDT_EINVAL; }
     Queue& q = *(Queue*)qv;
-    q.flip.clear(); q.relfix.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
+    q.flip.clear(); q.fin.clear(); q.bfin.clear(); q.sfin.clear(); q.csum.clear(); q.wgrad.clear(); q.mwgrad.clear(); q.reduce.clear();
     return MEDT_OK;
 }
 

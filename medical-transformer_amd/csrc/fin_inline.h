@@ -132,4 +132,67 @@ __device__ __forceinline__ void fin_wave_sums(const T* partials, int rows, int C
     s1 = fin_wave_sum_d(b);
 }
 
+// ---- bn_similarity backward (axial_core.hip: sim_bwd_finalize_kernel) --------------------------------------------------------------
+// coef[SC][3] = (e, u, w) with dS_x = e * dZ + u * S_x + w
+__device__ __forceinline__ void sim_coef(double a0, double sxh, double count, double mean, double rstd, double w,
+                                         int training, float* cf) {
+    const double e = w * rstd;
+    cf[0] = (float)e;
+    if (training) {
+        const double m1 = a0 / count, m2 = sxh / count;
+        const double u = -e * rstd * m2;
+        cf[1] = (float)u;
+        cf[2] = (float)(-e * m1 - u * mean);
+    } else {
+        cf[1] = 0.f;
+        cf[2] = 0.f;
+    }
+}
+
+struct SimBSrc {                     // partial rows [rows][G][4] FLOATS = sum dZ * {1, S_qk, S_qr, S_kr} (one BatchNorm group)
+    const float* partials;
+    int rows, G, SC, training, on;
+    double count;
+    BnStats ss;
+    const float* weight;
+    float *coef, *dweight, *dbias;
+};
+inline SimBSrc no_simb_src() { SimBSrc s{}; s.on = 0; return s; }
+
+__device__ __forceinline__ double fin_bcast_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// The three channels (qk, qr, kr) of head hg, by every wave that calls it: slot v = (lane >> 3) & 3 sums value v of the partial rows,
+// slots 1..3 run the double arithmetic of their channel, cf[x][0..2] is broadcast to all lanes.  `writer`: this wave also writes the
+// coefficients (the relfix kernel behind reads them) and bn_similarity's parameter gradients.
+__device__ __forceinline__ void sim_coef_inline(const SimBSrc& s, int hg, int lane, bool writer, float (&cf)[3][3]) {
+    const int slot = lane >> 3, sub = lane & 7, vi = slot & 3;
+    double a = 0.0;
+    for (int r0 = sub; r0 < s.rows; r0 += 64) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = s.partials[((size_t)min(r0 + 8 * u, s.rows - 1) * s.G + hg) * 4 + vi];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + 8 * u < s.rows) a += (double)t[u];
+    }
+    a = fin_sum8(a);
+    const double a0 = fin_bcast_d(a, 0);
+    const int x = vi > 0 ? vi - 1 : 0, ch = x * s.G + hg;
+    const double mean = s.ss.mean[ch], rstd = s.ss.rstd[ch];
+    const double sxh = rstd * (a - mean * a0);                // sum dZ * xhat
+    float c3[3];
+    sim_coef(a0, sxh, s.count, mean, rstd, s.weight[ch], s.training, c3);
+    if (writer && sub == 0 && slot >= 1 && slot <= 3) {
+        s.coef[(size_t)ch * 3] = c3[0]; s.coef[(size_t)ch * 3 + 1] = c3[1]; s.coef[(size_t)ch * 3 + 2] = c3[2];
+        s.dweight[ch] = (float)sxh;
+        s.dbias[ch] = (float)a0;
+    }
+#pragma unroll
+    for (int xx = 0; xx < 3; ++xx)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cf[xx][k] = fin_bcast(c3[k], 8 * (xx + 1));
+}
+
 }  // namespace medt

@@ -134,8 +134,8 @@ struct BwdWs {
 // axial_bwd.hip, or the two generic L x L passes of axial_core.hip.
 static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, const medt_axial_params* p, const BwdWs& w,
                               const float* qkv_raw, const float* stacked, const float* lse, const float* dy, const LayerStats& st,
-                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s, Queue* q,
-                              const BfinSrc* ob = nullptr) {
+                              GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s,
+                              const BfinSrc* ob = nullptr, bool sim_inline = false, const BfinSrc* qb = nullptr) {
     const int tr = d->training ? 1 : 0;
     int rc;
     if (w.sweep) {
@@ -144,15 +144,24 @@ static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, cons
                                        want_gates ? w.gate_raw : nullptr, s, w.raw32, ob))) return rc;
         AxialGeom gs = g;
         gs.tpg = w.plan.nparts;                               // part_sb rows per group
-        // (+ the sliding-window table sums of the fix kernel as extra blocks of this launch)
-        const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
-        if ((rc = axial_sim_bwd_finalize(gs, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, d_sim_w, d_sim_b, s, &tj)))
-            return rc;
+        SimBSrc sb = no_simb_src();
+        if (sim_inline) {
+            // (round 6, fin_inline.h: the fix kernel derives bn_similarity's backward coefficients from the sweep's partial rows and
+            //  writes them for the relfix kernel; the tables were built by the first workgroups of axial_out_bwd_stats)
+            sb.partials = w.part_sb; sb.rows = w.plan.nparts; sb.G = g.G; sb.SC = g.SC; sb.training = tr; sb.on = 1;
+            sb.count = g.sim_count; sb.ss = st.sim; sb.weight = p->bn_similarity.weight;
+            sb.coef = w.coef_sim; sb.dweight = d_sim_w; sb.dbias = d_sim_b;
+        } else {
+            // (+ the sliding-window table sums of the fix kernel as extra blocks of this launch)
+            const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
+            if ((rc = axial_sim_bwd_finalize(gs, w.part_sb, st.sim, p->bn_similarity.weight, tr, w.coef_sim, d_sim_w, d_sim_b, s, &tj)))
+                return rc;
+        }
         if ((rc = axial_attn_bwd_fix(g, w.plan, qkv_raw, st.qkv, w.coef_sim, w.tables, w.gram, gates, tr, w.dqkv, w.part_qb,
-                                     w.qb_rpg, s))) return rc;
+                                     w.qb_rpg, s, sim_inline ? &sb : nullptr))) return rc;
         return axial_attn_bwd_relfix(g, w.plan, p->relative, w.coef_sim, st.sim, gates, w.pg_part,
                                      want_gates ? w.gate_raw : nullptr, tr, d->eps,
-                                     w.rel_part + w.sweep_blocks * 2 * g.gp * (2 * g.L - 1), w.gate_rows, s, q);
+                                     w.rel_part + w.sweep_blocks * 2 * g.gp * (2 * g.L - 1), w.gate_rows, s, qb);
     }
     // bn_similarity backward statistics (pass A), coefficients, attention backward (pass B)
     if ((rc = axial_attn_bwd_stats(g, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out, d->stride,
@@ -272,7 +281,7 @@ int medt_axial_core_bwd(const medt_axial_desc* d, const medt_axial_params* p, co
     // generic L x L passes; coef_out is whatever the preceding medt_axial_layer_bwd left in the workspace, bn_similarity's
     // parameter gradients land in scratch (part_ob is dead by then)
     return attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, p->f_qr != nullptr, w.part_ob,
-                              w.part_ob + g.SC, s, nullptr);
+                              w.part_ob + g.SC, s);
 }
 
 int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, const float* x, float* y,
@@ -386,7 +395,11 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
     const float out_dscale = 1.f / (float)(d->stride * d->stride);
-    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s))) return rc;
+    // (round 6: where the fix kernel finalises bn_similarity's backward itself, the tables it reads ride on this launch)
+    const bool sim_inl = w.sweep && g.pos && inline_fin_ok(tr, g.groups, w.plan.nparts) &&
+                         axial_out_bwd_stats_tables_ok(*d, sim_tables_blocks(g), g.L);
+    const TablesJob btj{p->relative, w.tables, g.hq, g.L, sim_tables_blocks(g)};
+    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s, sim_inl ? &btj : nullptr))) return rc;
     // (round 6, fin_inline.h: where the single sweep runs inside the networks, IT derives bn_output's backward coefficients from the
     //  partial rows and its first workgroup per head writes them and the parameter gradients -- no bn_bwd_finalize launch)
     BfinSrc ob = no_bfin_src();
@@ -397,11 +410,17 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     } else if ((rc = bn_bwd_finalize(w.part_ob, ppg, g.groups, g.OC, g.row_count, out_dscale, st.out, p->bn_output.weight, tr,
                                      w.coef_out, gr->bn_out_weight, gr->bn_out_bias, s))) return rc;
     // softmax / bn_similarity / logits backward: dqkv, the partial rows of bn_qkv's backward, of the tables and of the gates
-    // (sigmoid gates: the gate reduction + sigmoid backward below run immediately and read what the relfix kernel writes,
-    //  so that kernel must not be recorded for the flush -- MEDT_DEFER_RELFIX=1 -- in that mode)
-    Queue* relfix_q = (d->gate_mode == 1 && p->f_qr && gr->gates) ? nullptr : queue_for(s);
+    // (round 6, fin_inline.h: where the single sweep runs inside the networks, bn_qkv's backward finalisation rides on the relfix
+    //  launch -- one workgroup per head, between the fix kernel that completes the partial rows and the 1x1 kernels that apply the
+    //  coefficients -- except with bf16 storage without the widened copy, where finalisation and application are one launch)
+    BfinSrc qb = no_bfin_src();
+    if (w.sweep && (!g.bf16 || w.raw32) && inline_fin_ok(tr, g.groups, w.qb_rpg)) {
+        qb.j = BfinJob{w.part_qb, w.qb_rpg, g.groups, 2 * g.C, tr, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, w.coef_qkv,
+                       gr->bn_qkv_weight, gr->bn_qkv_bias};
+        qb.on = 1;
+    }
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
-                                 gr->bn_sim_weight, gr->bn_sim_bias, s, relfix_q, ob.on ? &ob : nullptr))) return rc;
+                                 gr->bn_sim_weight, gr->bn_sim_bias, s, ob.on ? &ob : nullptr, sim_inl, qb.on ? &qb : nullptr))) return rc;
     // bn_qkv backward, qkv_transform backward
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
     static const bool bf16_fused = [] { const char* e = getenv("MEDT_BF16_FIN_APPLY"); return !(e && e[0] == '0'); }();
@@ -409,8 +428,8 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         // bf16 storage, round 5: the sweep has left qkv_raw widened to float32 in the workspace (one extra store per element of a
         // VALU-bound kernel): bn_qkv's backward is then applied on load by the 1x1 dgrad / wgrad exactly as with fp32 storage --
         // no extra launch, no extra pass over dqkv (gatedaxialunet bs 8: bf16 was 4-6 % slower than fp32 with the separate pass)
-        if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
-                                  w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
+        if (!qb.on && (rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
+                                         w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
         bq_raw = w.raw32;
     } else if (g.bf16 && bf16_fused && (long)g.N * 2 * g.C <= 65535) {
         // bf16 storage: the finalisation and the bn_qkv backward materialised in fp32 in ONE launch, then the plain 1x1 dgrad / wgrad
@@ -419,8 +438,8 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         bq_raw = nullptr;
         bq_coef = nullptr;
     } else {
-        if ((rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
-                                  w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
+        if (!qb.on && (rc = bn_bwd_finalize(w.part_qb, w.qb_rpg, g.groups, 2 * g.C, g.row_count, 1.f, st.qkv, p->bn_qkv.weight, tr,
+                                            w.coef_qkv, gr->bn_qkv_weight, gr->bn_qkv_bias, s))) return rc;
         if (g.bf16) {   // (MEDT_BF16_FIN_APPLY=0: round 4's two launches)
             if ((rc = bn_bwd_apply_raw_bf16(w.dqkv, qkv_raw, w.coef_qkv, g.N, 2 * g.C, g.HW, g.groups, s))) return rc;
             bq_raw = nullptr;

@@ -44,8 +44,11 @@ int bn_bwd_fin_apply_bf16(const float* partials, int ppg, int groups, int CH, do
                           const float* weight, int training, float* coef, float* dweight, float* dbias, float* d,
                           const float* raw_bf16, int N, int HW, hipStream_t s);
 // partials [n][ptile][OC][2] of [sum dstk, sum dstk*xhat] with dstk = dy (un-pooled, unscaled)
+// tj (optional): the launch's first tj->blocks workgroups also build the sliding-window tables of the layer's relative table (what
+// sim_bwd_finalize's appended blocks build otherwise -- axial_out_bwd_stats_tables_ok() says whether the grid has room)
+bool axial_out_bwd_stats_tables_ok(const medt_axial_desc& d, int blocks, int L);
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st,
-                        float* partials, hipStream_t s);
+                        float* partials, hipStream_t s, const TablesJob* tj = nullptr);
 
 // out[k] = sum_p in[p][k]
 int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
@@ -275,10 +278,11 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
 // u / w terms of dq | dk (apply != 0: training mode) and the bn_qkv partial rows [nparts, nparts + fparts) (q | k channels)
 int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
                        const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,
-                       int qb_rpg, hipStream_t s);
+                       int qb_rpg, hipStream_t s, const struct SimBSrc* sb = nullptr);   // sb (fin_inline.h): sim_coef derived in the kernel
 // u / w terms of the table gradients -> rel_rows [groups * G][2gp * TL]; gate gradients -> gate_rows [groups * G][4]
 int axial_attn_bwd_relfix(const AxialGeom& g, const SweepPlan& p, const float* relative, const float* sim_coef, BnStats sim,
                           GatePtrs gates, const float* pg_part, const float* gate_raw, int training, float eps,
-                          float* rel_rows, float* gate_rows, hipStream_t s, Queue* q);
+                          float* rel_rows, float* gate_rows, hipStream_t s, const BfinSrc* qb = nullptr);
+// qb (fin_inline.h, one BatchNorm group): the launch also finalises bn_qkv's backward (coefficients + parameter gradients), head by head
 
 }  // namespace medt

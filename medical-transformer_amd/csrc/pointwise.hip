@@ -668,8 +668,12 @@ int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, fl
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const float* __restrict__ stk,
                                                                            const float* __restrict__ dy, BnStats st,
                                                                            float* __restrict__ partials, int C, int H,
-                                                                           int W, int OC, int stride, int npg, int bf16) {
+                                                                           int W, int OC, int stride, int npg, int bf16, TablesJob tj) {
     MEDT_STATIC_SHARED float red[MEDT_WAVES * 2];
+    if (blockIdx.y == 0 && (int)blockIdx.x < tj.blocks) {        // (fin_inline.h: the fix kernel's tables, no launch of their own)
+        MEDT_STATIC_SHARED float tl[512];
+        sim_tables_block(blockIdx.x, tj.relative, tj.tables, tj.HQ, tj.L, tl);
+    }
     const int HW = H * W, Ho = H / stride, Wo = W / stride;
     const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, ch = blockIdx.y;
@@ -690,12 +694,18 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
     block_sum<2>(v, red, partials + ((size_t)blockIdx.x * OC + ch) * 2);
 }
 
+bool axial_out_bwd_stats_tables_ok(const medt_axial_desc& d, int blocks, int L) {
+    return blocks <= d.bn_groups * cdiv((d.N / d.bn_groups) * d.H * d.W, MEDT_THREADS) && L <= 128;
+}
+
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, float* partials,
-                        hipStream_t s) {
+                        hipStream_t s, const TablesJob* tjp) {
     const int OC = d.has_pos ? 2 * d.C : d.C;
     const int npg = d.N / d.bn_groups, ppg = cdiv(npg * d.H * d.W, MEDT_THREADS);
+    const TablesJob tj = tjp ? *tjp : TablesJob{nullptr, nullptr, 0, 0, 0};
+    if (tj.blocks && !axial_out_bwd_stats_tables_ok(d, tj.blocks, tj.L)) { set_error("axial_out_bwd_stats: no room for the table blocks"); return MEDT_EINVAL; }
     hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(d.bn_groups * ppg, OC), dim3(MEDT_THREADS), 0, s, stacked, dy, st,
-                       partials, d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype);
+                       partials, d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype, tj);
     return launch_status("axial_out_bwd_stats");
 }
 
