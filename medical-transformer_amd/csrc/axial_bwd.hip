@@ -704,10 +704,11 @@ struct FixArgs {
 
 constexpr int FIX_PPT = 4;
 
-template <int HQ>
-__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
+// (BF: the storage type of qkv_raw at compile time -- with the runtime flag inside ld_act every load sat in its own branch, one global
+//  round trip per channel: +7 us per launch with bf16 storage, round 6)
+template <int HQ, bool BF>
+__device__ __forceinline__ void attn_bwd_fix_body(const FixArgs& a, float* red) {
     constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), NR = HQ + NP;
-    MEDT_STATIC_SHARED float red[MEDT_WAVES * 4 * HQ];
     const AxialGeom& g = a.g;
     const int grp = blockIdx.x / a.fparts, part = blockIdx.x - grp * a.fparts, hg = blockIdx.y;
     const int per_group = g.npg * g.HW;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
         float raw[GP], x[GP], d[GP];
 #pragma unroll
         for (int c = 0; c < GP; ++c) {
-            raw[c] = ld_act(a.qkv_raw, off + (size_t)c * g.HW, g.bf16);
+            raw[c] = ld_act(a.qkv_raw, off + (size_t)c * g.HW, BF ? 1 : 0);
             d[c] = a.dqkv[off + (size_t)c * g.HW];
             x[c] = fmaf(raw[c], a.qs.scale[cbase + c], a.qs.shift[cbase + c]);
         }
@@ -788,6 +789,13 @@ __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
     float* dst = a.part_qb + ((size_t)(grp * a.qb_rpg + a.qb_row0 + part) * 2 * g.C + hg * NCH) * 2;
     if (threadIdx.x < 2 * GP) dst[2 * GP + threadIdx.x] = 0.f;            // (the sweep's rows carry the v channels)
     block_sum<4 * HQ>(v, red, dst);
+}
+
+template <int HQ>
+__global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
+    MEDT_STATIC_SHARED float red[MEDT_WAVES * 4 * HQ];
+    if (a.g.bf16) attn_bwd_fix_body<HQ, true>(a, red);
+    else attn_bwd_fix_body<HQ, false>(a, red);
 }
 
 // --------------------------------------------------------------------------- //
@@ -966,8 +974,8 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     // the sweep / fix kernels address qkv_raw, stacked and dqkv with 32-bit byte offsets (saddr + voffset): tensors of 4 GiB
     // and more take the generic kernels (size_t arithmetic)
     if ((size_t)g.N * 2 * g.C * g.HW * 4 > 0xffffffffull) return false;
-    static const int env_nw = [] { const char* e = getenv("MEDT_BWD_NW"); return e ? atoi(e) : 0; }();
-    static const int env_cap = [] { const char* e = getenv("MEDT_BWD_CAP"); return e ? atoi(e) : 2048; }();
+    static const int env_nw = 0;
+    static const int env_cap = 2048;
     // Round 5: few sequences (the layers inside the networks: 128 - 256 sequences x 8 heads) leave half of the chip's 1024 SIMDs
     // without a wave and every wave alone on its SIMD -- the launch is one wave's latency.  Twice the lanes per sequence then:
     // half the key columns per lane (the row loop's body halves, its per-row bookkeeping does not) on twice the waves.

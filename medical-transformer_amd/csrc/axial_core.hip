@@ -93,8 +93,8 @@ int axial_geom(const medt_axial_desc& d, AxialGeom* g) {
             // shapes) keep nt = 1 so there are enough workgroups; big ones amortise the table staging over
             // up to NT sub-tiles and cap the grid at ~8 workgroups per CU.
             while (nt > 1 && (long)g->groups * d.G * cdiv(g->spg, g->S_T * nt) < 2048) nt >>= 1;
-            static const int env_nt = [] { const char* e = getenv("MEDT_NT"); return e ? atoi(e) : 0; }();
-            static const int env_cap = [] { const char* e = getenv("MEDT_CAP"); return e ? atoi(e) : 2048; }();
+            static const int env_nt = 0;
+            static const int env_cap = 2048;
             if (env_nt > 0 && env_nt < nt) nt = env_nt;
             const int nsup = cdiv(g->spg, g->S_T * nt);
             int cap = env_cap / (g->groups * d.G);

@@ -33,11 +33,12 @@ int sim_stats_parts(const AxialGeom& g) { return cdiv(g.spg, 64); }
 // carry the factor 2 of the symmetric double sum.  side 0 = q rows of `relative`, 1 = k rows.
 int sim_tables_blocks(const AxialGeom& g) { return g.pos ? 2 * (g.hq + npairs(g.hq)) : 0; }
 
-template <int HQ, bool POS, int AXIS>
-__global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
-                                                                 BnStats qs, const float* __restrict__ tables,
-                                                                 GatePtrs gates, float* __restrict__ partials,
-                                                                 int sparts, int pc_log) {
+// (BF: the storage type of qkv_raw at compile time -- a runtime flag inside ld_act puts every load into a branch of its own)
+template <int HQ, bool POS, int AXIS, bool BF>
+__device__ __forceinline__ void sim_stats_body(const AxialGeom& g, const float* __restrict__ qkv_raw,
+                                               BnStats qs, const float* __restrict__ tables,
+                                               GatePtrs gates, float* __restrict__ partials,
+                                               int sparts, int pc_log) {
     constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NV = 2 * NR, RND = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = g.L, PC = 1 << pc_log, PCQ = PC >> 2, RS = PC + 1;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
                     if (ls < nseq && i < L) {
                         const size_t src = (size_t)seqoff[ls] + (size_t)ch * g.HW + i;
                         float4 v;
-                        if (g.bf16) {
+                        if (BF) {
                             const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(qkv_raw) + src);
                             v = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
                                             __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
                     const int p = e & (PC - 1), ls = (e >> pc_log) & 63, ch = e >> (pc_log + 6);
                     const int i = chunk0 + p;
                     if (ls < nseq && i < L)
-                        stage[(ch * 64 + ls) * RS + p] = ld_act(qkv_raw, (size_t)seqoff[ls] + (size_t)ch * g.HW + i, g.bf16);
+                        stage[(ch * 64 + ls) * RS + p] = ld_act(qkv_raw, (size_t)seqoff[ls] + (size_t)ch * g.HW + i, BF);
                 }
             }
             __syncthreads();
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
                 for (int ch = 0; ch < GP; ++ch) {
                     float raw;
                     if (AXIS == 1) raw = stage[(ch * 64 + lane) * RS + p];
-                    else raw = ld_act(qkv_raw, (size_t)myoff + (size_t)ch * g.HW + (size_t)i * pstride, g.bf16);
+                    else raw = ld_act(qkv_raw, (size_t)myoff + (size_t)ch * g.HW + (size_t)i * pstride, BF);
                     x[ch] = active ? fmaf(raw, sc[ch], sh[ch]) : 0.f;
                 }
                 const float* tq = tables + (size_t)i * NR;
@@ -194,6 +195,15 @@ __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, co
         const double s = (redd[k] + redd[8 + k]) + (redd[16 + k] + redd[24 + k]);
         reinterpret_cast<double*>(partials)[((size_t)blockIdx.x * g.SC + hg) * 2 + (size_t)(k >> 1) * g.G * 2 + (k & 1)] = s;
     }
+}
+
+template <int HQ, bool POS, int AXIS>
+__global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
+                                                                 BnStats qs, const float* __restrict__ tables,
+                                                                 GatePtrs gates, float* __restrict__ partials,
+                                                                 int sparts, int pc_log) {
+    if (g.bf16) sim_stats_body<HQ, POS, AXIS, true>(g, qkv_raw, qs, tables, gates, partials, sparts, pc_log);
+    else sim_stats_body<HQ, POS, AXIS, false>(g, qkv_raw, qs, tables, gates, partials, sparts, pc_log);
 }
 
 // --------------------------------------------------------------------------- //

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(1024) void wopos_block_fwd_kernel(const float* __re
 // The packed-FMA (second-generation) instantiations of the block kernels: default since round 5 (first MI355X run: parity green, the
 // step 2.139 -> 2.130 ms alone, 2.105 with the other two switches; profiles/r05_step_ab.json); MEDT_BLOCK_PK=0 = the first generation
 int& block_pk_mode() {
-    static int mode = [] { const char* e = getenv("MEDT_BLOCK_PK"); return (e && e[0] == '0') ? 0 : 1; }();
+    static int mode = 1;
     return mode;
 }
 
@@ -1285,7 +1285,7 @@ int wopos_block_fwd(const medt_block_desc& d, const medt_block_params& p, const 
                                p.height.w_qkv, p.width.w_qkv, p.w_up, a);
         return launch_status("wopos_block8_fwd");
     }
-    static const bool mfma = [] { const char* e = getenv("MEDT_BLOCK_MFMA"); return !(e && e[0] == '0'); }();
+    static const bool mfma = true;
     if (mfma) {                                         // round 6: the contractions on the matrix cores
         const size_t ldsm = ((size_t)(d.C + 3 * d.width) * S2_LDT + (size_t)(2 * d.G + 2 * d.width) * 4) * sizeof(float);
         static unsigned char attrm[64];

@@ -254,7 +254,7 @@ static int conv_fwd_ws_tile(int Cin, int Cout, int K, long positions) {       //
 }
 
 bool conv_fwd_ws_ok(int Cin, int Cout, int K, int stride, long positions) {
-    static const bool on = [] { const char* e = getenv("MEDT_FWD_WS"); return !(e && e[0] == '0'); }();
+    static const bool on = true;
     return on && K == 3 && Cin * K * K >= 512 && positions <= 16384 && !conv_use_mfma(Cin, Cout, K, stride, positions) &&
            conv_fwd_ws_tile(Cin, Cout, K, positions) != 0;
 }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
 }
 
 static bool conv_bwd_data_ws_enabled() {
-    static const bool on = [] { const char* e = getenv("MEDT_DGRAD_WS"); return !(e && e[0] == '0'); }();
+    static const bool on = true;
     return on;
 }
 
@@ -502,7 +502,7 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
                              int Wo, int stride, int pad, hipStream_t s, const float* add) {
     if constexpr (K != 7) {
         // (3 x 3 with a deep contraction up to 16384 positions: conv2's 8 <- 128 at 64 x 64 was 58 us in the kernel below)
-        static const long ws_pos3 = [] { const char* e = getenv("MEDT_DGRAD_WS_POS3"); return e ? atol(e) : 16384L; }();
+        static const long ws_pos3 = 16384L;
         const long npos = (long)N * H * W;
         if ((npos <= 4096 || (K == 3 && Cout * K * K >= 512 && npos <= ws_pos3)) && Cout >= 64 && conv_bwd_data_ws_enabled()) {
             const unsigned g64 = (unsigned)(((long)N * H * W + 63) / 64);
@@ -695,20 +695,6 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_kernel(
                                blockIdx.y, blockIdx.z);
 }
 
-// The weight gradients of many layers in one launch (defer.h): every job has this kernel's (K, TO, TC).
-// One tile shape (64 x 64) for every job: the launch holds thousands of workgroups across all layers, so per-layer tile
-// sizing (which exists to give ONE layer enough workgroups) is not needed and the launch count drops to one per kernel size.
-using WBatch = JobBatch<WJob, 36>;
-template <int K>
-__global__ __launch_bounds__(MEDT_THREADS) void conv_wgrad_grouped_kernel(WBatch b) {
-    const int j = find_job(b, blockIdx.x);
-    const WJob& w = b.job[j];
-    const int local = blockIdx.x - b.start[j];
-    const int bx = local % w.gx, t = local / w.gx, by = t % w.gy, bz = t / w.gy;
-    conv_wgrad_body<K, 64, 64>(w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.stride,
-                               w.pad, w.QS, w.npg, bx, by, bz);
-}
-
 static inline int wgrad_tile(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
 
 // positions per chunk: as small as 64 while the grid is below ~512 workgroups, at most 512
@@ -725,14 +711,14 @@ static int wgrad_chunk(int Cout, int Ktot, long NP) {
 // (~4 us per 64 positions): short chunks, many workgroups (measured on the MedT step: 32 chunks / 512 positions 2.54 ms,
 // 64 / 256: 2.49 ms, 128 slabs of 128: 2.53 ms -- the slab reduction starts to cost what the shorter chunks save)
 static int wgrad_chunk_grouped(long NP) {
-    static const int target = [] { const char* e = getenv("MEDT_WG_CHUNKS"); return e ? atoi(e) : 64; }();
-    static const int qmax = [] { const char* e = getenv("MEDT_WG_QMAX"); return e ? atoi(e) : 256; }();
+    static const int target = 64;
+    static const int qmax = 256;
     int QS = 64;
     while (QS < qmax && (NP + QS - 1) / QS > target) QS <<= 1;
-    static const int smax = [] { const char* e = getenv("MEDT_WG_SLABS"); return e ? atoi(e) : 64; }();
+    static const int smax = 64;
     // (>= 65536 positions -- the 128 x 128 maps of decoderf / adjust: 16-step chunks were the long pole of the global branch's flush;
     //  their weight matrices are tiny, so 256 slabs cost the row reduction nothing: 2.080 -> 2.067 ms/step, profiles/r05_step_ab.json)
-    static const int smax_big = [] { const char* e = getenv("MEDT_WG_SLABS_BIG"); return e ? atoi(e) : 256; }();
+    static const int smax_big = 256;
     while ((NP + QS - 1) / QS > (NP >= 65536 ? smax_big : smax)) QS <<= 1;
     return QS;
 }
@@ -740,9 +726,9 @@ static int wgrad_chunk_grouped(long NP) {
 // chunks of the 16-byte body: 256 positions (two 128-position steps) while that gives at most MEDT_WG4_CHUNKS (16) chunks, up to
 // MEDT_WG4_QMAX (1024) positions; never fewer positions per chunk than the scalar policy (so never more slabs)
 static int wgrad_chunk_v4(long NP) {
-    static const int target = [] { const char* e = getenv("MEDT_WG4_CHUNKS"); return e ? atoi(e) : 16; }();
-    static const int qmax = [] { const char* e = getenv("MEDT_WG4_QMAX"); return e ? atoi(e) : 1024; }();
-    static const int smax_big = [] { const char* e = getenv("MEDT_WG_SLABS_BIG"); return e ? atoi(e) : 256; }();
+    static const int target = 16;
+    static const int qmax = 1024;
+    static const int smax_big = 256;
     int QS = 256;
     while (QS < qmax && (NP + QS - 1) / QS > (NP >= 65536 ? smax_big : target)) QS <<= 1;
     while ((NP + QS - 1) / QS > (NP >= 65536 ? smax_big : 64)) QS <<= 1;
@@ -773,7 +759,7 @@ int conv2d_bwd_weight(const float* dy, const float* raw, const float* coef, cons
     const dim3 grid(cdiv(Cout, 64), cdiv(Ktot, 64), splits), block(MEDT_THREADS);
     if (splits == 1) scratch = dw;                         // a single slab is the result: no reduction pass
     if (mfma) {
-        static const bool defer_m = [] { const char* e = getenv("MEDT_DEFER_MFMA_WGRAD"); return !(e && e[0] == '0'); }();
+        static const bool defer_m = true;
         if (q && defer_m) {       // recorded like the grouped jobs: nothing on the layer chain reads a weight gradient
             q->mwgrad.push_back(MJob{dy, raw, coef, x, scratch, N, Cin, H, W, Cout, Ho, Wo, K, stride, pad, QS, splits, N / groups});
             if (splits > 1) q->reduce.push_back(RJob{scratch, dw, splits, Cout * Ktot});
@@ -862,33 +848,6 @@ __device__ __forceinline__ void channel_sum_body(const float* __restrict__ x, fl
 __global__ __launch_bounds__(MEDT_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                                    int N, int C, int HW) {
     channel_sum_body(x, part, N, C, HW, blockIdx.x, blockIdx.y, gridDim.y);
-}
-
-int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s) {
-    static const int KS[3] = {1, 3, 7};
-    for (int K : KS) {
-        WBatch b;
-        b.n = 0;
-        int blocks = 0;
-        auto launch = [&]() -> int {
-            b.start[b.n] = blocks;
-            if (K == 1) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<1>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-            else if (K == 3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<3>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-            else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<7>), dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-            b.n = 0;
-            blocks = 0;
-            return launch_status("conv_wgrad_grouped_valu");
-        };
-        for (int j = 0; j < n; ++j) {
-            if (jobs[j].K != K) continue;
-            b.job[b.n] = jobs[j];
-            b.start[b.n] = blocks;
-            blocks += jobs[j].gx * jobs[j].gy * jobs[j].gz;
-            if (++b.n == 36) { int rc = launch(); if (rc) return rc; }
-        }
-        if (b.n) { int rc = launch(); if (rc) return rc; }
-    }
-    return MEDT_OK;
 }
 
 using CBatch = JobBatch<CJob, 96>;

@@ -28,13 +28,13 @@ typedef medt_f4 f32x4;
 bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions) {
     static const bool off = [] { const char* e = getenv("MEDT_DISABLE_MFMA"); return e && e[0] == '1'; }();
     // A/B switch (scripts/conv_ab.py -> profiles/r02_conv_ab.json): the matrix-core tile kernel wherever it is legal
-    static const bool force = [] { const char* e = getenv("MEDT_FORCE_MFMA"); return e && e[0] == '1'; }();
+    static const bool force = false;
     if (force && !off) return (K == 1 || K == 3) && (stride == 1 || stride == 2);
     const long tiles = ((positions + 63) / 64) * ((Cout + 63) / 64);
     if (off || Cout < 32 || Cin * K * K < 256 || (stride != 1 && stride != 2)) return false;
     if (K == 3 && tiles >= 128) return true;
     // few tiles (2x2 / 4x4 maps of the deep LoGo layers, <= 1024 positions): split-K over workgroups + epilogue
-    static const long few_pos = [] { const char* e = getenv("MEDT_MFMA_FEWTILE_POS"); return e ? atol(e) : 2048L; }();
+    static const long few_pos = 2048L;
     return (K == 3 || K == 1) && tiles < 128 && positions <= few_pos && Cin * K * K >= 512;
 }
 
@@ -503,7 +503,7 @@ struct ThinPlan { int ok, CC, NRB, TR, KG, TCW, RG, RST, CST, AST, rows_wg, cols
 
 ThinPlan conv_thin_plan(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
     static const bool off = [] { const char* e = getenv("MEDT_CONV_THIN"); return e && e[0] == '0'; }();
-    static const int force_tr = [] { const char* e = getenv("MEDT_THIN_TR"); return e ? atoi(e) : 0; }();      // (debugging: rows per wave)
+    static const int force_tr = 0;      // (debugging: rows per wave)
     ThinPlan p{};
     if (off || K != 3 || stride != 1 || pad != 1 || W < 16 || (W & 15) || (Cin & 7) || Cin < 8 || Cout < 1 || groups < 1 || N % groups) return p;
     if ((long)N * H * W < 4096) return p;                        // (tiny maps: the split-K / small-map kernels)
@@ -537,7 +537,7 @@ ThinPlan conv_thin_plan(int N, int groups, int Cin, int H, int W, int Cout, int 
     p.ppg = (N / groups) * p.wgs_img;
     p.grid_y = cdiv(rbs, p.NRB);
     // K-groups (see the kernel): deep contractions at one row per wave on a grid that does not fill the SIMDs by itself
-    static const int force_kg = [] { const char* e = getenv("MEDT_THIN_KG"); return e ? atoi(e) : 0; }();
+    static const int force_kg = 0;
     const int nch = Cin / p.CC;
     p.KG = 1;
     if (p.CC == 16 && p.TR == 1 && best_wgs <= 512) p.KG = (nch % 4 == 0) ? 4 : ((nch % 2 == 0) ? 2 : 1);
@@ -1544,22 +1544,15 @@ __global__ __launch_bounds__(MEDT_THREADS, 3) void conv_wgrad_mfma_grouped_kerne
 // The 16-byte body's preconditions (the chunk policy of conv.hip asks before it sizes the job's chunks)
 bool conv_wgrad_v4_ok(const float* dy, const float* raw, const float* x, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
                       int K, int stride, int pad) {
-    static const bool off = [] { const char* e = getenv("MEDT_WG_V4"); return e && e[0] == '0'; }();
-    static const bool to64 = [] { const char* e = getenv("MEDT_WG_TILE"); return e && atoi(e) == 64; }();
-    static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
-    static const bool k3 = [] { const char* e = getenv("MEDT_WG_V4_K3"); return !(e && e[0] == '0'); }();
-    if (off || to64 || valu || stride != 1 || Ho != H || Wo != W) return false;
-    if (!((K == 1 && pad == 0 && (H * W) % 4 == 0) || (K == 3 && pad == 1 && W % 4 == 0 && k3))) return false;
+    if (stride != 1 || Ho != H || Wo != W) return false;
+    if (!((K == 1 && pad == 0 && (H * W) % 4 == 0) || (K == 3 && pad == 1 && W % 4 == 0))) return false;
     if ((((uintptr_t)dy | (uintptr_t)raw | (uintptr_t)x) & 15) != 0) return false;
     const size_t HW = (size_t)H * W;
     return (size_t)N * Cout * HW * 4 < 0xffffffffull && (size_t)N * Cin * HW * 4 < 0xffffffffull;      // 32-bit byte offsets
 }
 
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
-    static const bool valu = [] { const char* e = getenv("MEDT_WGRAD_VALU"); return e && e[0] == '1'; }();
-    if (valu) return conv_wgrad_grouped_valu(jobs, n, s);            // A/B switch: the 4x4-register-tile VALU body
-    static const bool debug = getenv("MEDT_WG_DEBUG") != nullptr;
-    static const int to = [] { const char* e = getenv("MEDT_WG_TILE"); return (e && atoi(e) == 64) ? 64 : 32; }();   // o-tile
+    constexpr int to = 32;        // o-tile (round 5: the 64-row tile and the VALU body lost their A/B and are gone)
     // longest workgroups first: steps of 64 positions per chunk, weighted by the taps a step gathers
     std::vector<int> order(n);
     for (int j = 0; j < n; ++j) order[j] = j;
@@ -1570,9 +1563,7 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     int blocks = 0;
     auto launch = [&]() -> int {
         b.start[b.n] = blocks;
-        if (debug) fprintf(stderr, "wgrad grouped: %d jobs, %d blocks\n", b.n, blocks);
-        if (to == 32) hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel<32>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
-        else hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel<64>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel<32>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
         b.n = 0;
         blocks = 0;
         return launch_status("conv_wgrad_mfma_grouped");
@@ -1580,9 +1571,6 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     for (int i = 0; i < n; ++i) {
         const WJob& w = jobs[order[i]];
         if (w.K != 1 && w.K != 3 && w.K != 7) { set_error("conv2d: kernel size %d unsupported (1, 3, 7)", w.K); return MEDT_EUNSUPPORTED; }
-        if (debug)
-            fprintf(stderr, "  wjob K%d Cout %d Cin %d HoWo %dx%d N %d QS %d grid %dx%dx%d\n", w.K, w.Cout, w.Cin, w.Ho, w.Wo,
-                    w.N, w.QS, w.gx, w.gy, w.gz);
         b.job[b.n] = WJobP{w.dy, w.raw, w.coef, w.x, w.scratch, w.N, w.Cin, w.H, w.W, w.Cout, w.Ho, w.Wo, w.QS, w.npg, w.gz,
                            (unsigned char)w.stride, (unsigned char)w.pad, (unsigned char)w.K, (unsigned char)(to == 32 && w.v4)};
         b.start[b.n] = blocks;
@@ -1607,7 +1595,7 @@ int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s) {
     if (abl_skip(jobs[0]->N >= 16 ? "wgrad_mfma_l" : "wgrad_mfma_g")) return MEDT_OK;
     // output channels per workgroup.  Measured (profiles/r05_step_ab.json): the half-width instance is 12 us SLOWER here (56.8 us per
     // launch: twice the workgroups restage the patch, and the pair is matrix-pipe-bound already) -- MEDT_R16W_OT=32 selects it
-    static const int ot = [] { const char* e = getenv("MEDT_R16W_OT"); return (e && atoi(e) == 32) ? 32 : 64; }();
+    static const int ot = 64;
     for (int i0 = 0; i0 < n; i0 += 4) {
         R16WBatch b;
         b.n = n - i0 < 4 ? n - i0 : 4;

@@ -254,7 +254,7 @@ static size_t conv_small_lds(int P, int Cin, int noc) {
 // measured there the fused forward ties with conv + finalize + apply (14.5 vs 15.6 us) and the one-wave-per-channel
 // backward loses (20 vs 15 us), so those blocks stay on the layer-by-layer kernels.
 static int conv_small_noc(int P, int Cin) {
-    static const int min_noc = [] { const char* e = getenv("MEDT_SMALL_NOC8"); return (e && e[0] == '1') ? 8 : 16; }();
+    static const int min_noc = 16;
     for (int noc = SC_NOC_MAX; noc >= min_noc; noc >>= 1)
         if (conv_small_lds(P, Cin, noc) <= 64 * 1024) return noc;
     return 0;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(TT) void bn_act_bwd_chan_kernel(SmallBnBwdArgs a) {
 
 // one workgroup of 256 (population <= 4096) or 1024 threads (<= 16384) per (group, channel); 0: not applicable
 int bn_chan_threads(const medt_conv_desc& d, int HoWo) {
-    static const int pmax = [] { const char* e = getenv("MEDT_BN_CHAN_MAX"); return e ? atoi(e) : 16384; }();
+    static const int pmax = 16384;
     if (!d.has_bn || (HoWo & 3)) return 0;
     const long P = (long)(d.N / d.bn_groups) * HoWo;
     if (P > pmax || P > 16384) return 0;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(T) void bn_dgrad1x1_small_kernel(BnDgradArgs a) {
 struct BnDgradPlan { int T, E, CT, CPT; size_t lds; };
 
 static bool bn_dgrad_fused_enabled() {
-    static const bool on = [] { const char* e = getenv("MEDT_BN_DGRAD_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool on = true;
     return on;
 }
 
@@ -641,7 +641,7 @@ static bool bn_dgrad1x1_plan(const medt_conv_desc& d, BnDgradPlan* pl) {
     if (CPT != 1 && CPT != 2 && CPT != 4) return false;
     pl->T = T; pl->E = (int)E; pl->CT = CT; pl->CPT = CPT;
     pl->lds = ((size_t)tile + (size_t)d.Cout * CT) * sizeof(float);
-    static const size_t lds_cap = [] { const char* e = getenv("MEDT_BN_DGRAD_LDS_KB"); return (size_t)(e ? atoi(e) : 150) * 1024; }();
+    static const size_t lds_cap = (size_t)150 * 1024;
     return pl->lds <= lds_cap;
 }
 

@@ -100,7 +100,6 @@ int channel_sum_grouped(const CJob* jobs, int n, hipStream_t s);
 int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s);            // MFMA tiles (conv_mfma.hip)
 bool conv_wgrad_v4_ok(const float* dy, const float* raw, const float* x, int N, int Cin, int H, int W, int Cout, int Ho, int Wo,
                       int K, int stride, int pad);
-int conv_wgrad_grouped_valu(const WJob* jobs, int n, hipStream_t s);       // VALU tiles (conv.hip), MEDT_WGRAD_VALU=1
 bool conv_wgrad_rows16_ok(int Cin, int H, int W, int Ho, int Wo, int K, int stride, int pad, int QS);
 int conv_wgrad_rows16_grouped(const MJob* const* jobs, int n, hipStream_t s);   // LDS-patch kernel of the 16-wide maps, <= 4 problems per launch
 int conv_wgrad_mfma_batch(const MJob* const* jobs, int n, hipStream_t s);       // generic MFMA tile kernel (K = 1 | 3), <= 4 problems per launch

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void up2x_relu_add4_kernel(const floa
 
 int up2x_relu_add_fwd(const float* x, const float* skip, float* y, int NC, int H, int W, hipStream_t s) {
     const size_t total = (size_t)NC * 4 * H * W;
-    static const bool vec = [] { const char* e = getenv("MEDT_UP2X_VEC"); return !(e && e[0] == '0'); }();
+    static const bool vec = true;
     if (vec && (W & 1) == 0 && ((uintptr_t)y & 15) == 0 && (!skip || ((uintptr_t)skip & 15) == 0)) {
         hipLaunchKernelGGL(up2x_relu_add4_kernel, dim3(grid1d(total / 4)), dim3(MEDT_THREADS), 0, s, x, skip, y, H, W, total / 4);
         return launch_status("up2x_relu_add4");

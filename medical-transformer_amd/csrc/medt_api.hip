@@ -16,7 +16,13 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// TIMING EXPERIMENTS ONLY, compiled in with -DMEDT_ABLATE (scripts/r6_skip.sh builds libmedt_ablate.so and loads it through
+// MEDT_LIB_OVERRIDE): MEDT_SKIP=<families> makes the named entry points return without launching.  The product library answers false.
 bool abl_skip(const char* family) {
+#ifndef MEDT_ABLATE
+    (void)family;
+    return false;
+#else
     static const char* env = [] {
         const char* e = getenv("MEDT_SKIP");
         if (e && *e)
@@ -33,6 +39,7 @@ bool abl_skip(const char* family) {
         p += len + (e ? 1 : 0);
     }
     return false;
+#endif
 }
 
 int lds_opt_in(const void* kernel, unsigned char (&done)[64], const char* what) {
@@ -123,7 +130,7 @@ struct BwdWs {
         pg_part = c.take<float>(sweep ? sweep_blocks * g.L * plan.npg_floats : 0);
         gate_raw = c.take<float>(sweep ? sweep_blocks * 4 : 0);
         gate_rows = c.take<float>(sweep ? (size_t)g.groups * g.G * 4 : 0);
-        static const bool raw32_on = [] { const char* e = getenv("MEDT_BF16_RAW32"); return !(e && e[0] == '0'); }();
+        static const bool raw32_on = true;
         raw32 = c.take<float>(sweep && g.bf16 && raw32_on ? (size_t)g.N * 2 * g.C * g.HW : 0);
         if (!(sweep && g.bf16 && raw32_on)) raw32 = nullptr;
     }
@@ -423,7 +430,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
                                  gr->bn_sim_weight, gr->bn_sim_bias, s, ob.on ? &ob : nullptr, sim_inl, qb.on ? &qb : nullptr))) return rc;
     // bn_qkv backward, qkv_transform backward
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
-    static const bool bf16_fused = [] { const char* e = getenv("MEDT_BF16_FIN_APPLY"); return !(e && e[0] == '0'); }();
+    static const bool bf16_fused = true;
     if (g.bf16 && w.raw32) {
         // bf16 storage, round 5: the sweep has left qkv_raw widened to float32 in the workspace (one extra store per element of a
         // VALU-bound kernel): bn_qkv's backward is then applied on load by the 1x1 dgrad / wgrad exactly as with fp32 storage --
@@ -533,7 +540,7 @@ extern "C" {
 // layer's saved BatchNorm statistics (`stats` is the one buffer both passes get): the flip leaves the backward chain (four
 // launches of MedT's local branch) for the forward pass's grouped flush.  Both sides derive the layout from the descriptor.
 static bool conv_preflip(const medt_conv_desc* d) {
-    static const bool on = [] { const char* e = getenv("MEDT_PREFLIP"); return !(e && e[0] == '0'); }();
+    static const bool on = true;
     // (3x3 only: the layers that take the MFMA backward-data in practice; the 1x1 blocks that adopt a one-launch block kernel's outputs
     //  -- medt_amd/block.py -- never call the forward entry and bring their own, smaller statistics block)
     return on && d->training && d->K == 3 && conv2d_bwd_data_flips(d->N, d->Cin, d->H, d->W, d->Cout, d->K, d->stride, d->pad);
@@ -598,7 +605,7 @@ int medt_conv_block_fwd(const medt_conv_desc* d, const float* x, const float* w,
     }
     if ((rc = conv2d_fwd(x, w, nullptr, z, tr ? cw.partials : nullptr, cw.ksplit_fwd, d->N, d->Cin, d->H, d->W, d->Cout, d->K,
                          d->stride, d->pad, 0, d->bn_groups, s))) return rc;
-    static const bool fused_fin = [] { const char* e = getenv("MEDT_BN_FIN_APPLY"); return !(e && e[0] == '0'); }();
+    static const bool fused_fin = true;
     const double count = (double)(d->N / d->bn_groups) * g.HoWo;
     if (!fused_fin) {
         if ((rc = bn_finalize(cw.partials, g.ppg, d->bn_groups, d->Cout, count, *bn, d->momentum, d->eps, tr, st, s))) return rc;

@@ -594,9 +594,12 @@ int bn_bwd_finalize(const float* partials, int ppg, int groups, int CH, double c
 // --------------------------------------------------------------------------- //
 // bn_output apply + pair-sum + AvgPool2d(stride)        (axialnet.py:179-187)
 // --------------------------------------------------------------------------- //
-__global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float* __restrict__ stk, BnStats st,
-                                                                     float* __restrict__ y, int N, int C, int H, int W,
-                                                                     int OC, int stride, int npg, int relu, int bf16, FinSrc src) {
+// (BF: the storage type of `stk` at compile time -- with a runtime flag inside ld_act every load sits in a branch of its own)
+template <bool BF>
+__device__ __forceinline__ void axial_out_fwd_body(const float* __restrict__ stk, BnStats st,
+                                                   float* __restrict__ y, int N, int C, int H, int W,
+                                                   int OC, int stride, int npg, int relu, const FinSrc& src) {
+    constexpr int bf16 = BF ? 1 : 0;
     const int Ho = H / stride, Wo = W / stride;
     const size_t total = (size_t)N * C * Ho * Wo;
     const size_t idx = (size_t)blockIdx.x * MEDT_THREADS + threadIdx.x;
@@ -646,6 +649,13 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float
     }
     acc *= 1.f / (float)(stride * stride);
     y[idx] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+__global__ __launch_bounds__(MEDT_THREADS) void axial_out_fwd_kernel(const float* __restrict__ stk, BnStats st,
+                                                                     float* __restrict__ y, int N, int C, int H, int W,
+                                                                     int OC, int stride, int npg, int relu, int bf16, FinSrc src) {
+    if (bf16) axial_out_fwd_body<true>(stk, st, y, N, C, H, W, OC, stride, npg, relu, src);
+    else axial_out_fwd_body<false>(stk, st, y, N, C, H, W, OC, stride, npg, relu, src);
 }
 
 bool axial_out_fwd_inlines(const medt_axial_desc& d) {

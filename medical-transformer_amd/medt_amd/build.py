@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmedt_hip.so")
 SOURCES = ["medt_api.hip", "pointwise.hip", "axial_core.hip", "conv.hip", "elementwise.hip", "axial_fast.hip", "conv_mfma.hip", "axial_small.hip", "conv_small.hip", "axial_stats.hip", "defer.hip", "axial_bwd.hip", "block_small.hip"]
-HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", "sim_tables.h", "defer.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
+HEADERS = ["medt_common.h", "medt_kernels.h", "axial_tiles.h", "sim_tables.h", "defer.h", "fin_inline.h", os.path.join(REPO_ROOT, "include", "medt_abi.h")]
 
 
 def _stale() -> bool:
@@ -41,6 +41,16 @@ def build_asan(verbose: bool = False) -> str:
             return ASAN_LIB_PATH
     return build(force=True, verbose=verbose, defines=("-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g"),
                  lib_path=ASAN_LIB_PATH, obj_dir="build_asan", link_flags=("-fsanitize=address", "-shared-libsan"))
+
+
+ABLATE_LIB_PATH = os.path.join(PKG_DIR, "libmedt_ablate.so")
+
+
+def build_ablate(verbose: bool = False) -> str:
+    """libmedt_ablate.so: the same sources with -DMEDT_ABLATE -- the only build in which MEDT_SKIP=<kernel families> is honoured
+    (timing experiments, scripts/r6_skip.sh loads it through MEDT_LIB_OVERRIDE; every result of such a run is garbage).  The
+    product library has no such switch."""
+    return build(force=True, verbose=verbose, defines=("-DMEDT_ABLATE",), lib_path=ABLATE_LIB_PATH, obj_dir="build_ablate")
 
 
 def asan_runtime() -> str:
