@@ -329,14 +329,25 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
                             d->momentum, d->eps, tr, s);
     }
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
-    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
-                         2 * g.C, 1, 1, 0, 0, g.groups, s, g.bf16))) return rc;
-    // (+ the sliding-window tables of the statistics kernel below as extra blocks of this launch)
+    // Round 6 (fin_inline.h), second step: bn_qkv is finalised by the statistics kernel that consumes it (every workgroup for the
+    // channels of its head, the first workgroup of the head saves them), and the sliding-window tables of that kernel ride on the
+    // qkv convolution's launch instead of on the bn_finalize launch that is gone: 5 launches per layer become 4.
     const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
-    if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
-                          st.qkv, s, &tj))) return rc;
+    const bool qkv_inl_ok = inline_fin_ok(tr, g.groups, ppg);
+    bool tj_done = false;
+    if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
+                         2 * g.C, 1, 1, 0, 0, g.groups, s, g.bf16, qkv_inl_ok ? &tj : nullptr, &tj_done))) return rc;
+    const bool qkv_inl = qkv_inl_ok && tj_done;
+    // (else: a bn_finalize launch, + the sliding-window tables of the statistics kernel below as extra blocks of it)
+    if (!qkv_inl && (rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
+                                      st.qkv, s, &tj))) return rc;
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
-    if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
+    FinSrc qkv_src = no_fin_src();
+    if (qkv_inl) {
+        qkv_src.f = make_fin(w.part_qkv, ppg, 2 * g.C, g.row_count, p->bn_qkv, st.qkv);
+        qkv_src.momentum = d->momentum; qkv_src.eps = d->eps; qkv_src.on = 1;
+    }
+    if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s, qkv_inl ? &qkv_src : nullptr))) return rc;
     // Round 6 (fin_inline.h): inside the networks (training mode, one BatchNorm group, few partial rows) bn_similarity and bn_output
     // are finalised by the kernels that consume them -- the attention kernel and the output pass -- instead of by a bn_finalize
     // launch each: 7 launches per layer become 5.

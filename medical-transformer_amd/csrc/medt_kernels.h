@@ -69,9 +69,11 @@ int conv_stem7_parts_per_group(int N, int groups, int HoWo);
 int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W, int Cout,
                    int relu, hipStream_t s);
 // y_bf16: store y as bfloat16 (VALU path only: the 1x1 qkv_transform of a bf16-storage attention layer)
+// tj / tj_done (optional): the sliding-window tables of the layer's statistics kernel as extra workgroups of THIS launch; *tj_done says
+// whether the kernel that ran took them (the generic 1x1 kernel does) -- if not, the caller builds them elsewhere (bn_finalize)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
-               int y_bf16 = 0);
+               int y_bf16 = 0, const TablesJob* tj = nullptr, bool* tj_done = nullptr);
 size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // wt_scratch: Cout*Cin*K*K floats (used by the MFMA path for the flipped weights; may be NULL -> VALU path)
 // add (optional): dx = dgrad + add -- the other gradient contributions of a fanned-out input, summed in the epilogue
@@ -230,8 +232,11 @@ bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernel
 size_t sim_tables_floats(const AxialGeom& g);
 int sim_tables_blocks(const AxialGeom& g);
 int sim_stats_parts(const AxialGeom& g);
+// qsrc (optional, fin_inline.h): bn_qkv is finalised by the statistics kernel itself from the qkv convolution's partial rows and saved
+// by its first workgroups -- `qkv` is written, not read; no bn_finalize launch in front (the tables then come from the convolution
+// launch: conv2d_fwd's TablesJob)
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      const float* tables, float* partials, hipStream_t s);
+                      const float* tables, float* partials, hipStream_t s, const FinSrc* qsrc = nullptr);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
 // simsrc (optional, fin_inline.h; only where axial_attn_fwd_inlines()): bn_similarity is finalised by the kernel itself from the
 // statistics kernel's partial rows -- `sim` is not read, no bn_finalize launch in front

@@ -27,9 +27,9 @@ grep -E "^local|^global" $O/step_chains.txt
 C="python bench.py --no-cpu-baseline --no-roofline --steps 3 --warmup 1"
 MEDT_BENCH_WINDOWS=1 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc1 -- $C > $O/pmc1.log 2>&1
 MEDT_BENCH_WINDOWS=1 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc2 -- $C > $O/pmc2.log 2>&1
-python - <<PY
+O=$O python - <<'PY'
 import collections, csv, glob, json, os, re
-O = "$O"
+O = os.environ["O"]
 out = {}
 for d in ("pmc1", "pmc2"):
     fs = glob.glob(f"{O}/{d}/**/*_counter_collection.csv", recursive=True)
