@@ -167,6 +167,7 @@ struct SweepArgs {
     int tiles, nparts;             // tiles of S_T sequences per BN group; workgroups per BN group
     int qb_rpg;                    // rows per BN group of part_qb (the sweep's nparts rows first, then the fix kernel's)
     BfinSrc ob;                    // on: bn_output's backward coefficients are derived here from axial_out_bwd_stats' partial rows (fin_inline.h)
+    const float* ymask;            // layers with a fused output ReLU: the layer's output y -- dy counts where y > 0 (no relu_mask launch in front)
 };
 
 // Sum K per-thread values over the workgroup (nw waves, fixed order); thread k < K stores value k to out[k].
@@ -226,12 +227,12 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     for (int ch = 0; ch < NCH; ++ch) {
         sc[ch] = a.qs.scale[grp * 2 * g.C + hg * NCH + ch];
         sh[ch] = a.qs.shift[grp * 2 * g.C + hg * NCH + ch];
-        if (!a.ob.on) {
+        if (!a.ob.on || MEDT_ABL == 10) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) cf[ch][k] = a.out_coef[((size_t)grp * g.OC + hg * NCH + ch) * 3 + k];
         }
     }
-    if (a.ob.on) {
+    if (a.ob.on && MEDT_ABL != 10) {
         // bn_output's backward finalised HERE (fin_inline.h: no bn_bwd_finalize launch in front of the sweep).  Eight lanes per
         // channel, eight channels of the head at a time: every wave sums the partial rows (one load round trip), runs the double
         // arithmetic once for all of them and broadcasts the three coefficients per channel; the first workgroup of the head writes
@@ -325,6 +326,23 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
             for (int c = 0; c < GP; ++c)
                 r.dyv[kk][c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dybase) + doff + (unsigned)(c * Ho * Wo) * 4u);
             r.lse[kk] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lbase) + ((unsigned)n * g.G * g.HW + pix) * 4u);
+        }
+        if (a.ymask) {                // (wave-uniform) the output ReLU's backward on load: one more load per dy element, same offsets
+            const char* ybase = reinterpret_cast<const char*>(a.ymask + (size_t)hg * GP * Ho * Wo);
+            float ym[D][GP];
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) {
+                int ls, i, n, h, w;
+                const bool ok = locate(kk, seq0_, nseq_, ls, i, n, h, w);
+                const int ho = min(h / a.pool, Ho - 1), wo = min(w / a.pool, Wo - 1);
+                const unsigned doff = ok ? (((unsigned)n * g.C * Ho + ho) * Wo + wo) * 4u : 0u;
+#pragma unroll
+                for (int c = 0; c < GP; ++c) ym[kk][c] = *reinterpret_cast<const float*>(ybase + doff + (unsigned)(c * Ho * Wo) * 4u);
+            }
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk)
+#pragma unroll
+                for (int c = 0; c < GP; ++c) r.dyv[kk][c] = ym[kk][c] > 0.f ? r.dyv[kk][c] : 0.f;
         }
     };
     auto issue = [&](int tile_, TileRegs& r) {
@@ -651,7 +669,7 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     // ---- workgroup results ------------------------------------------------------------------------------------------
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;       // (head, group, part)
-    {   // table gradients: waves in fixed order, the per-head scales, `relative`'s layout (Rk rows reversed back)
+    if (MEDT_ABL != 11) {   // table gradients: waves in fixed order, the per-head scales, `relative`'s layout (Rk rows reversed back)
         float* rp = a.rel_part + blk * NCH * TL;
         const float sq = f_qr * e_qr, sk = f_kr * e_kr, sv = GATES ? f_sve : 1.f;
         for (int e = threadIdx.x; e < NCH * TL; e += nthreads) {
@@ -1020,10 +1038,11 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
                          float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32,
-                         const BfinSrc* ob) {
+                         const BfinSrc* ob, const float* ymask) {
     if (abl_skip("sweep")) return MEDT_OK;
     SweepArgs a;
     a.ob = ob ? *ob : no_bfin_src();
+    a.ymask = ymask;
     a.g = g;
     a.qkv_raw = qkv_raw; a.stacked = stacked; a.lse = lse; a.dy = dy; a.relative = relative; a.out_coef = out_coef;
     a.qs = qkv; a.ss = sim; a.gates = gates; a.pool = stride;

@@ -21,7 +21,6 @@
 // the row, read back transposed with an odd stride).
 #include "axial_tiles.h"
 #include "sim_tables.h"
-#include "fin_inline.h"
 
 namespace medt {
 
@@ -39,7 +38,7 @@ template <int HQ, bool POS, int AXIS, bool BF>
 __device__ __forceinline__ void sim_stats_body(const AxialGeom& g, const float* __restrict__ qkv_raw,
                                                BnStats qs, const float* __restrict__ tables,
                                                GatePtrs gates, float* __restrict__ partials,
-                                               int sparts, int pc_log, const FinSrc& qsrc) {
+                                               int sparts, int pc_log) {
     constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NV = 2 * NR, RND = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = g.L, PC = 1 << pc_log, PCQ = PC >> 2, RS = PC + 1;
@@ -60,16 +59,10 @@ __device__ __forceinline__ void sim_stats_body(const AxialGeom& g, const float* 
     __syncthreads();
     const int myoff = seqoff[lane];
     float sc[GP], sh[GP];
-    if (qsrc.on) {
-        // bn_qkv finalised HERE from the qkv convolution's partial rows (fin_inline.h: no bn_finalize launch between the two); the
-        // first workgroup of the head saves the statistics for the kernels behind this one
-        qkv_fin_inline<4 * HQ, GP>(qsrc, hg * NCH, blockIdx.x == 0 && threadIdx.x < 64, sc, sh);
-    } else {
 #pragma unroll
-        for (int ch = 0; ch < GP; ++ch) {
-            sc[ch] = qs.scale[grp * 2 * g.C + hg * NCH + ch];
-            sh[ch] = qs.shift[grp * 2 * g.C + hg * NCH + ch];
-        }
+    for (int ch = 0; ch < GP; ++ch) {
+        sc[ch] = qs.scale[grp * 2 * g.C + hg * NCH + ch];
+        sh[ch] = qs.shift[grp * 2 * g.C + hg * NCH + ch];
     }
     // v[0..HQ) = Sq, [HQ..NR) = Gq pairs, [NR..NR+HQ) = Sk, [NR+HQ..NV) = Gk pairs
     float v[NV];
@@ -208,9 +201,9 @@ template <int HQ, bool POS, int AXIS>
 __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
                                                                  BnStats qs, const float* __restrict__ tables,
                                                                  GatePtrs gates, float* __restrict__ partials,
-                                                                 int sparts, int pc_log, FinSrc qsrc) {
-    if (g.bf16) sim_stats_body<HQ, POS, AXIS, true>(g, qkv_raw, qs, tables, gates, partials, sparts, pc_log, qsrc);
-    else sim_stats_body<HQ, POS, AXIS, false>(g, qkv_raw, qs, tables, gates, partials, sparts, pc_log, qsrc);
+                                                                 int sparts, int pc_log) {
+    if (g.bf16) sim_stats_body<HQ, POS, AXIS, true>(g, qkv_raw, qs, tables, gates, partials, sparts, pc_log);
+    else sim_stats_body<HQ, POS, AXIS, false>(g, qkv_raw, qs, tables, gates, partials, sparts, pc_log);
 }
 
 // --------------------------------------------------------------------------- //
@@ -265,21 +258,17 @@ template <int HQ, bool POS, int V>
 __global__ __launch_bounds__(MEDT_THREADS) void sim_stats_rows_kernel(AxialGeom g, const float* __restrict__ qkv_raw,
                                                                       BnStats qs, const float* __restrict__ tables,
                                                                       GatePtrs gates, float* __restrict__ partials,
-                                                                      int sparts, FinSrc qsrc) {
+                                                                      int sparts) {
     constexpr int GP = 2 * HQ, NP = HQ * (HQ + 1) / 2, NR = HQ + NP, NCH = 4 * HQ, L = 16 * V;
     MEDT_STATIC_SHARED double red[MEDT_WAVES * 8];
     const int grp = blockIdx.x / sparts, tile = blockIdx.x - grp * sparts, hg = blockIdx.y;
     const int seq0 = tile * 64, nseq = min(64, g.spg - seq0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, p0 = (lane & 15) * V;
     float sc[GP], sh[GP];
-    if (qsrc.on) {                      // (bn_qkv finalised here: see sim_stats_body)
-        qkv_fin_inline<NCH, GP>(qsrc, hg * NCH, blockIdx.x == 0 && threadIdx.x < 64, sc, sh);
-    } else {
 #pragma unroll
-        for (int ch = 0; ch < GP; ++ch) {
-            sc[ch] = qs.scale[grp * 2 * g.C + hg * NCH + ch];
-            sh[ch] = qs.shift[grp * 2 * g.C + hg * NCH + ch];
-        }
+    for (int ch = 0; ch < GP; ++ch) {
+        sc[ch] = qs.scale[grp * 2 * g.C + hg * NCH + ch];
+        sh[ch] = qs.shift[grp * 2 * g.C + hg * NCH + ch];
     }
     float tq[POS ? NR : 1][V], tk[POS ? NR : 1][V];         // this lane's positions of the sliding-window tables
     if (POS) {
@@ -375,15 +364,14 @@ static int stats_chunk_log(const AxialGeom& g) {
 }
 
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      const float* tables, float* partials, hipStream_t s, const FinSrc* qsrc_p) {
+                      const float* tables, float* partials, hipStream_t s) {
     const int sparts = sim_stats_parts(g), lg = stats_chunk_log(g);
-    const FinSrc qsrc = qsrc_p ? *qsrc_p : no_fin_src();
     if (g.pos && !tables) { set_error("sim_stats: no tables"); return MEDT_EINVAL; }
     if (g.axis == 1 && g.hq <= 2 && (g.L == 16 || g.L == 32 || g.L == 64 || g.L == 128) && (g.W & 3) == 0) {
         // rows-of-16-lanes kernel: no LDS transpose (width layers with the model's power-of-two lengths, hq <= 2)
         const dim3 gridr(g.groups * sparts, g.G), blockr(MEDT_THREADS);
 #define MEDT_SR(HQv, POSv, Vv) \
-    hipLaunchKernelGGL((sim_stats_rows_kernel<HQv, POSv, Vv>), gridr, blockr, 0, s, g, qkv_raw, qkv, tables, gates, partials, sparts, qsrc)
+    hipLaunchKernelGGL((sim_stats_rows_kernel<HQv, POSv, Vv>), gridr, blockr, 0, s, g, qkv_raw, qkv, tables, gates, partials, sparts)
 #define MEDT_SR_V(HQv, POSv)                                                                                          \
     do {                                                                                                              \
         if (g.L == 16) MEDT_SR(HQv, POSv, 1); else if (g.L == 32) MEDT_SR(HQv, POSv, 2);                               \
@@ -400,7 +388,7 @@ int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, con
     const dim3 grid(g.groups * sparts, g.G), block(MEDT_THREADS);
 #define MEDT_SS(HQv, POSv, AXv)                                                                                       \
     hipLaunchKernelGGL((sim_stats_kernel<HQv, POSv, AXv>), grid, block, lds, s, g, qkv_raw, qkv, tables, gates, partials, \
-                       sparts, lg, qsrc)
+                       sparts, lg)
     switch (g.hq * 4 + g.pos * 2 + g.axis) {
         case 1 * 4 + 0: MEDT_SS(1, false, 0); break;
         case 1 * 4 + 1: MEDT_SS(1, false, 1); break;

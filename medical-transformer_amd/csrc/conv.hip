@@ -7,7 +7,6 @@
 // channels in registers, the K*K taps of one input channel are loaded once per lane and the weights
 // arrive through the scalar path (wave-uniform addresses, K*K contiguous floats per (o,c) pair).
 #include "defer.h"
-#include "sim_tables.h"
 #include <type_traits>
 
 namespace medt {
@@ -22,17 +21,8 @@ template <int K, int OT>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ partials, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu,
-    int npg, int y_bf16, TablesJob tj) {
+    int npg, int y_bf16) {
     constexpr int KK = K * K;
-    if constexpr (K == 1) {
-        // appended workgroups (round 6): the sliding-window tables of the attention layer's statistics kernel ride on the qkv
-        // convolution's launch when bn_qkv is finalised by that kernel (fin_inline.h) -- there is no bn_finalize launch to carry them
-        if (blockIdx.x >= gridDim.x - tj.blocks) {
-            MEDT_STATIC_SHARED float tlds[512];
-            if (blockIdx.y == 0) sim_tables_block(blockIdx.x - (gridDim.x - tj.blocks), tj.relative, tj.tables, tj.HQ, tj.L, tlds);
-            return;
-        }
-    }
     MEDT_STATIC_SHARED float red[MEDT_WAVES * OT * 2 * 2];
     const int HoWo = Ho * Wo, per_group = npg * HoWo, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
     const int grp = blockIdx.x / ppg, part = blockIdx.x - grp * ppg, o0 = blockIdx.y * OT;
@@ -117,14 +107,12 @@ static int pick_tile(int C, int max_tile, long position_blocks) {
 template <int K>
 static int conv2d_fwd_k(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int Cin,
                         int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int relu, int groups,
-                        hipStream_t s, int y_bf16, const TablesJob* tjp) {
+                        hipStream_t s, int y_bf16) {
     const int npg = N / groups;
-    TablesJob tj = (tjp && K == 1) ? *tjp : TablesJob{nullptr, nullptr, 0, 0, 0};
-    if (tj.L > 256) tj.blocks = 0;                     // (the table workgroups stage 2L - 1 products in 512 floats of LDS)
-    const unsigned gx = (unsigned)(groups * conv2d_parts_per_group(N, groups, Ho * Wo)) + (unsigned)tj.blocks;
+    const unsigned gx = (unsigned)(groups * conv2d_parts_per_group(N, groups, Ho * Wo));
 #define MEDT_LAUNCH_FWD(OT)                                                                                        \
     hipLaunchKernelGGL((conv2d_fwd_kernel<K, OT>), dim3(gx, Cout / OT), dim3(MEDT_THREADS), 0, s, x, w, bias, y, partials, \
-                       Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg, y_bf16, tj)
+                       Cin, H, W, Cout, Ho, Wo, stride, pad, relu, npg, y_bf16)
     switch (pick_tile(Cout, K == 7 ? 8 : 16, gx)) {
         case 16: if constexpr (K != 7) { MEDT_LAUNCH_FWD(16); } break;
         case 8: MEDT_LAUNCH_FWD(8); break;
@@ -292,9 +280,8 @@ static int conv2d_fwd_ws(const float* x, const float* w, const float* bias, floa
 
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
-               int y_bf16, const TablesJob* tj, bool* tj_done) {
+               int y_bf16) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-    if (tj_done) *tj_done = false;
     if (abl_skip(N >= 16 ? (K == 3 ? "conv3_fwd_l" : (K == 1 ? "conv1_fwd_l" : "conv7_fwd_l")) : (K == 3 ? "conv3_fwd_g" : (K == 1 ? "conv1_fwd_g" : "conv7_fwd_g")))) return MEDT_OK;
     if (!y_bf16 && conv_stem7_ok(Cin, H, W, Cout, K, stride, pad))        // (medt_api.hip sizes the partial sums for it: conv_geom)
         return conv_stem7_fwd(x, w, bias, y, partials, N, H, W, Cout, relu, s);
@@ -307,11 +294,9 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
     if (conv_fwd_ws_ok(Cin, Cout, K, stride, (long)N * Ho * Wo))
         return conv2d_fwd_ws(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
     switch (K) {
-        case 1:
-            if (tj_done) *tj_done = tj && tj->L <= 256;
-            return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16, tj);
-        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16, nullptr);
-        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16, nullptr);
+        case 1: return conv2d_fwd_k<1>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
+        case 3: return conv2d_fwd_k<3>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
+        case 7: return conv2d_fwd_k<7>(x, w, bias, y, partials, N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, groups, s, y_bf16);
     }
     set_error("conv2d: kernel size %d unsupported (1, 3, 7)", K);
     return MEDT_EUNSUPPORTED;

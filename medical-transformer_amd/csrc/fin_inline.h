@@ -120,29 +120,6 @@ __device__ __forceinline__ void fin_slot_sums(const T* partials, int rows, int C
     s1 = fin_sum8(b);
 }
 
-// bn_qkv by the statistics kernel (axial_stats.hip): the NCH channels ch0 .. of one head from the qkv convolution's partial rows, by
-// every wave that calls it -- eight lanes per channel, eight channels per trip, one load round trip and ONE run of the double
-// arithmetic per trip.  scale / shift of the first GP channels (q | k: all the statistics kernel applies) are broadcast to every lane;
-// `writer`: this wave also saves all NCH channels (the attention kernel, the output pass and the backward read them from memory).
-template <int NCH, int GP>
-__device__ __forceinline__ void qkv_fin_inline(const FinSrc& s, int ch0, bool writer, float (&sc)[GP], float (&sh)[GP]) {
-    const int ln = threadIdx.x & 63, slot = ln >> 3, sub = ln & 7;
-#pragma unroll
-    for (int c0 = 0; c0 < NCH; c0 += 8) {
-        const int chl = min(c0 + slot, NCH - 1), ch = ch0 + chl;
-        double s1, s2;
-        fin_slot_sums(reinterpret_cast<const double*>(s.f.partials), s.f.ppg, s.f.CH, ch, sub, s1, s2);
-        const FinVals v = fin_vals(s1, s2, s.f.count, s.eps, s.f.weight[ch], s.f.bias[ch]);
-        if (writer && sub == 0 && c0 + slot < NCH) fin_save(s, ch, v);
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-            if (c0 + cc < GP) {
-                sc[c0 + cc] = fin_bcast(v.scale, cc * 8);
-                sh[c0 + cc] = fin_bcast(v.shift, cc * 8);
-            }
-    }
-}
-
 // Many rows: one WAVE sums channel ch (lane = row, strided by 64, then the xor tree) -- all of its lanes get the result.
 template <class T>
 __device__ __forceinline__ void fin_wave_sums(const T* partials, int rows, int CH, int ch, int lane, double& s0, double& s1) {

@@ -142,13 +142,14 @@ struct BwdWs {
 static int attention_core_bwd(const AxialGeom& g, const medt_axial_desc* d, const medt_axial_params* p, const BwdWs& w,
                               const float* qkv_raw, const float* stacked, const float* lse, const float* dy, const LayerStats& st,
                               GatePtrs gates, bool want_gates, float* d_sim_w, float* d_sim_b, hipStream_t s,
-                              const BfinSrc* ob = nullptr, bool sim_inline = false, const BfinSrc* qb = nullptr) {
+                              const BfinSrc* ob = nullptr, bool sim_inline = false, const BfinSrc* qb = nullptr,
+                              const float* ymask = nullptr) {
     const int tr = d->training ? 1 : 0;
     int rc;
     if (w.sweep) {
         if ((rc = axial_attn_bwd_sweep(g, w.plan, qkv_raw, st.qkv, st.sim, p->relative, gates, stacked, lse, dy, w.coef_out,
                                        d->stride, w.dqkv, w.part_qb, w.qb_rpg, w.part_sb, w.rel_part, w.pg_part, w.gram,
-                                       want_gates ? w.gate_raw : nullptr, s, w.raw32, ob))) return rc;
+                                       want_gates ? w.gate_raw : nullptr, s, w.raw32, ob, ymask))) return rc;
         AxialGeom gs = g;
         gs.tpg = w.plan.nparts;                               // part_sb rows per group
         SimBSrc sb = no_simb_src();
@@ -329,25 +330,18 @@ int medt_axial_layer_fwd(const medt_axial_desc* d, const medt_axial_params* p, c
                             d->momentum, d->eps, tr, s);
     }
     // qkv_transform (1x1 conv over channels, axis-agnostic on NCHW) + bn_qkv batch statistics      :151
-    // Round 6 (fin_inline.h), second step: bn_qkv is finalised by the statistics kernel that consumes it (every workgroup for the
-    // channels of its head, the first workgroup of the head saves them), and the sliding-window tables of that kernel ride on the
-    // qkv convolution's launch instead of on the bn_finalize launch that is gone: 5 launches per layer become 4.
-    const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
-    const bool qkv_inl_ok = inline_fin_ok(tr, g.groups, ppg);
-    bool tj_done = false;
     if ((rc = conv2d_fwd(x, p->w_qkv, nullptr, qkv_raw, tr ? w.part_qkv : nullptr, w.qkv_ksplit, g.N, g.C, g.H, g.W,
-                         2 * g.C, 1, 1, 0, 0, g.groups, s, g.bf16, qkv_inl_ok ? &tj : nullptr, &tj_done))) return rc;
-    const bool qkv_inl = qkv_inl_ok && tj_done;
-    // (else: a bn_finalize launch, + the sliding-window tables of the statistics kernel below as extra blocks of it)
-    if (!qkv_inl && (rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
-                                      st.qkv, s, &tj))) return rc;
+                         2 * g.C, 1, 1, 0, 0, g.groups, s, g.bf16))) return rc;
+    // (+ the sliding-window tables of the statistics kernel below as extra blocks of this launch)
+    const TablesJob tj{p->relative, w.tables, g.hq, g.L, tr ? sim_tables_blocks(g) : 0};
+    if ((rc = bn_finalize(w.part_qkv, ppg, g.groups, 2 * g.C, g.row_count, p->bn_qkv, d->momentum, d->eps, tr,
+                          st.qkv, s, &tj))) return rc;
+    // (round 6, measured and removed: bn_qkv finalised by the statistics kernel itself -- every workgroup for the channels of its
+    //  head from the qkv convolution's partial rows, the tables riding on the convolution's launch -- one launch fewer per layer
+    //  and SLOWER: the load round trip + double arithmetic in front of the statistics kernel's own loads cost more than the 5-us
+    //  launch they replace (gatedaxialunet bs 8: 3.95 vs 3.86 ms, MedT 128: 1.881 vs 1.874; profiles/r06_qkv_inline_ab.txt))
     // bn_similarity batch statistics over the (never materialised) logits                         :166-167
-    FinSrc qkv_src = no_fin_src();
-    if (qkv_inl) {
-        qkv_src.f = make_fin(w.part_qkv, ppg, 2 * g.C, g.row_count, p->bn_qkv, st.qkv);
-        qkv_src.momentum = d->momentum; qkv_src.eps = d->eps; qkv_src.on = 1;
-    }
-    if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s, qkv_inl ? &qkv_src : nullptr))) return rc;
+    if (tr && (rc = axial_logit_stats(g, qkv_raw, st.qkv, p->relative, gates, w.tables, w.part_sim, s))) return rc;
     // Round 6 (fin_inline.h): inside the networks (training mode, one BatchNorm group, few partial rows) bn_similarity and bn_output
     // are finalised by the kernels that consume them -- the attention kernel and the output pass -- instead of by a bn_finalize
     // launch each: 7 launches per layer become 5.
@@ -407,9 +401,16 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         return conv2d_bwd_weight(w.dqkv, qkv_raw, w.coef_qkv, x, gr->w_qkv, w.dw_scratch, g.N, g.C, g.H, g.W, 2 * g.C,
                                  1, 1, 0, g.groups, s, queue_for(s));
     }
+    const float* ymask = nullptr;
     if (d->out_relu) {               // fused ReLU after the layer: mask the incoming gradient by the output sign
-        if ((rc = relu_mask(dy, y, w.dy_masked, (size_t)g.N * g.C * (g.H / d->stride) * (g.W / d->stride), s))) return rc;
-        dy = w.dy_masked;
+#ifndef MEDT_AB_NO_MASK_FUSE           // (A/B build: medt_amd.build.build_ab)
+        // (round 6: the single sweep and the statistics kernel in front of it apply the mask as they load dy -- no relu_mask launch)
+        if (w.sweep) ymask = y;
+#endif
+        if (!ymask) {
+            if ((rc = relu_mask(dy, y, w.dy_masked, (size_t)g.N * g.C * (g.H / d->stride) * (g.W / d->stride), s))) return rc;
+            dy = w.dy_masked;
+        }
     }
     // AvgPool + bn_output backward (statistics, then coefficients applied on load downstream)
     const float out_dscale = 1.f / (float)(d->stride * d->stride);
@@ -417,7 +418,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
     const bool sim_inl = w.sweep && g.pos && inline_fin_ok(tr, g.groups, w.plan.nparts) &&
                          axial_out_bwd_stats_tables_ok(*d, sim_tables_blocks(g), g.L);
     const TablesJob btj{p->relative, w.tables, g.hq, g.L, sim_tables_blocks(g)};
-    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s, sim_inl ? &btj : nullptr))) return rc;
+    if ((rc = axial_out_bwd_stats(*d, stacked, dy, st.out, w.part_ob, s, sim_inl ? &btj : nullptr, ymask))) return rc;
     // (round 6, fin_inline.h: where the single sweep runs inside the networks, IT derives bn_output's backward coefficients from the
     //  partial rows and its first workgroup per head writes them and the parameter gradients -- no bn_bwd_finalize launch)
     BfinSrc ob = no_bfin_src();
@@ -438,7 +439,7 @@ int medt_axial_layer_bwd(const medt_axial_desc* d, const medt_axial_params* p, c
         qb.on = 1;
     }
     if ((rc = attention_core_bwd(g, d, p, w, qkv_raw, stacked, sv->lse, dy, st, gates, gr->gates != nullptr,
-                                 gr->bn_sim_weight, gr->bn_sim_bias, s, ob.on ? &ob : nullptr, sim_inl, qb.on ? &qb : nullptr))) return rc;
+                                 gr->bn_sim_weight, gr->bn_sim_bias, s, ob.on ? &ob : nullptr, sim_inl, qb.on ? &qb : nullptr, ymask))) return rc;
     // bn_qkv backward, qkv_transform backward
     const float *bq_raw = qkv_raw, *bq_coef = w.coef_qkv;
     static const bool bf16_fused = true;

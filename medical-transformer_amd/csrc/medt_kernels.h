@@ -47,8 +47,9 @@ int bn_bwd_fin_apply_bf16(const float* partials, int ppg, int groups, int CH, do
 // tj (optional): the launch's first tj->blocks workgroups also build the sliding-window tables of the layer's relative table (what
 // sim_bwd_finalize's appended blocks build otherwise -- axial_out_bwd_stats_tables_ok() says whether the grid has room)
 bool axial_out_bwd_stats_tables_ok(const medt_axial_desc& d, int blocks, int L);
+// ymask (optional): the layer's output y of a fused output ReLU -- dy counts where y > 0 (no relu_mask launch in front)
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st,
-                        float* partials, hipStream_t s, const TablesJob* tj = nullptr);
+                        float* partials, hipStream_t s, const TablesJob* tj = nullptr, const float* ymask = nullptr);
 
 // out[k] = sum_p in[p][k]
 int reduce_rows(const float* in, int P, int K, float* out, hipStream_t s);
@@ -69,11 +70,9 @@ int conv_stem7_parts_per_group(int N, int groups, int HoWo);
 int conv_stem7_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, int N, int H, int W, int Cout,
                    int relu, hipStream_t s);
 // y_bf16: store y as bfloat16 (VALU path only: the 1x1 qkv_transform of a bf16-storage attention layer)
-// tj / tj_done (optional): the sliding-window tables of the layer's statistics kernel as extra workgroups of THIS launch; *tj_done says
-// whether the kernel that ran took them (the generic 1x1 kernel does) -- if not, the caller builds them elsewhere (bn_finalize)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s,
-               int y_bf16 = 0, const TablesJob* tj = nullptr, bool* tj_done = nullptr);
+               int y_bf16 = 0);
 size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad);
 // wt_scratch: Cout*Cin*K*K floats (used by the MFMA path for the flipped weights; may be NULL -> VALU path)
 // add (optional): dx = dgrad + add -- the other gradient contributions of a fanned-out input, summed in the epilogue
@@ -232,11 +231,8 @@ bool fast_path_enabled();       // MEDT_DISABLE_FAST=1 forces the generic kernel
 size_t sim_tables_floats(const AxialGeom& g);
 int sim_tables_blocks(const AxialGeom& g);
 int sim_stats_parts(const AxialGeom& g);
-// qsrc (optional, fin_inline.h): bn_qkv is finalised by the statistics kernel itself from the qkv convolution's partial rows and saved
-// by its first workgroups -- `qkv` is written, not read; no bn_finalize launch in front (the tables then come from the convolution
-// launch: conv2d_fwd's TablesJob)
 int axial_logit_stats(const AxialGeom& g, const float* qkv_raw, BnStats qkv, const float* relative, GatePtrs gates,
-                      const float* tables, float* partials, hipStream_t s, const FinSrc* qsrc = nullptr);
+                      const float* tables, float* partials, hipStream_t s);
 // fused attention: stacked, lse, bn_output partials [group][tile][OC][2] (may be NULL)
 // simsrc (optional, fin_inline.h; only where axial_attn_fwd_inlines()): bn_similarity is finalised by the kernel itself from the
 // statistics kernel's partial rows -- `sim` is not read, no bn_finalize launch in front
@@ -279,7 +275,8 @@ int axial_attn_bwd_sweep(const AxialGeom& g, const SweepPlan& p, const float* qk
                          const float* relative, GatePtrs gates, const float* stacked, const float* lse, const float* dy,
                          const float* out_coef, int stride, float* dqkv, float* part_qb, int qb_rpg, float* part_sb,
                          float* rel_part, float* pg_part, float* gram, float* gate_raw, hipStream_t s, float* raw32 = nullptr,
-                         const BfinSrc* ob = nullptr);       // ob (fin_inline.h): bn_output's backward finalised by the sweep, out_coef not read
+                         const BfinSrc* ob = nullptr,        // ob (fin_inline.h): bn_output's backward finalised by the sweep, out_coef not read
+                         const float* ymask = nullptr);      // ymask: the layer's output y (fused output ReLU) -- dy counts where y > 0
 // u / w terms of dq | dk (apply != 0: training mode) and the bn_qkv partial rows [nparts, nparts + fparts) (q | k channels)
 int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_raw, BnStats qkv, const float* sim_coef,
                        const float* tables, const float* gram, GatePtrs gates, int apply, float* dqkv, float* part_qb,

@@ -678,7 +678,8 @@ int axial_out_fwd(const medt_axial_desc& d, const float* stacked, BnStats st, fl
 __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const float* __restrict__ stk,
                                                                            const float* __restrict__ dy, BnStats st,
                                                                            float* __restrict__ partials, int C, int H,
-                                                                           int W, int OC, int stride, int npg, int bf16, TablesJob tj) {
+                                                                           int W, int OC, int stride, int npg, int bf16, TablesJob tj,
+                                                                           const float* __restrict__ ymask) {
     MEDT_STATIC_SHARED float red[MEDT_WAVES * 2];
     if (blockIdx.y == 0 && (int)blockIdx.x < tj.blocks) {        // (fin_inline.h: the fix kernel's tables, no launch of their own)
         MEDT_STATIC_SHARED float tl[512];
@@ -695,7 +696,9 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
         const int h = p / W, w = p - h * W;
         const int ho = h / stride, wo = w / stride;
         if (ho < Ho && wo < Wo) {
-            const float d = dy[((size_t)(n * C + c) * Ho + ho) * Wo + wo];
+            const size_t di = ((size_t)(n * C + c) * Ho + ho) * Wo + wo;
+            float d = dy[di];
+            if (ymask) d = ymask[di] > 0.f ? d : 0.f;            // (fused output ReLU: its backward on load, see the sweep)
             const float xh = (ld_act(stk, ((size_t)n * OC + ch) * HW + p, bf16) - st.mean[grp * OC + ch]) * st.rstd[grp * OC + ch];
             v[0] = d;
             v[1] = d * xh;
@@ -709,13 +712,13 @@ bool axial_out_bwd_stats_tables_ok(const medt_axial_desc& d, int blocks, int L) 
 }
 
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, float* partials,
-                        hipStream_t s, const TablesJob* tjp) {
+                        hipStream_t s, const TablesJob* tjp, const float* ymask) {
     const int OC = d.has_pos ? 2 * d.C : d.C;
     const int npg = d.N / d.bn_groups, ppg = cdiv(npg * d.H * d.W, MEDT_THREADS);
     const TablesJob tj = tjp ? *tjp : TablesJob{nullptr, nullptr, 0, 0, 0};
     if (tj.blocks && !axial_out_bwd_stats_tables_ok(d, tj.blocks, tj.L)) { set_error("axial_out_bwd_stats: no room for the table blocks"); return MEDT_EINVAL; }
     hipLaunchKernelGGL(axial_out_bwd_stats_kernel, dim3(d.bn_groups * ppg, OC), dim3(MEDT_THREADS), 0, s, stacked, dy, st,
-                       partials, d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype, tj);
+                       partials, d.C, d.H, d.W, OC, d.stride, npg, d.act_dtype, tj, ymask);
     return launch_status("axial_out_bwd_stats");
 }
 

@@ -53,6 +53,15 @@ def build_ablate(verbose: bool = False) -> str:
     return build(force=True, verbose=verbose, defines=("-DMEDT_ABLATE",), lib_path=ABLATE_LIB_PATH, obj_dir="build_ablate")
 
 
+AB_LIB_PATH = os.path.join(PKG_DIR, "libmedt_ab.so")
+
+
+def build_ab(*defines: str, verbose: bool = False) -> str:
+    """libmedt_ab.so: the same sources with compile-time A/B switches (-DMEDT_AB_...: the side of a kernel experiment that is NOT the
+    product's) -- loaded through MEDT_LIB_OVERRIDE by the A/B scripts, so the product library itself carries no switch for it."""
+    return build(force=True, verbose=verbose, defines=tuple(defines), lib_path=AB_LIB_PATH, obj_dir="build_ab")
+
+
 def asan_runtime() -> str:
     """Path of the AddressSanitizer runtime a non-instrumented python has to LD_PRELOAD before loading libmedt_asan.so."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

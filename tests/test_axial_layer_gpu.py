@@ -134,6 +134,44 @@ def test_layer_vs_oracle(case, training, device):
     compare(got, want)
 
 
+@pytest.mark.parametrize("case", [("dynamic", 16, 64, True, 1, 2, 8), ("dynamic", 32, 64, False, 2, 2, 64), ("dynamic", 32, 32, True, 1, 3, 5),
+                                  ("plain", 32, 128, False, 1, 1, 6), ("dynamic", 64, 16, False, 1, 3, 16), ("wopos", 16, 16, False, 1, 4, 16)],
+                         ids=lambda c: "-".join(str(v) for v in c))
+def test_layer_fused_output_relu_vs_oracle(case, device):
+    """The width layer of an AxialBlock runs with its ReLU fused (out_relu): round 6 applies the ReLU's backward inside the single
+    sweep and the statistics kernel in front of it (mask on load, no relu_mask launch); the generic kernels (gp = 8 here) and the
+    small position-free layers keep their own handling.  Oracle: relu(axial_attention(x)) in float64."""
+    kind, C, L, width, stride, N, other = case
+    layer = make_layer(kind, C, L, width, stride, device)
+    st = O.randomize_state({k: v.cpu() for k, v in layer.state_dict().items()}, 300 + C + L)
+    g = torch.Generator().manual_seed(11 + L)
+    shape = (N, C, other, L) if width else (N, C, L, other)
+    x = torch.randn(shape, generator=g)
+    dout = torch.randn((N, C, shape[2] // stride, shape[3] // stride), generator=g)
+    layer.load_state_dict(st)
+    for p in layer.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    layer.train(True)
+    xg = x.to(device).float().clone().requires_grad_(True)
+    y = layer.run(xg, 1, True)
+    (y * dout.to(device).float()).sum().backward()
+    torch.cuda.synchronize()
+    got = {"y": y.detach(), "dx": xg.grad}
+    for k, p in layer.named_parameters():
+        got["grad/" + k] = p.grad if p.grad is not None else torch.zeros_like(p)
+    ost = O.clone_state({("m." + k): v for k, v in st.items()}, torch.float64, requires_grad=True)
+    xo = x.double().requires_grad_(True)
+    yo = torch.relu(O.axial_attention(xo, ost, "m", width, stride, True, 1, gate_mode="raw"))
+    (yo * dout.double()).sum().backward()
+    want = {"y": yo.detach(), "dx": xo.grad}
+    for k, _ in layer.named_parameters():
+        gr = ost["m." + k].grad
+        want["grad/" + k] = gr if gr is not None else torch.zeros_like(ost["m." + k])
+    assert (want["y"] == 0).float().mean().item() > 0.2          # (the mask matters on this input)
+    compare(got, want)
+
+
 @pytest.mark.parametrize("kind,C,L,width,stride", [("wopos", 16, 16, False, 1), ("wopos", 32, 8, True, 2),
                                                    ("dynamic", 16, 16, True, 1), ("dynamic", 16, 32, True, 1),
                                                    ("plain", 32, 32, False, 2)])
