@@ -214,59 +214,7 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     const float e_qk = a.ss.scale[grp * g.SC + hg], e_qr = a.ss.scale[grp * g.SC + g.G + hg],
                 e_kr = a.ss.scale[grp * g.SC + 2 * g.G + hg];
     const float s_qk = e_qk * MEDT_LOG2E, s_qr = e_qr * f_qr * MEDT_LOG2E, s_kr = e_kr * f_kr * MEDT_LOG2E;
-    // ---- tables: record d = { Rq[c][d] | Rk[c][2L-2-d] | Rv[c][d] } ---------------------------------------------
-    for (int e = threadIdx.x; e < (TL + 1) * TREC; e += nthreads) {
-        const int d = e / TREC, r = e - d * TREC;
-        float v = 0.f;
-        if (d < TL && r < NT) v = (r >= HQ && r < GP) ? a.relative[r * TL + (TL - 1 - d)] : a.relative[r * TL + d];
-        tab[e] = v;
-    }
-    for (int e = threadIdx.x; e < nw * (2 * NT * L + L * NPG); e += nthreads) wacc[e] = 0.f;        // wacc | pg contiguous
     float sc[NCH], sh[NCH], vmean[GP], vrstd[GP], cf[NCH][3];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        sc[ch] = a.qs.scale[grp * 2 * g.C + hg * NCH + ch];
-        sh[ch] = a.qs.shift[grp * 2 * g.C + hg * NCH + ch];
-        if (!a.ob.on || MEDT_ABL == 10) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) cf[ch][k] = a.out_coef[((size_t)grp * g.OC + hg * NCH + ch) * 3 + k];
-        }
-    }
-    if (a.ob.on && MEDT_ABL != 10) {
-        // bn_output's backward finalised HERE (fin_inline.h: no bn_bwd_finalize launch in front of the sweep).  Eight lanes per
-        // channel, eight channels of the head at a time: every wave sums the partial rows (one load round trip), runs the double
-        // arithmetic once for all of them and broadcasts the three coefficients per channel; the first workgroup of the head writes
-        // the coefficients and the parameter gradients (one BatchNorm group).
-        const BfinJob& j = a.ob.j;
-        const int ln = threadIdx.x & 63, slot = ln >> 3, sub = ln & 7;
-#pragma unroll
-        for (int c0 = 0; c0 < NCH; c0 += 8) {
-            const int chl = min(c0 + slot, NCH - 1), chg = hg * NCH + chl;
-            double s1, s2;
-            fin_slot_sums(j.partials, j.ppg, g.OC, chg, sub, s1, s2);
-            s1 *= j.dscale;
-            s2 *= j.dscale;
-            float c3[3];
-            bn_bwd_coef(s1, s2, j.count, j.dscale, j.st.mean[chg], j.st.rstd[chg], j.weight[chg], j.training, c3);
-            if (blockIdx.x == 0 && threadIdx.x < 64 && sub == 0 && c0 + slot < NCH) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) j.coef[(size_t)chg * 3 + k] = c3[k];
-                if (j.dweight) j.dweight[chg] = (float)s2;
-                if (j.dbias) j.dbias[chg] = (float)s1;
-            }
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc)
-                if (c0 + cc < NCH) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) cf[c0 + cc][k] = fin_bcast(c3[k], cc * 8);
-                }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < GP; ++c) {
-        vmean[c] = a.qs.mean[grp * 2 * g.C + hg * NCH + GP + c];
-        vrstd[c] = a.qs.rstd[grp * 2 * g.C + hg * NCH + GP + c];
-    }
     // sums over everything this workgroup sees
     float T_qk = 0.f, T_qr = 0.f, T_kr = 0.f, g_pe = 0.f, g_pv = 0.f;
     float vst[2 * GP];                                        // bn_qkv backward partials of the v channels
@@ -298,6 +246,9 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     constexpr bool QA_REC = RREC - (HQ + 2 * GP + 2) >= HQ;   // room in the row record for q * s_qk (one multiply less per row)
     // (measured on the C=16 L=64 B*=16384 shape: 0.87 ms with the tile prefetch against 0.72 ms without -- kept off)
     constexpr bool TPF = false && GP == 2 && D <= 4;
+    // (round 6) the wide instances (the launches inside the networks) keep the tile's raw v values in registers for bn_qkv's backward
+    // sums at the end instead of reading them again: one memory round trip less in the epilogue of a one-tile workgroup
+    constexpr bool KEEP_V = !TPF && LS == 32 && MEDT_ABL != 31;
     struct TileRegs { float raw[D][NCH], stk[D][NCH], dyv[D][GP], lse[D]; };
     auto issue_t = [&](int tile_, TileRegs& r, auto bf) {
         constexpr bool BF = decltype(bf)::value;              // (compile-time storage type: no branch per load)
@@ -397,11 +348,82 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
         }
     };
     TileRegs pf;
-    if (TPF && part < a.tiles) issue(part, pf);
+    // (only the gp <= 4 instances that run inside the networks -- 32 lanes per sequence or two columns per lane: the narrow instances of
+    //  the bandwidth shapes would spill, and the gp >= 8 instances at 256 registers measured SLOWER with it: <16,16,16> 58.7 -> 69.4 us)
+    constexpr bool EARLY = GP <= 4 && (LS == 32 || D <= 2);
+    if (EARLY && MEDT_ABL != 21 && MEDT_ABL != 32 && part < a.tiles) issue(part, pf);     // the first tile's loads: in flight during the whole set-up below
+    MEDT_SCHED_FENCE();
+    // ---- tables: record d = { Rq[c][d] | Rk[c][2L-2-d] | Rv[c][d] } ---------------------------------------------
+    // (round 6: inside the networks a workgroup sees ONE tile, and its prologue was four dependent memory round trips -- table entries
+    //  one per loop trip, coefficients, the partial rows of the consumer-side finalisation, the tile -- 11 us of a 33-us launch without
+    //  its row loop, profiles/r06_sweep_phases.txt.  Now the first tile's loads are issued first, the table entries behind them as one
+    //  batch of independent loads, and everything else follows while they fly)
+    constexpr int NTB = ((TL + 1) * TREC + 63) / 64;          // table entries per thread of a one-wave workgroup
+    float tb[NTB];
+#pragma unroll
+    for (int k = 0; k < NTB; ++k) {
+        const int e = threadIdx.x + k * nthreads, d = e / TREC, r = e - d * TREC;
+        float v = 0.f;
+        if (MEDT_ABL != 20 && e < (TL + 1) * TREC && d < TL && r < NT)
+            v = (r >= HQ && r < GP) ? a.relative[r * TL + (TL - 1 - d)] : a.relative[r * TL + d];
+        tb[k] = v;
+    }
+    MEDT_SCHED_FENCE();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        sc[ch] = a.qs.scale[grp * 2 * g.C + hg * NCH + ch];
+        sh[ch] = a.qs.shift[grp * 2 * g.C + hg * NCH + ch];
+        if (!a.ob.on || MEDT_ABL == 10) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cf[ch][k] = a.out_coef[((size_t)grp * g.OC + hg * NCH + ch) * 3 + k];
+        }
+    }
+    if (a.ob.on && MEDT_ABL != 10) {
+        // bn_output's backward finalised HERE (fin_inline.h: no bn_bwd_finalize launch in front of the sweep).  Eight lanes per
+        // channel, eight channels of the head at a time: every wave sums the partial rows (one load round trip), runs the double
+        // arithmetic once for all of them and broadcasts the three coefficients per channel; the first workgroup of the head writes
+        // the coefficients and the parameter gradients (one BatchNorm group).
+        const BfinJob& j = a.ob.j;
+        const int ln = threadIdx.x & 63, slot = ln >> 3, sub = ln & 7;
+#pragma unroll
+        for (int c0 = 0; c0 < NCH; c0 += 8) {
+            const int chl = min(c0 + slot, NCH - 1), chg = hg * NCH + chl;
+            double s1, s2;
+            fin_slot_sums(j.partials, j.ppg, g.OC, chg, sub, s1, s2);
+            s1 *= j.dscale;
+            s2 *= j.dscale;
+            float c3[3];
+            bn_bwd_coef(s1, s2, j.count, j.dscale, j.st.mean[chg], j.st.rstd[chg], j.weight[chg], j.training, c3);
+            if (blockIdx.x == 0 && threadIdx.x < 64 && sub == 0 && c0 + slot < NCH) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) j.coef[(size_t)chg * 3 + k] = c3[k];
+                if (j.dweight) j.dweight[chg] = (float)s2;
+                if (j.dbias) j.dbias[chg] = (float)s1;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (c0 + cc < NCH) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) cf[c0 + cc][k] = fin_bcast(c3[k], cc * 8);
+                }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < GP; ++c) {
+        vmean[c] = a.qs.mean[grp * 2 * g.C + hg * NCH + GP + c];
+        vrstd[c] = a.qs.rstd[grp * 2 * g.C + hg * NCH + GP + c];
+    }
+#pragma unroll
+    for (int k = 0; k < NTB; ++k) {
+        const int e = threadIdx.x + k * nthreads;
+        if (MEDT_ABL != 20 && e < (TL + 1) * TREC) tab[e] = tb[k];
+    }
+    for (int e = threadIdx.x; e < (MEDT_ABL == 27 ? 0 : nw * (2 * NT * L + L * NPG)); e += nthreads) wacc[e] = 0.f;        // wacc | pg contiguous
     for (int tile = part; tile < a.tiles; tile += a.nparts) {
         const int seq0 = tile * S_T, nseq = min(S_T, g.spg - seq0);
         __syncthreads();                                      // the previous tile's outputs have been read
-        if (!TPF) issue(tile, pf);
+        if (MEDT_ABL == 21) { float* z = reinterpret_cast<float*>(&pf); for (int k = 0; k < (int)(sizeof(pf) / 4); ++k) z[k] = 0.01f * k; }
+        else if (!TPF && (tile != part || !EARLY || MEDT_ABL == 32)) issue(tile, pf);
         commit(tile, pf);
         __syncthreads();
         if (TPF && tile + a.nparts < a.tiles) issue(tile + a.nparts, pf);          // in flight during the sweep below
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
             }
         }
         // per-sequence Gram matrices / sums of q and k (the fix kernel's operands) and the per-position products
-        {
+        if (MEDT_ABL != 22) {
             float pr[D][NPG], gsum[NPG];
 #pragma unroll
             for (int m = 0; m < NPG; ++m) gsum[m] = 0.f;
@@ -476,14 +498,16 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
 #endif
         // the row record (and the table entry that enters the chain behind it) of row i + 1 is fetched while row i is
         // computed: the loads sit in front of the row's exit store, whose address the compiler cannot tell apart
-        constexpr bool PREFETCH = GP == 2 && MEDT_ABL != 5;                   // (gp = 4: the 20 extra registers spill)
+        // (gp = 4: 20 more registers; measured at 32 lanes per sequence in round 6, where they fit: no gain -- the row loop of a wave that
+        //  has its SIMD to itself is bound by its 185 instructions per row, not by the LDS round trip)
+        constexpr bool PREFETCH = GP == 2 && MEDT_ABL != 5;
         float nrec[RREC], nfr[TREC];
 #pragma unroll
         for (int k = 0; k < RREC; ++k) nrec[k] = rrow[k];
 #pragma unroll
         for (int k = 0; k < TREC; ++k) nfr[k] = tab[L * TREC + k];
 #pragma unroll 1
-        for (int it = 0; it < (MEDT_ABL == 6 ? 0 : LS); ++it) {
+        for (int it = 0; it < ((MEDT_ABL == 6 || MEDT_ABL >= 20) ? 0 : LS); ++it) {
             const bool owner = cb == it;                      // this lane's columns are the rows of this iteration
 #pragma unroll
             for (int t = 0; t < D; ++t) {
@@ -607,7 +631,7 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
         // this lane folds d = its own D positions) and the ones still in the chain (d = 2L-2-j; slot s sits in physical
         // (s + 1) % D after the last row); the sequences of the wave are summed lane-wise, sequence 0's lanes accumulate
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
+        for (int s = 0; s < (MEDT_ABL == 23 ? 0 : D); ++s) {
             const int p = (s + 1) % D;
             const int j = cb * D + s;
             const float* pk = crow + j;                           // parked[m][j]
@@ -645,7 +669,7 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
         __syncthreads();
         // ---- write dqkv (NCHW), bn_qkv backward partials of the v channels (raw v re-read: L2-resident) --------------------
 #pragma unroll
-        for (int kk = 0; kk < D; ++kk) {
+        for (int kk = 0; kk < (MEDT_ABL == 24 ? 0 : D); ++kk) {
             int ls2, i2, n, h, w;
             if (locate(kk, seq0, nseq, ls2, i2, n, h, w)) {
                 const float* cr = colrec + (ls2 * L + i2) * CREC;
@@ -656,9 +680,14 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(obase) + ooff + (unsigned)(ch * g.HW) * 4u) = cr[ch];
 #pragma unroll
                 for (int c = 0; c < GP; ++c) {
-                    const unsigned o = ((unsigned)n * 2u * g.C * g.HW + pix + (unsigned)((GP + c) * g.HW)) * (unsigned)es;
-                    const float rv = g.bf16 ? bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(qbase + o))
-                                            : *reinterpret_cast<const float*>(qbase + o);
+                    float rv;
+                    if constexpr (KEEP_V) {
+                        rv = pf.raw[kk][GP + c];              // (the tile's own registers: same thread, same element as in `issue`)
+                    } else {
+                        const unsigned o = ((unsigned)n * 2u * g.C * g.HW + pix + (unsigned)((GP + c) * g.HW)) * (unsigned)es;
+                        rv = g.bf16 ? bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(qbase + o))
+                                    : *reinterpret_cast<const float*>(qbase + o);
+                    }
                     const float d = cr[GP + c];
                     vst[2 * c] += d;
                     vst[2 * c + 1] = fmaf(d, (rv - vmean[c]) * vrstd[c], vst[2 * c + 1]);
@@ -669,31 +698,37 @@ __global__ __launch_bounds__(MEDT_THREADS, (L > 64 || GP >= 8) ? 1 : 2) void att
     // ---- workgroup results ------------------------------------------------------------------------------------------
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;       // (head, group, part)
-    if (MEDT_ABL != 11) {   // table gradients: waves in fixed order, the per-head scales, `relative`'s layout (Rk rows reversed back)
+    if (MEDT_ABL != 11 && MEDT_ABL != 25) {   // table gradients: waves in fixed order, the per-head scales, `relative`'s layout (Rk rows reversed back)
         float* rp = a.rel_part + blk * NCH * TL;
         const float sq = f_qr * e_qr, sk = f_kr * e_kr, sv = GATES ? f_sve : 1.f;
-        for (int e = threadIdx.x; e < NCH * TL; e += nthreads) {
-            const int r = e / TL, d = e - r * TL;
-            const int dd = (r >= HQ && r < GP) ? TL - 1 - d : d;
-            const int half = dd >= L - 1, j = half ? 2 * L - 2 - dd : dd;
-            const int idx = half * NT * L + (r * D + j % D) * LS + j / D;
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += wacc[w * 2 * NT * L + idx];
-            rp[e] = s * (r < HQ ? sq : (r < GP ? sk : sv));
+        // (round 6: a row r of the table per trip of the outer loop -- no division by TL = 2L - 1 per element, the LDS reads of a
+        //  trip independent of each other; same sums in the same order)
+#pragma unroll
+        for (int r = 0; r < NCH; ++r) {
+            const float scale = r < HQ ? sq : (r < GP ? sk : sv);
+            for (int d = threadIdx.x; d < TL; d += nthreads) {
+                const int dd = (r >= HQ && r < GP) ? TL - 1 - d : d;
+                const int half = dd >= L - 1, j = half ? 2 * L - 2 - dd : dd;
+                const int idx = half * NT * L + (r * D + j % D) * LS + j / D;
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w) s += wacc[w * 2 * NT * L + idx];
+                rp[r * TL + d] = s * scale;
+            }
         }
         float* pp = a.pg_part + blk * L * NPG;
-        for (int e = threadIdx.x; e < L * NPG; e += nthreads) {
-            const int j = e / NPG, m = e - j * NPG;
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += pg[w * L * NPG + (m * D + j % D) * LS + j / D];
-            pp[e] = s;
-        }
+#pragma unroll
+        for (int m = 0; m < NPG; ++m)
+            for (int j = threadIdx.x; j < L; j += nthreads) {
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w) s += pg[w * L * NPG + (m * D + j % D) * LS + j / D];
+                pp[j * NPG + m] = s;
+            }
     }
-    {
+    if (MEDT_ABL != 26) {
         float v[4] = {0.f, T_qk, f_qr * T_qr, f_kr * T_kr};     // sum dZ * {1, S_qk, S_qr, S_kr}
         wg_sum<4>(v, red, a.part_sb + ((size_t)blockIdx.x * g.G + hg) * 4, nw);
     }
-    {
+    if (MEDT_ABL != 26) {
         // bn_qkv backward partials [group][row][2C][2]: this head's v channels; its q | k columns are written as zeros
         // (attn_bwd_fix_kernel's rows carry those)
         float* dst = a.part_qb + ((size_t)(grp * a.qb_rpg + part) * 2 * g.C + hg * NCH) * 2;

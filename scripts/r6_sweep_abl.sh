@@ -5,7 +5,7 @@
 #   on the box:  bash scripts/r6_sweep_abl.sh run
 cd "$(dirname "$0")/.."
 C=medical-transformer_amd/csrc
-NS="6 10 11"
+NS="${NS:-6 10 11}"
 if [ "$1" = build ]; then
   mkdir -p $C/build/abl
   for n in $NS; do
@@ -21,7 +21,7 @@ else
   O=gpurun_out/r6_sweep_abl; rm -rf $O; mkdir -p $O
   for n in 0 $NS; do
     [ $n = 0 ] && unset MEDT_LIB_OVERRIDE || export MEDT_LIB_OVERRIDE=$GRAFT_REPO_ROOT/medical-transformer_amd/libmedt_abl$n.so
-    for cfg in "medt --model MedT" "gated --model gatedaxialunet --batch 8"; do
+    for cfg in "medt --model MedT" ${ABL_GATED:+"gated --model gatedaxialunet --batch 8"}; do
       set -- $cfg; name=$1; shift
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -- python bench.py "$@" --no-cpu-baseline --no-roofline --steps 20 --warmup 5 > $O/log_${n}_$name.txt 2>&1
       S=$(ls -S $(find $O/p -name "*kernel_stats.csv") | head -1)
