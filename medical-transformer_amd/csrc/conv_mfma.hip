@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <vector>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace medt {
 
@@ -1563,6 +1564,16 @@ int conv_wgrad_grouped(const WJob* jobs, int n, hipStream_t s) {
     int blocks = 0;
     auto launch = [&]() -> int {
         b.start[b.n] = blocks;
+#ifdef MEDT_ABLATE                      // (timing-experiment build only: the job table of a launch, MEDT_WG_DEBUG=1 -> profiles/r06_wgrad_jobs.txt)
+        if (getenv("MEDT_WG_DEBUG")) {
+            fprintf(stderr, "wgrad grouped: %d jobs, %d blocks\n", b.n, blocks);
+            for (int j = 0; j < b.n; ++j) {
+                const WJobP& w = b.job[j];
+                fprintf(stderr, "  wjob K%d v4 %d Cout %3d Cin %3d HoWo %3dx%3d N %2d QS %4d blocks %4d (o-tiles %d k-tiles %d chunks %d)\n", (int)w.K, (int)w.v4,
+                        w.Cout, w.Cin, w.Ho, w.Wo, w.N, w.QS, b.start[j + 1] - b.start[j], (w.Cout + 31) / 32, (w.Cin * w.K * w.K + 63) / 64, w.gz);
+            }
+        }
+#endif
         hipLaunchKernelGGL(conv_wgrad_mfma_grouped_kernel<32>, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
         b.n = 0;
         blocks = 0;
