@@ -755,11 +755,10 @@ struct FixArgs {
     SimBSrc sb;                    // on: bn_similarity's backward coefficients are derived here from the sweep's partial rows (fin_inline.h)
 };
 
-constexpr int FIX_PPT = 4;
 
 // (BF: the storage type of qkv_raw at compile time -- with the runtime flag inside ld_act every load sat in its own branch, one global
 //  round trip per channel: +7 us per launch with bf16 storage, round 6)
-template <int HQ, bool BF>
+template <int HQ, bool BF, int FIX_PPT>
 __device__ __forceinline__ void attn_bwd_fix_body(const FixArgs& a, float* red) {
     constexpr int GP = 2 * HQ, NCH = 2 * GP, NP = HQ * (HQ + 1) / 2, NPG = 2 * (NP + HQ), NR = HQ + NP;
     const AxialGeom& g = a.g;
@@ -844,11 +843,11 @@ __device__ __forceinline__ void attn_bwd_fix_body(const FixArgs& a, float* red) 
     block_sum<4 * HQ>(v, red, dst);
 }
 
-template <int HQ>
+template <int HQ, int PPT>
 __global__ __launch_bounds__(MEDT_THREADS) void attn_bwd_fix_kernel(FixArgs a) {
     MEDT_STATIC_SHARED float red[MEDT_WAVES * 4 * HQ];
-    if (a.g.bf16) attn_bwd_fix_body<HQ, true>(a, red);
-    else attn_bwd_fix_body<HQ, false>(a, red);
+    if (a.g.bf16) attn_bwd_fix_body<HQ, true, PPT>(a, red);
+    else attn_bwd_fix_body<HQ, false, PPT>(a, red);
 }
 
 // --------------------------------------------------------------------------- //
@@ -1052,7 +1051,19 @@ bool axial_bwd_sweep_plan(const AxialGeom& g, int gate_stride, SweepPlan* p) {
     int cap = env_cap / (g.groups * g.G);
     if (cap < 1) cap = 1;
     p->nparts = p->tiles < cap ? p->tiles : cap;
-    p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS * FIX_PPT);
+    // the fix kernel: four positions per thread (four independent load chains) -- or ONE where that leaves fewer than 32 workgroups (the
+    // deep layers of the unets: 2048 positions per group = 2 parts x 8 heads = 16 workgroups of a 14 - 30 us launch; round 6:
+    // gatedaxialunet bs 8 3.885 -> 3.779 ms/step, profiles/r06_fix_ppt_ab.txt.  At 32 workgroups -- MedT's 32 x 32 layers -- the kernel
+    // itself gains, 10.7 -> 7.0 us, and the step does not: the threshold stays below them) and the extra partial rows still fit the
+    // consumer-side finalisation of bn_qkv's backward (<= 256 rows)
+    p->fix_ppt = 4;
+    p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS * 4);
+#ifndef MEDT_AB_FIX_PPT4                // (A/B build: round 5's four positions per thread everywhere)
+    if ((long)g.groups * g.G * p->fparts < 32 && p->nparts + cdiv(g.npg * g.HW, MEDT_THREADS) <= 256) {
+        p->fix_ppt = 1;
+        p->fparts = cdiv(g.npg * g.HW, MEDT_THREADS);
+    }
+#endif
     const int hq = g.hq, np = hq * (hq + 1) / 2;
     p->npg_floats = 2 * (np + hq);
     p->lds = 0;
@@ -1109,10 +1120,16 @@ int axial_attn_bwd_fix(const AxialGeom& g, const SweepPlan& p, const float* qkv_
     a.g = g; a.qkv_raw = qkv_raw; a.sim_coef = sim_coef; a.tables = tables; a.gram = gram; a.qs = qkv; a.gates = gates;
     a.dqkv = dqkv; a.part_qb = part_qb; a.fparts = p.fparts; a.qb_rpg = qb_rpg; a.qb_row0 = p.nparts; a.apply = apply;
     const dim3 grid(g.groups * p.fparts, g.G), block(MEDT_THREADS);
-    if (g.hq == 1) hipLaunchKernelGGL((attn_bwd_fix_kernel<1>), grid, block, 0, s, a);
-    else if (g.hq == 2) hipLaunchKernelGGL((attn_bwd_fix_kernel<2>), grid, block, 0, s, a);
-    else if (g.hq == 4) hipLaunchKernelGGL((attn_bwd_fix_kernel<4>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_fix_kernel<8>), grid, block, 0, s, a);
+#define MEDT_FIX(HQv)                                                                                   \
+    do {                                                                                                \
+        if (p.fix_ppt == 1) hipLaunchKernelGGL((attn_bwd_fix_kernel<HQv, 1>), grid, block, 0, s, a);     \
+        else hipLaunchKernelGGL((attn_bwd_fix_kernel<HQv, 4>), grid, block, 0, s, a);                    \
+    } while (0)
+    if (g.hq == 1) MEDT_FIX(1);
+    else if (g.hq == 2) MEDT_FIX(2);
+    else if (g.hq == 4) MEDT_FIX(4);
+    else MEDT_FIX(8);
+#undef MEDT_FIX
     return launch_status("attn_bwd_fix_kernel");
 }
 

@@ -261,7 +261,8 @@ int axial_attn_bwd(const AxialGeom& g, const float* qkv_raw, BnStats qkv, BnStat
 struct SweepPlan {
     int LS, nw, S_T;        // lanes per sequence, waves per workgroup, sequences per workgroup tile
     int tiles, nparts;      // tiles per BN group, (persistent) workgroups per BN group
-    int fparts;             // 256-position parts per BN group of the fix kernel
+    int fparts;             // parts per BN group of the fix kernel: 256 * fix_ppt positions each
+    int fix_ppt;            // positions per thread of the fix kernel: 4, or 1 where that leaves fewer than 32 workgroups (round 6)
     int npg_floats;         // per-position / per-sequence Gram record: Gq pairs | Sq | Gk pairs | Sk
     size_t lds;
 };
