@@ -349,17 +349,19 @@ __global__ __launch_bounds__(MEDT_THREADS) void bn_act_bwd_small_kernel(SmallBnB
 // channel), 16 values per thread read once (float4), the two sums reduced over the block, dz written from registers.
 // Replaces bn_act_bwd_stats -> bn_bwd_finalize -> bn_bwd_apply (three dependent launches of ~5 us each, whatever the
 // tensor size) on the layer chain; the parameter gradients are produced off the chain by the recorded finalisation.
-template <int TT>
+// (NK float4s per thread: 4 -> populations up to 4 * 4 * TT; round 6: NK = 8 for the 32768-value populations of gatedaxialunet bs 8's and
+//  MedT-256 bs 2's first layers, which took the three-launch path -- 7 x (8.4 + 4.6 + 5.9 us + two boundaries) on the layer chain)
+template <int TT, int NK = 4>
 __global__ __launch_bounds__(TT) void bn_act_bwd_chan_kernel(SmallBnBwdArgs a) {
     MEDT_STATIC_SHARED float red[2 * (TT / 64)];
     const int grp = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     const int HW = a.HW, P = a.npg * HW, gc = grp * a.C + c;
     const float mean = a.st.mean[gc], rstd = a.st.rstd[gc];
-    float4 dv[4], zv[4];
-    size_t at[4];
+    float4 dv[NK], zv[NK];
+    size_t at[NK];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
         const int q = 4 * (tid + k * TT);
         dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         zv[k] = dv[k];
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(TT) void bn_act_bwd_chan_kernel(SmallBnBwdArgs a) {
         c2 = (float)(A * ((double)rstd * (double)mean * m2 - m1));
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
         const int q = 4 * (tid + k * TT);
         if (q < P) {
             float4 o;
@@ -421,12 +423,17 @@ __global__ __launch_bounds__(TT) void bn_act_bwd_chan_kernel(SmallBnBwdArgs a) {
     }
 }
 
-// one workgroup of 256 (population <= 4096) or 1024 threads (<= 16384) per (group, channel); 0: not applicable
+// one workgroup of 256 (population <= 4096) or 1024 threads (<= 16384; <= 32768 with eight float4s per thread) per (group, channel);
+// 0: not applicable
 int bn_chan_threads(const medt_conv_desc& d, int HoWo) {
+#ifdef MEDT_AB_BN_CHAN_16K              // (A/B build: round 5's limit)
     static const int pmax = 16384;
+#else
+    static const int pmax = 32768;
+#endif
     if (!d.has_bn || (HoWo & 3)) return 0;
     const long P = (long)(d.N / d.bn_groups) * HoWo;
-    if (P > pmax || P > 16384) return 0;
+    if (P > pmax) return 0;
     return P <= 4096 ? 256 : 1024;
 }
 
@@ -437,7 +444,8 @@ int bn_act_bwd_chan(const medt_conv_desc& d, const float* dy, const float* y, co
     a.C = d.Cout; a.HW = HoWo; a.npg = d.N / d.bn_groups; a.relu = d.relu; a.training = d.training ? 1 : 0;
     const dim3 grid(d.bn_groups, d.Cout);
     if (bn_chan_threads(d, HoWo) == 256) hipLaunchKernelGGL(bn_act_bwd_chan_kernel<256>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(bn_act_bwd_chan_kernel<1024>, grid, dim3(1024), 0, s, a);
+    else if ((long)a.npg * HoWo <= 16384) hipLaunchKernelGGL(bn_act_bwd_chan_kernel<1024>, grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((bn_act_bwd_chan_kernel<1024, 8>), grid, dim3(1024), 0, s, a);
     return launch_status("bn_act_bwd_chan");
 }
 

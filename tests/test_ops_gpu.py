@@ -89,6 +89,10 @@ CONV_CASES = [
     (32, 32, 1, 1, 0, False, True, False, True, 64, 16, 16),    # layer2_p.0 conv_down
     (32, 64, 1, 2, 0, False, True, False, False, 64, 16, 16),   # layer2_p.0 downsample (stride 2, 256 output positions)
     (64, 128, 1, 2, 0, False, True, False, False, 64, 8, 16),   # layer3_p.0 downsample (stride 2, 64 output positions)
+    # round 6: 32768-value BatchNorm populations (gatedaxialunet bs 8 at 64 x 64, MedT-256 bs 2 at 128 x 128) on the one-launch backward
+    # (bn_act_bwd_chan_kernel<1024, 8>: eight float4s per thread) instead of statistics -> finalisation -> application
+    (8, 16, 1, 1, 0, False, True, False, True, 8, 64, 1),       # layer1.0 conv_down of gatedaxialunet at bs 8
+    (16, 8, 1, 1, 0, False, True, True, True, 2, 128, 1),       # the same population from 2 images of 128 x 128, with the identity
 ]
 
 
