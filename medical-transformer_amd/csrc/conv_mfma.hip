@@ -1054,6 +1054,37 @@ int conv_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, hipSt
     return launch_status("flip_weights");
 }
 
+// The recorded flips of a flush in ONE launch (round 6: a flush of the forward pass issued 4 - 6 of them back to back, ~5 us + a boundary each --
+// on the layer chain itself in the single-stream networks)
+using FBatchW = JobBatch<FlipJob, 96>;
+__global__ __launch_bounds__(MEDT_THREADS) void flip_weights_grouped_kernel(FBatchW b) {
+    const int j = find_job(b, blockIdx.x);
+    const FlipJob& f = b.job[j];
+    const int KK = f.K * f.K;
+    const int idx = (blockIdx.x - b.start[j]) * MEDT_THREADS + threadIdx.x;
+    if (idx >= f.Cout * f.Cin * KK) return;
+    const int t = idx % KK, c = (idx / KK) % f.Cin, o = idx / (KK * f.Cin);
+    f.wt[((size_t)c * f.Cout + o) * KK + (KK - 1 - t)] = f.w[idx];
+}
+
+int conv_flip_weights_grouped(const FlipJob* jobs, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 96) {
+        FBatchW b;
+        b.n = n - i0 < 96 ? n - i0 : 96;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.job[i] = jobs[i0 + i];
+            b.start[i] = blocks;
+            blocks += cdiv(jobs[i0 + i].Cout * jobs[i0 + i].Cin * jobs[i0 + i].K * jobs[i0 + i].K, MEDT_THREADS);
+        }
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(flip_weights_grouped_kernel, dim3(blocks), dim3(MEDT_THREADS), 0, s, b);
+        int rc = launch_status("flip_weights_grouped");
+        if (rc) return rc;
+    }
+    return MEDT_OK;
+}
+
 // wt_ready: the flipped weights already sit in wt_scratch (round 5: the TRAINING forward pass leaves them behind the layer's saved
 // statistics -- recorded for the forward's grouped flush, off the backward chain; medt_api.hip)
 int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,

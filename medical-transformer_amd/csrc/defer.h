@@ -92,6 +92,7 @@ Queue* queue_for(hipStream_t s);     // the queue bound to this stream, or nullp
 BnFin make_fin(const float* partials, int ppg, int CH, double count, const medt_bn_ptrs& bn, BnStats out);
 
 // grouped launchers (each may issue several launches when the job table exceeds one kernel-argument block)
+int conv_flip_weights_grouped(const FlipJob* jobs, int n, hipStream_t s);     // conv_mfma.hip
 int bn_finalize_grouped(const FinJob* jobs, int n, hipStream_t s);
 int bn_bwd_finalize_grouped(const BfinJob* jobs, int n, hipStream_t s);
 int wopos_small_bwd_finalize_grouped(const SmallFinArgs* jobs, int n, hipStream_t s);

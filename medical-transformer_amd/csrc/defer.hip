@@ -86,8 +86,12 @@ static int queue_flush(Queue& q, hipStream_t s, hipStream_t aux) {
         if (hipEventRecord(ev[1], aux) != hipSuccess) { set_error("queue flush: event join failed"); return MEDT_ELAUNCH; }
     }
     // order: statistics bookkeeping; first-stage sums and weight gradients; then the reductions of their partial slabs
+#ifdef MEDT_AB_FLIP_EACH                // (A/B build: one launch per recorded flip)
     for (const FlipJob& f : q.flip)
         if (!rc) rc = conv_flip_weights(f.w, f.wt, f.Cout, f.Cin, f.K, s);
+#else
+    if (!rc && !q.flip.empty()) rc = conv_flip_weights_grouped(q.flip.data(), (int)q.flip.size(), s);
+#endif
     if (!rc && !q.fin.empty()) rc = bn_finalize_grouped(q.fin.data(), (int)q.fin.size(), s);
     if (!rc && !q.bfin.empty()) rc = bn_bwd_finalize_grouped(q.bfin.data(), (int)q.bfin.size(), s);
     if (!rc && !q.sfin.empty()) rc = wopos_small_bwd_finalize_grouped(q.sfin.data(), (int)q.sfin.size(), s);

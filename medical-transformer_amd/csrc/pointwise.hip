@@ -681,9 +681,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
                                                                            int W, int OC, int stride, int npg, int bf16, TablesJob tj,
                                                                            const float* __restrict__ ymask) {
     MEDT_STATIC_SHARED float red[MEDT_WAVES * 2];
-    if (blockIdx.y == 0 && (int)blockIdx.x < tj.blocks) {        // (fin_inline.h: the fix kernel's tables, no launch of their own)
+    // (fin_inline.h: the fix kernel's tables, no launch of their own -- the launch's first tj.blocks workgroups in (y, x) order: round 6,
+    //  so that the deep layers fit too: 28 / 88 table blocks for hq = 4 / 8 on a grid of 8 x 256)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin < tj.blocks) {
         MEDT_STATIC_SHARED float tl[512];
-        sim_tables_block(blockIdx.x, tj.relative, tj.tables, tj.HQ, tj.L, tl);
+        sim_tables_block(lin, tj.relative, tj.tables, tj.HQ, tj.L, tl);
     }
     const int HW = H * W, Ho = H / stride, Wo = W / stride;
     const int per_group = npg * HW, ppg = (per_group + MEDT_THREADS - 1) / MEDT_THREADS;
@@ -708,7 +711,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void axial_out_bwd_stats_kernel(const
 }
 
 bool axial_out_bwd_stats_tables_ok(const medt_axial_desc& d, int blocks, int L) {
+#ifdef MEDT_AB_TABLES_X                 // (A/B build: the table blocks in the grid's first row only)
     return blocks <= d.bn_groups * cdiv((d.N / d.bn_groups) * d.H * d.W, MEDT_THREADS) && L <= 128;
+#else
+    const long OC = d.has_pos ? 2 * d.C : d.C;
+    return blocks <= (long)d.bn_groups * cdiv((d.N / d.bn_groups) * d.H * d.W, MEDT_THREADS) * OC && L <= 128;
+#endif
 }
 
 int axial_out_bwd_stats(const medt_axial_desc& d, const float* stacked, const float* dy, BnStats st, float* partials,
