@@ -527,6 +527,16 @@ ThinPlan conv_thin_plan(int N, int groups, int Cin, int H, int W, int Cout, int 
         }
     }
     if (best_wgs < 0) return p;
+#ifndef MEDT_AB_THIN_TR                 // (A/B build: without this rule)
+    // Round 6: a DEEP contraction (>= 4 chunks of 16 channels: conv3 128 -> 8, conv2's backward-data) wants one row per wave + K-groups
+    // even where two rows per wave already give a workgroup per CU -- the rule above was tuned on 4 images; at 8 images of 64 x 64
+    // (gatedaxialunet bs 8) and 2 of 128 x 128 (MedT-256 bs 2) it picked <16,1,2,1>: 256 four-wave workgroups walking 8 chunks at a
+    // global round trip + two barriers each, 55 - 58 us for the 0.6 GFLOP that take 22 us at 4 images with KG = 4
+    if (p.CC == 16 && Cin / 16 >= 4 && best_tr > 1 && H % p.RG == 0 && !force_tr) {
+        const long w1 = (long)N * (H / p.RG) * (W / (16 * p.TCW)) * cdiv(rbs, best_nrb);
+        if (w1 <= 512) { best_tr = 1; best_wgs = w1; }
+    }
+#endif
     p.TR = best_tr; p.NRB = best_nrb;
     p.rows_wg = p.RG * p.TR; p.cols_wg = 16 * p.TCW;
     p.RST = p.cols_wg + 2;

@@ -93,6 +93,10 @@ CONV_CASES = [
     # (bn_act_bwd_chan_kernel<1024, 8>: eight float4s per thread) instead of statistics -> finalisation -> application
     (8, 16, 1, 1, 0, False, True, False, True, 8, 64, 1),       # layer1.0 conv_down of gatedaxialunet at bs 8
     (16, 8, 1, 1, 0, False, True, True, True, 2, 128, 1),       # the same population from 2 images of 128 x 128, with the identity
+    # round 6: deep thin contractions at 8 images of 64 x 64 / 2 of 128 x 128: one row per wave + four K-groups (conv_thin_plan's rule for >= 4 chunks)
+    (128, 8, 3, 1, 1, False, True, False, True, 8, 64, 1),      # conv3 of gatedaxialunet at bs 8 (forward <16,1,1,4> on 512 workgroups)
+    (8, 128, 3, 1, 1, False, True, False, True, 8, 64, 1),      # conv2 at bs 8 (its backward-data is the deep one)
+    (128, 8, 3, 1, 1, False, True, False, True, 2, 128, 1),     # conv3 of MedT-256 at bs 2
 ]
 
 
