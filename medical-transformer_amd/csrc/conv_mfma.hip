@@ -995,7 +995,13 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
 
 // number of K slices for a problem with `tiles` output tiles (1 = no split)
 int conv_mfma_ksplit(int Ktot, long tiles) {
+#ifdef MEDT_AB_KSPLIT128                // (A/B build: no split from 128 tiles on)
     if (tiles >= 128) return 1;
+#else
+    // (round 6: 128 ... 255 tiles -- decoder4 of gatedaxialunet at bs 8: 128 workgroups walking 36 k-steps, 44 us on half the CUs -- split in two)
+    if (tiles >= 256) return 1;
+    if (tiles >= 128) return Ktot >= 256 ? 2 : 1;
+#endif
     int ks = (int)(256 / tiles);
     const int maxks = Ktot / 64 > 0 ? Ktot / 64 : 1;          // at least 64 k (4 LDS steps) per slice
     if (ks > maxks) ks = maxks;

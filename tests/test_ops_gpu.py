@@ -97,6 +97,8 @@ CONV_CASES = [
     (128, 8, 3, 1, 1, False, True, False, True, 8, 64, 1),      # conv3 of gatedaxialunet at bs 8 (forward <16,1,1,4> on 512 workgroups)
     (8, 128, 3, 1, 1, False, True, False, True, 8, 64, 1),      # conv2 at bs 8 (its backward-data is the deep one)
     (128, 8, 3, 1, 1, False, True, False, True, 2, 128, 1),     # conv3 of MedT-256 at bs 2
+    (64, 32, 3, 1, 1, True, False, False, False, 8, 32, 1),     # decoder4 at bs 8: 128 MFMA tiles -> split in two k-slices (round 6)
+    (64, 48, 3, 1, 1, False, True, False, True, 8, 32, 1),      # the same tile count with BatchNorm (statistics from the split-K epilogue)
 ]
 
 
