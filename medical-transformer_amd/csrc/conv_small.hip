@@ -270,7 +270,14 @@ bool conv_small_ok(const medt_conv_desc& d) {
     if (d.stride < 1 || d.H % d.stride || d.W % d.stride) return false;
     if ((d.Cin & 15) || (d.Cout % SC_NOC_MAX)) return false;
     const int P = (d.N / d.bn_groups) * (d.H / d.stride) * (d.W / d.stride);
-    return P <= 1024 && conv_small_noc(P, d.Cin) != 0;
+    if (!(P <= 1024 && conv_small_noc(P, d.Cin) != 0)) return false;
+#ifndef MEDT_AB_SMALL_ANYGRID           // (A/B build: without this rule)
+    // (round 6: the kernels are one workgroup per (BatchNorm group, 16 output channels) -- built for the 16 patch groups of MedT's local
+    //  branch.  With ONE group (layer4 of the unets: 4 x 4 maps, 256 -> 256 channels) that is 16 workgroups walking the whole contraction,
+    //  23 - 28 us against ~12 for convolution + bn_fin_apply on the whole chip)
+    if ((long)d.bn_groups * (d.Cout / conv_small_noc(P, d.Cin)) < 32) return false;
+#endif
+    return true;
 }
 
 int conv_small_fwd(const medt_conv_desc& d, const float* x, const float* w, const medt_bn_ptrs& bn, const float* res,
