@@ -274,8 +274,9 @@ bool conv_small_ok(const medt_conv_desc& d) {
 #ifndef MEDT_AB_SMALL_ANYGRID           // (A/B build: without this rule)
     // (round 6: the kernels are one workgroup per (BatchNorm group, 16 output channels) -- built for the 16 patch groups of MedT's local
     //  branch.  With ONE group (layer4 of the unets: 4 x 4 maps, 256 -> 256 channels) that is 16 workgroups walking the whole contraction,
-    //  23 - 28 us against ~12 for convolution + bn_fin_apply on the whole chip)
-    if ((long)d.bn_groups * (d.Cout / conv_small_noc(P, d.Cin)) < 32) return false;
+    //  23 - 28 us against ~12 for convolution + bn_fin_apply on the whole chip.  Only the one-group case: the patch groups of the local branch
+    //  keep these kernels at every batch size)
+    if (d.bn_groups == 1 && d.Cout / conv_small_noc(P, d.Cin) < 32) return false;
 #endif
     return true;
 }
