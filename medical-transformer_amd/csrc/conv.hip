@@ -134,19 +134,19 @@ int conv_parts_per_group(int N, int groups, int HoWo, int Cin, int Cout, int K, 
         return conv_thin_parts_per_group(N, groups, Cin, H, W, Cout, K, stride, pad);
     if (conv_fwd_ws_ok(Cin, Cout, K, stride, (long)N * HoWo)) return cdiv((N / groups) * HoWo, 64);
     if (!conv_use_mfma(Cin, Cout, K, stride, (long)N * HoWo)) return conv2d_parts_per_group(N, groups, HoWo);
-    if (conv_mfma_scratch_floats(N, groups, HoWo, Cin, Cout, K) > 0) return conv2d_parts_per_group(N, groups, HoWo);
+    if (conv_mfma_scratch_floats(N, groups, HoWo, Cin, Cout, K, H > 0 && conv_rows16_ok(Cin, H, W, K, stride, pad)) > 0) return conv2d_parts_per_group(N, groups, HoWo);
     return conv_mfma_parts_per_group(N, groups, HoWo);
 }
 
 size_t conv2d_fwd_scratch_floats(int N, int groups, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     if (!conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo)) return 0;
-    return conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K);
+    return conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K, conv_rows16_ok(Cin, H, W, K, stride, pad));
 }
 
 size_t conv2d_bwd_data_scratch_floats(int N, int Cin, int H, int W, int Cout, int K, int stride, int pad) {
     if (stride != 1 || K - 1 - pad < 0 || !conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W)) return 0;
-    return conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K);
+    return conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K, conv_rows16_ok(Cout, H, W, K, 1, K - 1 - pad));
 }
 
 // Deep contraction, narrow output (conv3 128 -> 8 at 64 x 64, the decoders' 64 -> 32 and 128 -> 64 on small maps): in
@@ -286,7 +286,7 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, floa
     if (!y_bf16 && conv_stem7_ok(Cin, H, W, Cout, K, stride, pad))        // (medt_api.hip sizes the partial sums for it: conv_geom)
         return conv_stem7_fwd(x, w, bias, y, partials, N, H, W, Cout, relu, s);
     if (!y_bf16 && conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) &&
-        (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K) == 0))
+        (scratch || conv_mfma_scratch_floats(N, groups, Ho * Wo, Cin, Cout, K, conv_rows16_ok(Cin, H, W, K, stride, pad)) == 0))
         return conv_mfma_fwd(x, w, bias, y, partials, scratch, N, Cin, H, W, Cout, K, stride, pad, relu, groups, s);
     // thin-channel 3x3 layers (Cout < 32 or Cin * 9 < 256: refused above) on the LDS-patch MFMA kernel of round 6
     if (!y_bf16 && (conv_thin_mode() & 1) && !conv_use_mfma(Cin, Cout, K, stride, (long)N * Ho * Wo) && conv_thin_ok(N, groups, Cin, H, W, Cout, K, stride, pad))
@@ -568,7 +568,7 @@ int conv2d_bwd_data(const float* dy, const float* w, float* dx, float* wt_scratc
     }
     // (the `add` epilogue: thin kernel above and the VALU path only)
     if (!add && wt_scratch && conv_use_mfma(Cout, Cin, K, 1, (long)N * H * W) && conv2d_bwd_data_flips(N, Cin, H, W, Cout, K, stride, pad) &&
-        (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K) == 0))
+        (ksplit_scratch || conv_mfma_scratch_floats(N, 1, H * W, Cout, Cin, K, conv_rows16_ok(Cout, H, W, K, 1, K - 1 - pad)) == 0))
         return conv_mfma_bwd_data_s1(dy, w, wt_scratch, ksplit_scratch, dx, N, Cin, H, W, Cout, K, pad, s, wt_ready);
     switch (K) {
         case 1: return conv2d_bwd_data_k<1>(dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, stride, pad, s, add);

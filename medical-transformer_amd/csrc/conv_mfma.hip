@@ -994,12 +994,13 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv_splitk_epilogue_kernel(
 }
 
 // number of K slices for a problem with `tiles` output tiles (1 = no split)
-int conv_mfma_ksplit(int Ktot, long tiles) {
+int conv_mfma_ksplit(int Ktot, long tiles, bool rows16) {
 #ifdef MEDT_AB_KSPLIT128                // (A/B build: no split from 128 tiles on)
     if (tiles >= 128) return 1;
 #else
-    // (round 6: 128 ... 255 tiles -- decoder4 of gatedaxialunet at bs 8: 128 workgroups walking 36 k-steps, 44 us on half the CUs -- split in two)
-    if (tiles >= 256) return 1;
+    // (round 6: 128 ... 255 tiles -- decoder4 of gatedaxialunet at bs 8: 128 workgroups walking 36 k-steps, 44 us on half the CUs -- split in two;
+    //  NOT on the 16-wide maps, where the unsplit problem takes the LDS-patch kernel: conv3_p of MedT-256 at bs 2 is such a case)
+    if (tiles >= 256 || (rows16 && tiles >= 128)) return 1;
     if (tiles >= 128) return Ktot >= 256 ? 2 : 1;
 #endif
     int ks = (int)(256 / tiles);
@@ -1008,9 +1009,9 @@ int conv_mfma_ksplit(int Ktot, long tiles) {
     return ks < 1 ? 1 : ks;
 }
 
-size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, int K) {
+size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, int K, bool rows16) {
     const long qt = (long)groups * conv_mfma_parts_per_group(N, groups, HoWo);
-    const int ks = conv_mfma_ksplit(Cin * K * K, qt * cdiv(Cout, 64));
+    const int ks = conv_mfma_ksplit(Cin * K * K, qt * cdiv(Cout, 64), rows16);
     return ks > 1 ? (size_t)ks * qt * 64 * Cout : 0;
 }
 
@@ -1019,7 +1020,7 @@ int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, f
     const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
     const int ppg64 = conv_mfma_parts_per_group(N, groups, Ho * Wo), Ktot = Cin * K * K;
     const long qt = (long)groups * ppg64;
-    int ks = scratch ? conv_mfma_ksplit(Ktot, qt * cdiv(Cout, 64)) : 1;
+    int ks = scratch ? conv_mfma_ksplit(Ktot, qt * cdiv(Cout, 64), conv_rows16_ok(Cin, H, W, K, stride, pad)) : 1;
     int kchunk = Ktot;
     if (ks > 1) {
         kchunk = cdiv(cdiv(Ktot, ks), 16) * 16;

@@ -95,7 +95,8 @@ int channel_sum(const float* x, float* out, float* scratch /* 16*C floats */, in
 bool conv_use_mfma(int Cin, int Cout, int K, int stride, long positions);
 int conv_mfma_parts_per_group(int N, int groups, int HoWo);
 // scratch: conv_mfma_scratch_floats() floats when the split-K variant may run (NULL forbids it)
-size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, int K);
+bool conv_rows16_ok(int Cin, int H, int W, int K, int stride, int pad);          // conv_mfma.hip: the LDS-patch kernels of the 16-wide maps
+size_t conv_mfma_scratch_floats(int N, int groups, int HoWo, int Cin, int Cout, int K, bool rows16 = false);   // rows16: conv_rows16_ok() of the problem
 int conv_mfma_fwd(const float* x, const float* w, const float* bias, float* y, float* partials, float* scratch, int N,
                   int Cin, int H, int W, int Cout, int K, int stride, int pad, int relu, int groups, hipStream_t s);
 int conv_mfma_bwd_data_s1(const float* dy, const float* w, float* wt_scratch, float* ksplit_scratch, float* dx, int N,
