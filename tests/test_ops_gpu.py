@@ -99,6 +99,8 @@ CONV_CASES = [
     (128, 8, 3, 1, 1, False, True, False, True, 2, 128, 1),     # conv3 of MedT-256 at bs 2
     (64, 32, 3, 1, 1, True, False, False, False, 8, 32, 1),     # decoder4 at bs 8: 128 MFMA tiles -> split in two k-slices (round 6)
     (64, 48, 3, 1, 1, False, True, False, True, 8, 32, 1),      # the same tile count with BatchNorm (statistics from the split-K epilogue)
+    (256, 256, 3, 2, 1, True, False, False, False, 64, 2, 1),   # decoder1_p at BASELINE size: stride 2 on 2 x 2 maps (staged wave-split backward-data, 4 of 9 taps live)
+    (256, 256, 3, 2, 1, True, False, False, False, 8, 4, 1),    # decoder1 of the unets at bs 8: 4 x 4 -> 2 x 2 (every tap live somewhere)
 ]
 
 
