@@ -372,7 +372,10 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_kernel(
 // would each walk all Cout output channels serially -- a chain of Cout/4 dependent global round trips (round 2: 78 us
 // for decoder1_p's 67 MFLOP).  Here a workgroup owns 64 positions, its four waves split the o-contraction and combine
 // through LDS (fixed order), and the loop keeps 8-16 channels' loads in flight.
-template <int K, int CT>
+// TM: the taps (bit t = 3 kh + kw) that ANY input pixel of the geometry uses -- compile-time, so dead taps cost nothing: a stride-2 layer on
+// 2 x 2 maps (decoder1_p) meets its single output pixel through the four taps (1..2, 1..2) only (round 6; as a run-time mask behind
+// uniform branches the same idea was SLOWER, 49.6 vs 28.2 us: the unrolled tap loop lost its shape)
+template <int K, int CT, int TM = (1 << (K * K)) - 1>
 __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin, int H, int W,
     int Cout, int Ho, int Wo, int stride, int pad, const float* __restrict__ add, int stage_dy) {
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
     const int HW = H * W;
     const long q = (long)blockIdx.x * 64 + lane;
     const int c0 = blockIdx.y * CT;
-    {
+    if constexpr (TM == (1 << KK) - 1) {
         const int nw = Cout * CT * KK;
         for (int e0 = threadIdx.x; e0 < nw; e0 += 8 * MEDT_THREADS) {            // 8 loads in flight per lane
             float v[8];
@@ -398,6 +401,29 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (e0 + u * MEDT_THREADS < nw) wl[e0 + u * MEDT_THREADS] = v[u];
+        }
+    } else {
+        // only the live taps of the slice are staged (same LDS layout, the dead slots are never read)
+        constexpr int NL = __builtin_popcount((unsigned)TM);
+        const int nw = Cout * CT * NL;
+        for (int e0 = threadIdx.x; e0 < nw; e0 += 8 * MEDT_THREADS) {
+            float v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * MEDT_THREADS, nw - 1), oc = e / NL, tl = e - oc * NL;
+                int t = 0, seen = 0;                                              // the tl-th set bit of TM
+#pragma unroll
+                for (int b = 0; b < KK; ++b)
+                    if ((TM >> b) & 1) { if (seen == tl) t = b; ++seen; }
+                const int o = oc / CT, c = oc - o * CT;
+                dst[u] = oc * KK + t;
+                v[u] = w[((size_t)o * Cin + c0 + c) * KK + t];
+            }
+            MEDT_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * MEDT_THREADS < nw) wl[dst[u]] = v[u];
         }
     }
     float* dl = wl + Cout * CT * KK;
@@ -452,12 +478,12 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
 #pragma unroll
             for (int u = 0; u < UU; ++u)
 #pragma unroll
-                for (int t = 0; t < KK; ++t) dr[u][t] = dln[(o + u) * HoWo + max(off[t], 0)];
+                for (int t = 0; t < KK; ++t) dr[u][t] = ((TM >> t) & 1) ? dln[(o + u) * HoWo + max(off[t], 0)] : 0.f;
         } else {
 #pragma unroll
             for (int u = 0; u < UU; ++u)
 #pragma unroll
-                for (int t = 0; t < KK; ++t) dr[u][t] = dyn[(size_t)(o + u) * HoWo + max(off[t], 0)];
+                for (int t = 0; t < KK; ++t) dr[u][t] = ((TM >> t) & 1) ? dyn[(size_t)(o + u) * HoWo + max(off[t], 0)] : 0.f;
             MEDT_SCHED_FENCE();
         }
 #pragma unroll
@@ -469,7 +495,8 @@ __global__ __launch_bounds__(MEDT_THREADS) void conv2d_bwd_data_ws_kernel(
             for (int c = 0; c < CT; ++c) {
                 const float* wp = wl + ((o + u) * CT + c) * KK;
 #pragma unroll
-                for (int t = 0; t < KK; ++t) acc[c] = fmaf(wp[t], dv[t], acc[c]);
+                for (int t = 0; t < KK; ++t)
+                    if ((TM >> t) & 1) acc[c] = fmaf(wp[t], dv[t], acc[c]);
             }
         }
         MEDT_SCHED_FENCE();
@@ -509,10 +536,33 @@ static int conv2d_bwd_data_k(const float* dy, const float* w, float* dx, int N, 
             // images one 64-position workgroup can touch, and their output gradient in floats
             const int imgs = H * W >= 64 ? 2 : 64 / (H * W) + 1;
             const size_t dy_floats = (size_t)imgs * (Cout * Ho * Wo + 1);
+            // the taps any input pixel uses (see the kernel's TM)
+            int tmask = 0;
+            if (K == 3)
+                for (int h = 0; h < H && h < 8; ++h)
+                    for (int ww = 0; ww < W && ww < 8; ++ww)
+                        for (int t = 0; t < 9; ++t) {
+                            const int hh = h + pad - t / 3, wq = ww + pad - t % 3;
+                            if (hh >= 0 && wq >= 0 && hh % stride == 0 && wq % stride == 0 && hh / stride < Ho && wq / stride < Wo) tmask |= 1 << t;
+                        }
+#ifdef MEDT_AB_DGRAD_ALLTAPS             // (A/B build: every tap)
+            tmask = 0x1ff;
+#endif
+            const bool four = K == 3 && H <= 8 && W <= 8 && tmask == 0x1b0;
 #define MEDT_LAUNCH_WS(CT)                                                                                           \
-    hipLaunchKernelGGL((conv2d_bwd_data_ws_kernel<K, CT>), dim3(g64, Cin / CT), dim3(MEDT_THREADS),                   \
-                       ((size_t)Cout * CT * K * K + (stage ? dy_floats : 0)) * sizeof(float), s, dy, w, dx, N, Cin, H, W, \
-                       Cout, Ho, Wo, stride, pad, add, stage)
+    do {                                                                                                             \
+        if constexpr (K == 3) {                                                                                      \
+            if (four) {                                                                                              \
+                hipLaunchKernelGGL((conv2d_bwd_data_ws_kernel<K, CT, 0x1b0>), dim3(g64, Cin / CT), dim3(MEDT_THREADS), \
+                                   ((size_t)Cout * CT * K * K + (stage ? dy_floats : 0)) * sizeof(float), s, dy, w, dx, N, Cin, H, W, \
+                                   Cout, Ho, Wo, stride, pad, add, stage);                                          \
+                break;                                                                                               \
+            }                                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL((conv2d_bwd_data_ws_kernel<K, CT>), dim3(g64, Cin / CT), dim3(MEDT_THREADS),               \
+                           ((size_t)Cout * CT * K * K + (stage ? dy_floats : 0)) * sizeof(float), s, dy, w, dx, N, Cin, H, W, \
+                           Cout, Ho, Wo, stride, pad, add, stage);                                                  \
+    } while (0)
             int ct = pick_tile(Cin, K == 1 ? 8 : 4, g64);
             while (ct > 1 && (size_t)Cout * ct * K * K * sizeof(float) > 48 * 1024) ct >>= 1;
             if ((size_t)Cout * ct * K * K * sizeof(float) > 48 * 1024) ct = 0;          // does not fit: the kernel below
